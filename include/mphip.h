@@ -1,0 +1,129 @@
+/*
+ * mphip.h — C ABI of libmphip.so: the MI355X (gfx950) kernels behind the MegaPortraits
+ * Gbase hot slice (reference: johndpope/MegaPortrait-hack model.py:1151-1171).
+ *
+ * The reference has no native code and no FFI: its hot path is Python calling PyTorch ATen
+ * ops.  Every entry point below therefore replaces an ATen call site (or a short run of
+ * them) of model.py, cited per function; the reference-side binding a maintainer would add
+ * is the ctypes stub shown in INTEGRATION.md (and implemented for real in
+ * megaportrait-hack_amd/_lib.py).
+ *
+ * Conventions
+ *  - Plain C: pointers are DEVICE pointers (HBM) unless named host_*; sizes are ints.
+ *    No torch types.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ *  - Tensors are float32, contiguous, NCDHW (N,C,D,H,W), exactly the layout the reference's
+ *    modules exchange (model.py:271 defines the volume layout: channel c*16+d -> (c,d)).
+ *  - Every function returns 0 on success or a negative MPHIP_E* code, never throws, never
+ *    allocates device memory, never synchronises the stream.  Work is stream-ordered;
+ *    borrowed pointers must stay valid until the stream reaches the end of the call's work.
+ *    mphip_last_error() returns a thread-local message for the last failing call.
+ *  - Scratch memory is caller-supplied: query with the matching *_workspace_bytes().
+ */
+#ifndef MPHIP_H
+#define MPHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MPHIP_OK 0
+#define MPHIP_EINVAL (-1)   /* bad argument (shape, null pointer, unsupported size) */
+#define MPHIP_ELAUNCH (-2)  /* hipLaunchKernel / runtime error, see mphip_last_error() */
+#define MPHIP_EWORKSPACE (-3) /* workspace too small */
+
+int mphip_version(void);
+const char *mphip_last_error(void);
+
+/* ------------------------------------------------------------------ K0  rigid transform
+ * Replaces compute_rotation_matrix + the 4x4 assembly + torch.inverse of compute_rt_warp,
+ * model.py:790-801 and 811-856: rotation [B,3] Euler degrees (x,y,z), translation [B,3] ->
+ * theta [B,3,4] = first three rows of A=[R|t;0 0 0 1] (R = Rx@(Ry@Rz)), inverted when
+ * invert != 0 (WarpGeneratorS2C, model.py:965).  On the device so the forward has no host sync. */
+int mphip_rt_theta(const float *rotation_deg, const float *translation, float *theta, int B, int invert,
+                   void *stream);
+
+/* ------------------------------------------------------------------ K1  warp field compose
+ * Replaces model.py:965-973 / 1016-1022 (inside WarpGeneratorS2C/C2D.forward):
+ *   F.affine_grid(theta,(B,1,G,G,G),align_corners=False).permute(0,4,1,2,3)       [:804-806]
+ * + F.interpolate(em,(G,G,G),'trilinear',align_corners=False)                      [:971]
+ * theta [B,3,4] (already inverted for S2C), em [B,3,eD,eH,eW], base_tbl[G] =
+ * torch.linspace(-1,1,G)*(G-1)/G built on the host -> w [B,3,G,G,G].
+ * If rt_out / em_out are non-NULL the two addends are also written (same shape) for tests. */
+int mphip_warp_field_compose(const float *theta, const float *em, const float *base_tbl, float *w,
+                             float *rt_out, float *em_out, int B, int eD, int eH, int eW, int G,
+                             void *stream);
+
+/* ------------------------------------------------------------------ K2  volumetric warp
+ * Replaces apply_warping_field(v, warp_field), model.py:1028-1065:
+ *   F.interpolate(field,(D,H,W),'trilinear',align_corners=True) + linspace identity grid
+ *   + 2*g/(S-1)-1 + F.grid_sample(v, grid, 'bilinear', 'border', align_corners=True).
+ * v [B,C,D,H,W], field [B,3,fD,fH,fW], lin_d/h/w = torch.linspace(-1,1,S) host-built tables
+ * on the device -> out [B,C,D,H,W].  Optional (may be NULL) debug outputs for the bit-exact
+ * index contract: coords_out [B,D,H,W,3] float (clipped x,y,z), idx_out [B,D,H,W,3] int32. */
+int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                      const float *lin_w, float *out, float *coords_out, int32_t *idx_out, int B, int C,
+                      int D, int H, int W, int fD, int fH, int fW, void *stream);
+
+/* ------------------------------------------------------------------ K3  warp + depth projection
+ * Replaces apply_warping_field (model.py:1167) fused with torch.sum(dim=2) (model.py:1171):
+ * out [B,C,H,W] = sum_d warp(v, field)[b,c,d,h,w]; the warped volume is never written.     */
+int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                           const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
+                           int fH, int fW, void *stream);
+
+/* ------------------------------------------------------------------ K4/K5  Conv3d k=3 / k=1
+ * Replaces nn.Conv3d(Ci,Co,3,padding=1) (model.py:505,507,591,374-375,458) and
+ * nn.Conv3d(Ci,Co,1) / nn.Conv2d 1x1 (model.py:510,380,446) — stride 1, bias.
+ * Weights are used in a packed layout built once per weight version:
+ *   mphip_pack_conv_weight: OIDHW [Co,Ci,k,k,k] -> [k^3][CiP][CoP] (CoP = Co rounded up to 32,
+ *   CiP = Ci rounded up to 2, zero padded); size from mphip_packed_weight_elems().
+ * precision: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).
+ * x [N,Ci,D,H,W] -> y [N,Co,D,H,W].  workspace: mphip_conv3d_workspace_bytes() (split-K
+ * partial sums for small volumes; 0 when not needed).                                    */
+size_t mphip_packed_weight_elems(int Co, int Ci, int k);
+int mphip_pack_conv_weight(const float *w_oidhw, float *w_packed, int Co, int Ci, int k, void *stream);
+size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
+int mphip_conv3d_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int Ci,
+                     int Co, int D, int H, int W, int k, int precision, void *workspace,
+                     size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------ K6  GroupNorm
+ * Replaces nn.GroupNorm(G,C) eps=1e-5 (model.py:506,508,460,309) and what the reference
+ * applies right after it.  Two steps so the global per-(sample,group) reduction is explicit:
+ *  stats: x [N,C,S] -> stats [N*G][2] = (mean, rstd), biased variance.
+ *         workspace: mphip_groupnorm_workspace_bytes(N,C,S,G).
+ *  apply: y = (x-mean)*rstd*gamma[c]+beta[c];  if w2: y = y*w2[c]+b2[c]  (AdaptiveGroupNorm,
+ *         model.py:314-316);  if residual: y += residual  (model.py:522);  if relu: max(y,0)
+ *         (model.py:517,523);  if tanh_: y = tanh(y) after relu (model.py:462-465).
+ *         pool2 != 0 additionally averages 2x2x2 cells (nn.AvgPool3d(2,2), model.py:576-580):
+ *         then y is [N,C,D/2,H/2,W/2] and D,H,W must be given (S = D*H*W).                 */
+size_t mphip_groupnorm_workspace_bytes(int N, int C, int S, int G);
+int mphip_groupnorm_stats(const float *x, float *stats, int N, int C, int S, int G, float eps,
+                          void *workspace, size_t workspace_bytes, void *stream);
+int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,
+                          const float *w2, const float *b2, const float *residual, float *y, int N, int C,
+                          int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream);
+
+/* ------------------------------------------------------------------ K7  resampling
+ * avgpool2:            nn.AvgPool3d(2,2)                                   (model.py:576-580)
+ * upsample_trilinear2: nn.Upsample(scale_factor=2,'trilinear',align_corners=True) (:585-589)
+ * upsample_nearest:    nn.Upsample(scale_factor=(sD,sH,sW)) default nearest (:427-433)   */
+int mphip_avgpool2(const float *x, float *y, int NC, int D, int H, int W, void *stream);
+int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D, int H, int W, void *stream);
+int mphip_upsample_nearest(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW,
+                           void *stream);
+
+/* ------------------------------------------------------------------ K8  small head ops
+ * mphip_add_matmul: out[b,n] = sum_k (a[b,k]+a2[b,k]) * m[k,n]   — (z+e) @ Gamma, model.py:945-957
+ *                   (a2 may be NULL; trans!=0 uses m[n,k] and adds bias[n]: the 1x1 Conv2d on a
+ *                   1x1 map at model.py:446).                                              */
+int mphip_add_matmul(const float *a, const float *a2, const float *m, const float *bias, float *out, int B,
+                     int K, int N, int trans, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPHIP_H */

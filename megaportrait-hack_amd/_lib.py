@@ -1,0 +1,83 @@
+"""ctypes binding of libmphip.so (C ABI declared in include/mphip.h).
+
+This is the only way the Python host reaches the HIP kernels: device pointers come from
+`torch.Tensor.data_ptr()`, the stream from `torch.cuda.current_stream()`.  There is NO CPU
+fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmphip.so")
+BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as raw addresses
+_i = ctypes.c_int
+_sz = ctypes.c_size_t
+_p = ctypes.c_void_p
+
+# name -> (restype, argtypes); mirrors include/mphip.h one to one.
+SIGNATURES = {
+    "mphip_version": (_i, []),
+    "mphip_last_error": (ctypes.c_char_p, []),
+    "mphip_rt_theta": (_i, [_p, _p, _p, _i, _i, _p]),
+    "mphip_warp_field_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_packed_weight_elems": (_sz, [_i, _i, _i]),
+    "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _p]),
+    "mphip_conv3d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "mphip_conv3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mphip_groupnorm_stats": (_i, [_p, _p, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
+    "mphip_groupnorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_avgpool2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mphip_upsample_trilinear2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mphip_upsample_nearest": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_add_matmul": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+}
+
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    """Compile csrc/*.hip for gfx950 into libmphip.so (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.isfile(LIB_PATH) or _stale():
+        subprocess.run(["bash", BUILD_SCRIPT, LIB_PATH], check=True)
+    return LIB_PATH
+
+
+def _stale() -> bool:
+    src_dir = os.path.join(_HERE, "csrc")
+    lib_m = os.path.getmtime(LIB_PATH)
+    inc = os.path.join(os.path.dirname(_HERE), "include", "mphip.h")
+    files = [os.path.join(src_dir, f) for f in os.listdir(src_dir) if f.endswith((".hip", ".h", ".sh"))] + [inc]
+    return any(os.path.getmtime(f) > lib_m for f in files if os.path.isfile(f))
+
+
+def load() -> ctypes.CDLL:
+    """Loads libmphip.so; raises (never falls back) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is required (no CPU fallback). "
+            "Build it with `python -c 'import __graft_entry__ as g; g.build()'`."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().mphip_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,16 @@
+// Library-level entry points: version and the thread-local error string.
+#include "mphip_common.h"
+
+namespace mphip {
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+}  // namespace mphip
+
+extern "C" int mphip_version(void) { return 1; }
+extern "C" const char *mphip_last_error(void) { return mphip::g_err; }

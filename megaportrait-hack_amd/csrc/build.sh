@@ -1,0 +1,19 @@
+#!/bin/bash
+# Builds libmphip.so (gfx950 only) next to this script's parent package directory.
+# -ffp-contract=off: roundings are placed by hand (explicit fmaf where ATen fuses), see warp.hip.
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${1:-$here/../libmphip.so}"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=default -Wall -Wno-unused-function"
+objs=()
+pids=()
+mkdir -p "$here/build"
+for f in api warp norm conv3d; do
+  "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
+  pids+=($!)
+  objs+=("$here/build/$f.o")
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"
+echo "built $out"

@@ -1,0 +1,303 @@
+// K4/K5 — Conv3d 3x3x3 (pad 1) and 1x1x1 as implicit GEMM on the fp32 matrix cores.
+// Reference call sites: nn.Conv3d at model.py:505,507,510,591 (G3d/ResBlock3D), 374-380,458
+// (FlowField/ResBlock3D_Adaptive) and the 1x1 Conv2d at model.py:446.
+//
+// GEMM view (per conv):  Y[co][vox] = sum_{tap,ci} Wp[tap][ci][co] * X[ci][vox + tap]
+//   M = Co (MFMA rows), N = voxels N*D*H*W (MFMA cols, contiguous in NCDHW so the C/D fragment's
+//   32 lanes store 128 contiguous bytes), K = taps*Ci.
+// MFMA: v_mfma_f32_32x32x2_f32 — exact fp32 (bitwise an fmaf chain), 64 FLOP/clk/SIMD.
+//   A fragment = weights  A[i=lane&31][k=lane>>5] -> Wp[tap][ci+k][co0+i]   (one dword per lane)
+//   B fragment = voxels   B[k=lane>>5][j=lane&31] -> X[ci+k][vox0+j + tap]  (one dword per lane)
+//   C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include "mphip_common.h"
+
+namespace mphip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+
+constexpr unsigned OOB = 0x80000000u;  // >= num_records -> buffer load returns 0 (zero padding)
+
+// OIDHW [Co,Ci,k,k,k] -> [k^3][CiP][CoP], zero padded.
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int CoP,
+                                   int CiP, int taps) {
+    size_t n = (size_t)taps * CiP * CoP;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        int co = (int)(i % CoP);
+        int ci = (int)((i / CoP) % CiP);
+        int tap = (int)(i / ((size_t)CoP * CiP));
+        wp[i] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * taps + tap] : 0.0f;
+    }
+}
+
+// Generic gather variant: both operands straight from global/L2 (buffer loads, hardware zero fill
+// for the padding halo), any D,H,W, batch folded into the voxel axis.  Block = 4 waves laid out
+// WCO (along Co) x 4/WCO (along voxels); each wave owns MT x NT tiles of 32x32.
+// gridDim = (voxel tiles, co tiles, split-K slices of the Ci range).
+template <int KS, int MT, int NT, int WCO, bool SKIP>
+__global__ void __launch_bounds__(256)
+conv3d_gather_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+                     float *__restrict__ y, int N, int Ci, int CiP, int Co, int CoP, int D, int H, int W,
+                     int ci_per_split, unsigned x_bytes) {
+    constexpr int TAPS = KS * KS * KS;
+    constexpr int WVOX = 4 / WCO;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave_co = wave % WCO, wave_vox = wave / WCO;
+    const int j = lane & 31, kk = lane >> 5;
+    const int HW = H * W, DHW = D * HW;
+    const long M = (long)N * DHW;
+
+    const int co0 = (blockIdx.y * WCO + wave_co) * MT * 32;
+    const long v0 = ((long)blockIdx.x * WVOX + wave_vox) * NT * 32;
+    if (co0 >= CoP || v0 >= M) return;  // wave-uniform
+
+    const int ci_begin = blockIdx.z * ci_per_split;
+    const int ci_end = min(CiP, ci_begin + ci_per_split);
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+
+    // per-lane voxel bookkeeping for each of the wave's NT column tiles
+    unsigned vbyte[NT];   // byte offset of (n, ci=kk, d, h, w) in x
+    unsigned vmask[NT];   // bit tap -> that neighbour exists (inside the volume)
+    unsigned anymask = 0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        long vg = v0 + t * 32 + j;
+        bool ok = vg < M;
+        long vv = ok ? vg : 0;
+        int n = (int)(vv / DHW);
+        int r = (int)(vv - (long)n * DHW);
+        int d = r / HW, h = (r / W) % H, w = r % W;
+        vbyte[t] = (unsigned)(((long)n * Ci * DHW + (long)kk * DHW + r) * 4);
+        unsigned m = 0;
+        if (ok) {
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                int kd = KS == 3 ? tap / 9 - 1 : 0, kh = KS == 3 ? (tap / 3) % 3 - 1 : 0, kw = KS == 3 ? tap % 3 - 1 : 0;
+                bool in = (unsigned)(d + kd) < (unsigned)D && (unsigned)(h + kh) < (unsigned)H &&
+                          (unsigned)(w + kw) < (unsigned)W;
+                m |= in ? (1u << tap) : 0u;
+            }
+        }
+        vmask[t] = m;
+        anymask |= m;
+    }
+    if (SKIP) {  // wave-wide OR: taps no lane needs are skipped (tiny volumes: most taps are padding)
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) anymask |= __shfl_xor(anymask, s, 64);
+        anymask = __builtin_amdgcn_readfirstlane(anymask);
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+
+    const float *wlane = wp + (size_t)kk * CoP + co0 + j;
+
+    for (int ci = ci_begin; ci < ci_end; ci += 2) {
+        const bool ci_ok = ci + kk < Ci;  // CiP may exceed Ci by one (odd Ci)
+        const unsigned soff = (unsigned)((long)ci * DHW * 4);
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            if (SKIP && !((anymask >> tap) & 1u)) continue;
+            const int kd = KS == 3 ? tap / 9 - 1 : 0, kh = KS == 3 ? (tap / 3) % 3 - 1 : 0, kw = KS == 3 ? tap % 3 - 1 : 0;
+            const int toff = (kd * HW + kh * W + kw) * 4;
+            float a[MT], b[NT];
+            const float *wrow = wlane + ((size_t)tap * CiP + ci) * CoP;
+#pragma unroll
+            for (int m = 0; m < MT; ++m) a[m] = wrow[m * 32];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                bool ok = ((vmask[t] >> tap) & 1u) && ci_ok;
+                b[t] = buf_load(rsrc, ok ? vbyte[t] + (unsigned)toff : OOB, soff);
+            }
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[m][t], 0, 0, 0);
+        }
+    }
+
+    // epilogue: gridDim.z == 1 -> y (+bias); else partial slab z (bias added by the reduce kernel)
+    const bool direct = gridDim.z == 1;
+    float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        long vg = v0 + t * 32 + j;
+        if (vg >= M) continue;
+        int n = (int)(vg / DHW);
+        int r = (int)(vg - (long)n * DHW);
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                if (co < Co) {
+                    float vout = acc[m][t][reg];
+                    if (direct && bias) vout += bias[co];
+                    dst[((size_t)n * Co + co) * DHW + r] = vout;
+                }
+            }
+        }
+    }
+}
+
+// y = bias + sum_z partial[z]  (z ascending: deterministic)
+__global__ void __launch_bounds__(256)
+splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias, float *__restrict__ y,
+                     size_t n_out, int Co, int DHW, int splits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out) return;
+    float s = partial[i];
+    for (int z = 1; z < splits; ++z) s += partial[(size_t)z * n_out + i];
+    if (bias) s += bias[(i / DHW) % Co];
+    y[i] = s;
+}
+
+struct ConvPlan {
+    int MT, NT, WCO, splits, ci_per_split, CoP, CiP;
+    bool skip;
+    dim3 grid;
+};
+
+static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
+    ConvPlan p;
+    p.CoP = (Co + 31) / 32 * 32;
+    p.CiP = (Ci + 1) / 2 * 2;
+    const long M = (long)N * D * H * W;
+    const int co_tiles32 = p.CoP / 32;
+    if (co_tiles32 % 3 == 0) p.MT = 3;
+    else if (co_tiles32 % 4 == 0) p.MT = 4;
+    else if (co_tiles32 % 2 == 0) p.MT = 2;
+    else p.MT = 1;
+    p.NT = M >= 64 * 64 ? 2 : 1;
+    // waves along Co when the voxel axis is too short to feed 4 waves
+    const long vox_tiles = (M + p.NT * 32 - 1) / (p.NT * 32);
+    const int co_wave_tiles = co_tiles32 / p.MT;
+    p.WCO = 1;
+    if (vox_tiles < 4 * 64 && co_wave_tiles % 4 == 0) p.WCO = 4;
+    else if (vox_tiles < 4 * 64 && co_wave_tiles % 2 == 0) p.WCO = 2;
+    const int wvox = 4 / p.WCO;
+    p.grid.x = (unsigned)((vox_tiles + wvox - 1) / wvox);
+    p.grid.y = (unsigned)((co_wave_tiles + p.WCO - 1) / p.WCO);
+    // split-K over Ci until ~2 workgroups per CU, keeping >= 8 input channels per slice
+    long blocks = (long)p.grid.x * p.grid.y;
+    int splits = 1;
+    while (blocks * splits < 512 && p.CiP / (splits * 2) >= 8 && (p.CiP % (splits * 2 * 2) == 0)) splits *= 2;
+    p.splits = splits;
+    p.ci_per_split = p.CiP / splits;
+    p.grid.z = splits;
+    p.skip = (k == 3) && (D < 3 || H < 3 || W < 3);
+    return p;
+}
+
+}  // namespace mphip
+
+using namespace mphip;
+
+extern "C" size_t mphip_packed_weight_elems(int Co, int Ci, int k) {
+    if (Co <= 0 || Ci <= 0 || (k != 1 && k != 3)) return 0;
+    return (size_t)k * k * k * ((Ci + 1) / 2 * 2) * ((Co + 31) / 32 * 32);
+}
+
+extern "C" int mphip_pack_conv_weight(const float *w, float *wp, int Co, int Ci, int k, void *stream) {
+    MPHIP_REQUIRE(w && wp, "pack_conv_weight: null pointer");
+    MPHIP_REQUIRE(Co > 0 && Ci > 0 && (k == 1 || k == 3), "pack_conv_weight: bad dims");
+    size_t n = mphip_packed_weight_elems(Co, Ci, k);
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci,
+                       (Co + 31) / 32 * 32, (Ci + 1) / 2 * 2, k * k * k);
+    return check_launch("pack_conv_weight");
+}
+
+extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
+    ConvPlan p = plan_conv(N, Ci, Co, D, H, W, k);
+    return p.splits > 1 ? (size_t)p.splits * N * Co * D * H * W * sizeof(float) : 0;
+}
+
+template <int KS, int MT, int NT, int WCO, bool SKIP>
+static void launch_gather(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *dst, int N,
+                          int Ci, int Co, int D, int H, int W, unsigned x_bytes, hipStream_t s) {
+    hipLaunchKernelGGL((conv3d_gather_kernel<KS, MT, NT, WCO, SKIP>), p.grid, dim3(256), 0, s, x, wp, bias, dst, N, Ci,
+                       p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, x_bytes);
+}
+
+template <int KS, int MT, int NT, int WCO>
+static void dispatch_skip(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *dst, int N,
+                          int Ci, int Co, int D, int H, int W, unsigned xb, hipStream_t s) {
+    if (KS == 3 && p.skip) launch_gather<KS, MT, NT, WCO, true>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s);
+    else launch_gather<KS, MT, NT, WCO, false>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s);
+}
+
+template <int KS, int MT, int NT>
+static void dispatch_wco(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *dst, int N,
+                         int Ci, int Co, int D, int H, int W, unsigned xb, hipStream_t s) {
+    switch (p.WCO) {
+        case 4: dispatch_skip<KS, MT, NT, 4>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+        case 2: dispatch_skip<KS, MT, NT, 2>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+        default: dispatch_skip<KS, MT, NT, 1>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+    }
+}
+
+template <int KS, int MT>
+static void dispatch_nt(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *dst, int N,
+                        int Ci, int Co, int D, int H, int W, unsigned xb, hipStream_t s) {
+    if (p.NT == 2) dispatch_wco<KS, MT, 2>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s);
+    else dispatch_wco<KS, MT, 1>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s);
+}
+
+template <int KS>
+static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, const float *bias, float *dst, int N,
+                        int Ci, int Co, int D, int H, int W, unsigned xb, hipStream_t s) {
+    switch (p.MT) {
+        case 4: dispatch_nt<KS, 4>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+        case 3: dispatch_nt<KS, 3>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+        case 2: dispatch_nt<KS, 2>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+        default: dispatch_nt<KS, 1>(p, x, wp, bias, dst, N, Ci, Co, D, H, W, xb, s); break;
+    }
+}
+
+extern "C" int mphip_conv3d_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int Ci,
+                                int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
+    MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
+    MPHIP_REQUIRE(k == 1 || k == 3, "conv3d_fwd: kernel size %d not supported (1 or 3)", k);
+    MPHIP_REQUIRE(precision == 0, "conv3d_fwd: precision %d not supported", precision);
+    const size_t x_bytes = (size_t)N * Ci * D * H * W * sizeof(float);
+    MPHIP_REQUIRE(x_bytes < 0x80000000ull, "conv3d_fwd: input of %zu bytes exceeds the 2 GiB buffer-addressing limit",
+                  x_bytes);
+    ConvPlan p = plan_conv(N, Ci, Co, D, H, W, k);
+    hipStream_t s = (hipStream_t)stream;
+    float *dst = y;
+    if (p.splits > 1) {
+        size_t need = (size_t)p.splits * N * Co * D * H * W * sizeof(float);
+        if (!workspace || workspace_bytes < need) {
+            set_error("conv3d_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+            return MPHIP_EWORKSPACE;
+        }
+        dst = (float *)workspace;
+    }
+    if (k == 3) dispatch_mt<3>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
+    else dispatch_mt<1>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
+    int rc = check_launch("conv3d_fwd");
+    if (rc) return rc;
+    if (p.splits > 1) {
+        size_t n_out = (size_t)N * Co * D * H * W;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, (const float *)workspace, bias,
+                           y, n_out, Co, D * H * W, p.splits);
+        rc = check_launch("conv3d_fwd(splitk_reduce)");
+    }
+    return rc;
+}

@@ -1,0 +1,43 @@
+// Shared helpers for libmphip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/mphip.h"
+
+namespace mphip {
+
+void set_error(const char *fmt, ...);
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return MPHIP_ELAUNCH;
+    }
+    return MPHIP_OK;
+}
+
+#define MPHIP_REQUIRE(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            mphip::set_error(__VA_ARGS__); \
+            return MPHIP_EINVAL;          \
+        }                                 \
+    } while (0)
+
+inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on the same
+// XCD (hardware round-robins physical ids over the 8 XCDs), so neighbouring tiles share an L2.
+__device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
+    const unsigned nx = 8;
+    unsigned q = nwg / nx, r = nwg % nx;
+    unsigned xcd = bid % nx, idx = bid / nx;
+    unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace mphip

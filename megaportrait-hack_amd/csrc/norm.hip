@@ -1,0 +1,388 @@
+// K6/K7/K8 — GroupNorm (stats + fused apply), resampling and the small head ops.  HBM-bound.
+// Reference call sites: nn.GroupNorm model.py:506,508,460,309; AdaptiveGroupNorm 314-316;
+// ReLU/residual 517-523, 390-403; AvgPool3d 576-580; nn.Upsample 427-433, 585-589;
+// (z+e)@Gamma 945-957; 1x1 Conv2d 446; relu+tanh 462-465.
+#include "mphip_common.h"
+#include "mphip_resample.h"
+
+namespace mphip {
+
+constexpr int GN_CHUNK = 16384;  // floats reduced by one workgroup (256 threads x 16 float4)
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// Stage 1: per (sample,group) span [cnt floats, contiguous in NCDHW] -> per-chunk (sum, sumsq).
+// fp32 per-thread partials over <=64 elements, wavefront-shuffle + LDS reduction in double.
+__global__ void __launch_bounds__(256)
+gn_partial_kernel(const float *__restrict__ x, double *__restrict__ partial, size_t cnt, int chunks) {
+    const int grp = blockIdx.y, chunk = blockIdx.x;
+    const float *p = x + (size_t)grp * cnt;
+    const size_t begin = (size_t)chunk * GN_CHUNK;
+    const size_t end = begin + GN_CHUNK < cnt ? begin + GN_CHUNK : cnt;
+    float s = 0.0f, ss = 0.0f;
+    if ((cnt & 3) == 0 && (((size_t)p) & 15) == 0) {
+        for (size_t i = begin + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+            float4 v = *reinterpret_cast<const float4 *>(p + i);
+            s += (v.x + v.y) + (v.z + v.w);
+            ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (size_t i = begin + threadIdx.x; i < end; i += 256) {
+            float v = p[i];
+            s += v;
+            ss += v * v;
+        }
+    }
+    double ds = wave_sum((double)s), dss = wave_sum((double)ss);
+    __shared__ double red[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = ds;
+        red[wave * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = (red[0] + red[2]) + (red[4] + red[6]);
+        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        partial[((size_t)grp * chunks + chunk) * 2] = a;
+        partial[((size_t)grp * chunks + chunk) * 2 + 1] = b;
+    }
+}
+
+// Stage 2: (mean, rstd) per (sample,group); biased variance, eps inside the sqrt.
+__global__ void gn_finalize_kernel(const double *__restrict__ partial, float *__restrict__ stats, int ngroups,
+                                   int chunks, double cnt, float eps) {
+    int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= ngroups) return;
+    double s = 0.0, ss = 0.0;
+    for (int c = 0; c < chunks; ++c) {
+        s += partial[((size_t)g * chunks + c) * 2];
+        ss += partial[((size_t)g * chunks + c) * 2 + 1];
+    }
+    double mean = s / cnt;
+    double var = ss / cnt - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[g * 2] = (float)mean;
+    stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+struct GnParams {
+    const float *x, *stats, *gamma, *beta, *w2, *b2, *residual;
+    float *y;
+    int C, cpg;
+    int relu, tanh_;
+};
+
+__device__ __forceinline__ float gn_value(const GnParams &p, float xv, float mean, float rstd, float g, float b,
+                                          float w2, float b2, bool has2, float res, bool has_res) {
+    float v = (xv - mean) * rstd * g + b;
+    if (has2) v = v * w2 + b2;
+    if (has_res) v += res;
+    if (p.relu) v = fmaxf(v, 0.0f);
+    if (p.tanh_) v = tanhf(v);
+    return v;
+}
+
+// apply, no pooling: one thread per VW contiguous elements of one (n,c) plane.
+template <int VW>
+__global__ void __launch_bounds__(256) gn_apply_kernel(GnParams p, int S, size_t total_vec) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total_vec) return;
+    const int SV = S / VW;
+    size_t plane = t / SV;  // n*C + c
+    int c = (int)(plane % p.C);
+    int n = (int)(plane / p.C);
+    int grp = n * (p.C / p.cpg) + c / p.cpg;
+    float mean = p.stats[grp * 2], rstd = p.stats[grp * 2 + 1];
+    float g = p.gamma[c], b = p.beta[c];
+    bool has2 = p.w2 != nullptr, has_res = p.residual != nullptr;
+    float w2 = has2 ? p.w2[c] : 1.0f, b2 = has2 ? p.b2[c] : 0.0f;
+    size_t o = t * VW;
+    if (VW == 4) {
+        float4 xv = *reinterpret_cast<const float4 *>(p.x + o);
+        float4 rv = has_res ? *reinterpret_cast<const float4 *>(p.residual + o) : make_float4(0, 0, 0, 0);
+        float4 out;
+        out.x = gn_value(p, xv.x, mean, rstd, g, b, w2, b2, has2, rv.x, has_res);
+        out.y = gn_value(p, xv.y, mean, rstd, g, b, w2, b2, has2, rv.y, has_res);
+        out.z = gn_value(p, xv.z, mean, rstd, g, b, w2, b2, has2, rv.z, has_res);
+        out.w = gn_value(p, xv.w, mean, rstd, g, b, w2, b2, has2, rv.w, has_res);
+        *reinterpret_cast<float4 *>(p.y + o) = out;
+    } else {
+        p.y[o] = gn_value(p, p.x[o], mean, rstd, g, b, w2, b2, has2, has_res ? p.residual[o] : 0.0f, has_res);
+    }
+}
+
+// apply + AvgPool3d(2,2): one thread per pooled output element (sum order kd,kh,kw then /8 like ATen).
+__global__ void __launch_bounds__(256) gn_apply_pool_kernel(GnParams p, int D, int H, int W, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int oD = D / 2, oH = H / 2, oW = W / 2;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    int c = (int)(plane % p.C);
+    int n = (int)(plane / p.C);
+    int grp = n * (p.C / p.cpg) + c / p.cpg;
+    float mean = p.stats[grp * 2], rstd = p.stats[grp * 2 + 1];
+    float g = p.gamma[c], b = p.beta[c];
+    bool has2 = p.w2 != nullptr, has_res = p.residual != nullptr;
+    float w2 = has2 ? p.w2[c] : 1.0f, b2 = has2 ? p.b2[c] : 0.0f;
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 2; ++bb) {
+            size_t o = ((plane * D + 2 * od + a) * H + 2 * oh + bb) * W + 2 * ow;
+            float2 xv = *reinterpret_cast<const float2 *>(p.x + o);
+            float2 rv = has_res ? *reinterpret_cast<const float2 *>(p.residual + o) : make_float2(0, 0);
+            s += gn_value(p, xv.x, mean, rstd, g, b, w2, b2, has2, rv.x, has_res);
+            s += gn_value(p, xv.y, mean, rstd, g, b, w2, b2, has2, rv.y, has_res);
+        }
+    p.y[t] = s / 8.0f;
+}
+
+__global__ void __launch_bounds__(256) avgpool2_kernel(const float *__restrict__ x, float *__restrict__ y, int D,
+                                                       int H, int W, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int oD = D / 2, oH = H / 2, oW = W / 2;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    float s = 0.0f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const float *q = x + ((plane * D + 2 * od + a) * H + 2 * oh + b) * W + 2 * ow;
+            s += q[0];
+            s += q[1];
+        }
+    y[t] = s / 8.0f;
+}
+
+// nn.Upsample(scale_factor=2, trilinear, align_corners=True): src = dst*(in-1)/(out-1).
+__global__ void __launch_bounds__(256) upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                  int D, int H, int W, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int oD = 2 * D, oH = 2 * H, oW = 2 * W;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    SrcIdx sd = src_index<true>(od, D, oD), sh = src_index<true>(oh, H, oH), sw = src_index<true>(ow, W, oW);
+    y[t] = trilerp(x + plane * D * H * W, H, W, sd, sh, sw);
+}
+
+__global__ void __launch_bounds__(256) upsample_nearest_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                               int D, int H, int W, int sD, int sH, int sW,
+                                                               size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int oD = D * sD, oH = H * sH, oW = W * sW;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    y[t] = x[((plane * D + od / sD) * H + oh / sH) * W + ow / sW];
+}
+
+// out[b,n] = sum_k (a[b,k]+a2[b,k]) * M(k,n) + bias[n];  M(k,n) = m[k*N+n] (trans=0) or m[n*K+k] (trans=1).
+// One wave per output column n, all B rows at once (B <= 16 per pass) so the matrix streams once.
+template <bool TRANS>
+__global__ void __launch_bounds__(256)
+add_matmul_kernel(const float *__restrict__ a, const float *__restrict__ a2, const float *__restrict__ m,
+                  const float *__restrict__ bias, float *__restrict__ out, int B, int K, int N) {
+    constexpr int BMAX = 8;
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    for (int b0 = 0; b0 < B; b0 += BMAX) {
+        float acc[BMAX];
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i) acc[i] = 0.0f;
+        for (int k = lane; k < K; k += 64) {
+            float mv = TRANS ? m[(size_t)n * K + k] : m[(size_t)k * N + n];
+#pragma unroll
+            for (int i = 0; i < BMAX; ++i) {
+                if (b0 + i < B) {
+                    float av = a[(size_t)(b0 + i) * K + k];
+                    if (a2) av += a2[(size_t)(b0 + i) * K + k];
+                    acc[i] = fmaf(av, mv, acc[i]);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < BMAX; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0 && b0 + i < B) out[(size_t)(b0 + i) * N + n] = v + (bias ? bias[n] : 0.0f);
+        }
+    }
+}
+
+// K0: theta[b] = rows 0..2 of A = [R|t; 0 0 0 1], optionally inverted (Gauss-Jordan, partial pivoting).
+__global__ void rt_theta_kernel(const float *__restrict__ rot, const float *__restrict__ tr, float *__restrict__ theta,
+                                int B, int invert) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float k = 0.017453292519943295f;  // torch.pi / 180.0 as fp32 (model.py:823)
+    float ra = rot[b * 3] * k, rb = rot[b * 3 + 1] * k, rg = rot[b * 3 + 2] * k;
+    float ca = cosf(ra), sa = sinf(ra), cb = cosf(rb), sb = sinf(rb), cg = cosf(rg), sg = sinf(rg);
+    float Rx[3][3] = {{1, 0, 0}, {0, ca, -sa}, {0, sa, ca}};
+    float Ry[3][3] = {{cb, 0, sb}, {0, 1, 0}, {-sb, 0, cb}};
+    float Rz[3][3] = {{cg, -sg, 0}, {sg, cg, 0}, {0, 0, 1}};
+    float T[3][3], R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.0f;
+            for (int q = 0; q < 3; ++q) s = fmaf(Ry[i][q], Rz[q][j], s);
+            T[i][j] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            float s = 0.0f;
+            for (int q = 0; q < 3; ++q) s = fmaf(Rx[i][q], T[q][j], s);
+            R[i][j] = s;
+        }
+    float A[4][8];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j) {
+            A[i][j] = i < 3 ? (j < 3 ? R[i][j] : tr[b * 3 + i]) : (j == 3 ? 1.0f : 0.0f);
+            A[i][4 + j] = i == j ? 1.0f : 0.0f;
+        }
+    if (invert) {
+        for (int col = 0; col < 4; ++col) {
+            int piv = col;
+            float best = fabsf(A[col][col]);
+            for (int r = col + 1; r < 4; ++r)
+                if (fabsf(A[r][col]) > best) { best = fabsf(A[r][col]); piv = r; }
+            if (piv != col)
+                for (int j = 0; j < 8; ++j) { float tmp = A[col][j]; A[col][j] = A[piv][j]; A[piv][j] = tmp; }
+            float inv = 1.0f / A[col][col];
+            for (int j = 0; j < 8; ++j) A[col][j] *= inv;
+            for (int r = 0; r < 4; ++r) {
+                if (r == col) continue;
+                float f = A[r][col];
+                for (int j = 0; j < 8; ++j) A[r][j] = fmaf(-f, A[col][j], A[r][j]);
+            }
+        }
+    }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 4; ++j) theta[(b * 3 + i) * 4 + j] = invert ? A[i][4 + j] : A[i][j];
+}
+
+}  // namespace mphip
+
+using namespace mphip;
+
+extern "C" int mphip_rt_theta(const float *rot, const float *tr, float *theta, int B, int invert, void *stream) {
+    MPHIP_REQUIRE(rot && tr && theta, "rt_theta: null pointer");
+    MPHIP_REQUIRE(B > 0, "rt_theta: bad batch");
+    hipLaunchKernelGGL(rt_theta_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, rot, tr, theta, B, invert);
+    return check_launch("rt_theta");
+}
+
+extern "C" size_t mphip_groupnorm_workspace_bytes(int N, int C, int S, int G) {
+    if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return 0;
+    size_t cnt = (size_t)(C / G) * S;
+    size_t chunks = (cnt + GN_CHUNK - 1) / GN_CHUNK;
+    return (size_t)N * G * chunks * 2 * sizeof(double);
+}
+
+extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C, int S, int G, float eps,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(x && stats, "groupnorm_stats: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_stats: bad dims (C=%d G=%d)", C, G);
+    size_t need = mphip_groupnorm_workspace_bytes(N, C, S, G);
+    if (!workspace || workspace_bytes < need) {
+        set_error("groupnorm_stats: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    size_t cnt = (size_t)(C / G) * S;
+    int chunks = (int)((cnt + GN_CHUNK - 1) / GN_CHUNK);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N * G), dim3(256), 0, s, x, (double *)workspace, cnt, chunks);
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const double *)workspace, stats,
+                       N * G, chunks, (double)cnt, eps);
+    return check_launch("groupnorm_stats");
+}
+
+extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,
+                                     const float *w2, const float *b2, const float *residual, float *y, int N, int C,
+                                     int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream) {
+    MPHIP_REQUIRE(x && stats && gamma && beta && y, "groupnorm_apply: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && G > 0 && C % G == 0, "groupnorm_apply: bad dims");
+    MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_apply: w2/b2 must both be set or both NULL");
+    GnParams p{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_};
+    hipStream_t s = (hipStream_t)stream;
+    const int S = D * H * W;
+    if (pool2) {
+        MPHIP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "groupnorm_apply: pool2 needs even D,H,W");
+        size_t total = (size_t)N * C * (D / 2) * (H / 2) * (W / 2);
+        hipLaunchKernelGGL(gn_apply_pool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p, D, H, W, total);
+    } else if (S % 4 == 0) {
+        size_t total = (size_t)N * C * S / 4;
+        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(cdiv(total, 256)), dim3(256), 0, s, p, S, total);
+    } else {
+        size_t total = (size_t)N * C * S;
+        hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, s, p, S, total);
+    }
+    return check_launch("groupnorm_apply");
+}
+
+extern "C" int mphip_avgpool2(const float *x, float *y, int NC, int D, int H, int W, void *stream) {
+    MPHIP_REQUIRE(x && y, "avgpool2: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
+                  "avgpool2: dims must be positive and even");
+    size_t total = (size_t)NC * (D / 2) * (H / 2) * (W / 2);
+    hipLaunchKernelGGL(avgpool2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W, total);
+    return check_launch("avgpool2");
+}
+
+extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D, int H, int W, void *stream) {
+    MPHIP_REQUIRE(x && y, "upsample_trilinear2: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0, "upsample_trilinear2: bad dims");
+    size_t total = (size_t)NC * D * H * W * 8;
+    hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D, H,
+                       W, total);
+    return check_launch("upsample_trilinear2");
+}
+
+extern "C" int mphip_upsample_nearest(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW,
+                                      void *stream) {
+    MPHIP_REQUIRE(x && y, "upsample_nearest: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && sD > 0 && sH > 0 && sW > 0, "upsample_nearest: bad dims");
+    size_t total = (size_t)NC * D * H * W * sD * sH * sW;
+    hipLaunchKernelGGL(upsample_nearest_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W,
+                       sD, sH, sW, total);
+    return check_launch("upsample_nearest");
+}
+
+extern "C" int mphip_add_matmul(const float *a, const float *a2, const float *m, const float *bias, float *out, int B,
+                                int K, int N, int trans, void *stream) {
+    MPHIP_REQUIRE(a && m && out, "add_matmul: null pointer");
+    MPHIP_REQUIRE(B > 0 && K > 0 && N > 0, "add_matmul: bad dims");
+    dim3 grid(cdiv(N, 4));
+    if (trans)
+        hipLaunchKernelGGL(add_matmul_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, a2, m, bias, out, B, K, N);
+    else
+        hipLaunchKernelGGL(add_matmul_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, a2, m, bias, out, B, K, N);
+    return check_launch("add_matmul");
+}

@@ -1,0 +1,284 @@
+"""Host-side mirror of the reference's hot-path modules (johndpope/MegaPortrait-hack model.py).
+
+Same class names, constructor signatures, parameter names/shapes (=> identical state-dict keys,
+SURVEY.md Appendix C) and forward signatures as the reference, so its callers
+(`train.py:194,283`, `inference.py:35`, `PairwiseTransferLoss` model.py:2192-2214) drop in; the
+arithmetic runs in libmphip.so (hand-written HIP for gfx950) through the C ABI.  nn.Conv3d /
+nn.GroupNorm objects are kept purely as parameter containers (names, shapes, default init,
+.to()/.state_dict()); their own forward is never called.
+
+Forward only this round: the HIP path has no backward yet, so calling a hot
+module while autograd needs a graph raises instead of silently detaching.
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+COMPRESS_DIM = 512  # model.py:48
+
+
+def _no_autograd(*tensors, module: nn.Module):
+    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor))
+                                    or any(p.requires_grad for p in module.parameters())):
+        raise NotImplementedError(
+            f"{type(module).__name__}: the HIP hot path is forward-only in this release; call it under "
+            "torch.no_grad() (training backward is the next scope row, see DESIGN.md)")
+
+
+class _PackCache:
+    """Packed conv weights, rebuilt when the parameter changes (in-place update or .to())."""
+
+    def __init__(self):
+        self._store = {}
+
+    def get(self, conv: nn.Module) -> ops.PackedConv:
+        w, b = conv.weight, conv.bias
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), str(w.device))
+        hit = self._store.get(id(conv))
+        if hit is None or hit[0] != key:
+            hit = (key, ops.PackedConv(w, b))
+            self._store[id(conv)] = hit
+        return hit[1]
+
+
+_packs = _PackCache()
+
+
+def compute_rt_warp(rotation, translation, invert=False, grid_size=64):
+    """model.py:777-809 — rigid warp grid [B,3,G,G,G] (x,y,z channels)."""
+    theta = ops.rt_theta(rotation, translation, invert)
+    zero_em = torch.zeros((rotation.shape[0], 3, 1, 1, 1), dtype=torch.float32, device=rotation.device)
+    _, rt, _ = ops.warp_field_compose(theta, zero_em, grid_size, parts=True)
+    return rt
+
+
+def apply_warping_field(v, warp_field):
+    """model.py:1028-1065 — same signature and result; one fused HIP kernel (K2)."""
+    return ops.warp_volume(v, warp_field)
+
+
+class AdaptiveGroupNorm(nn.Module):
+    """model.py:304-316."""
+
+    def __init__(self, num_channels, num_groups=32):
+        super().__init__()
+        self.num_channels = num_channels
+        self.num_groups = num_groups
+        self.weight = nn.Parameter(torch.ones(1, num_channels, 1, 1, 1))
+        self.bias = nn.Parameter(torch.zeros(1, num_channels, 1, 1, 1))
+        self.group_norm = nn.GroupNorm(num_groups, num_channels)
+
+    def forward(self, x):
+        _no_autograd(x, module=self)
+        st = ops.groupnorm_stats(x, self.num_groups, self.group_norm.eps)
+        return ops.groupnorm_apply(x, st, self.group_norm.weight, self.group_norm.bias, self.num_groups,
+                                   w2=self.weight, b2=self.bias)
+
+
+class ResBlock3D_Adaptive(nn.Module):
+    """model.py:369-408 (the `upsample` flag is never set on the hot path; kept for signature parity)."""
+
+    def __init__(self, in_channels, out_channels, upsample=False, scale_factors=(1, 1, 1)):
+        super().__init__()
+        if upsample:
+            raise NotImplementedError("ResBlock3D_Adaptive(upsample=True) is not used by Gbase's hot path")
+        self.upsample = upsample
+        self.scale_factors = scale_factors
+        self.conv1 = nn.Conv3d(in_channels, out_channels, 3, padding=1)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, 3, padding=1)
+        self.norm1 = AdaptiveGroupNorm(out_channels)
+        self.norm2 = AdaptiveGroupNorm(out_channels)
+        if in_channels != out_channels:
+            self.residual_conv = nn.Conv3d(in_channels, out_channels, 1)
+        else:
+            self.residual_conv = nn.Identity()
+
+    def forward(self, x):
+        _no_autograd(x, module=self)
+        n1, n2 = self.norm1, self.norm2
+        y = ops.conv3d(x, _packs.get(self.conv1))
+        st = ops.groupnorm_stats(y, n1.num_groups, n1.group_norm.eps)
+        a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
+                                b2=n1.bias, relu=True)
+        y = ops.conv3d(a, _packs.get(self.conv2))
+        st = ops.groupnorm_stats(y, n2.num_groups, n2.group_norm.eps)
+        res = x if isinstance(self.residual_conv, nn.Identity) else ops.conv3d(x, _packs.get(self.residual_conv))
+        return ops.groupnorm_apply(y, st, n2.group_norm.weight, n2.group_norm.bias, n2.num_groups, w2=n2.weight,
+                                   b2=n2.bias, residual=res, relu=True)
+
+
+class FlowField(nn.Module):
+    """model.py:415-471: [B,512,1,1] -> [B,3,16,16,16] in [0,1)."""
+
+    _UPS = ((2, 2, 2), (2, 2, 2), (1, 2, 2), (1, 2, 2))
+
+    def __init__(self):
+        super().__init__()
+        self.conv1x1 = nn.Conv2d(512, 2048, kernel_size=1)
+        self.resblock1 = ResBlock3D_Adaptive(in_channels=512, out_channels=256)
+        self.upsample1 = nn.Upsample(scale_factor=(2, 2, 2))
+        self.resblock2 = ResBlock3D_Adaptive(in_channels=256, out_channels=128)
+        self.upsample2 = nn.Upsample(scale_factor=(2, 2, 2))
+        self.resblock3 = ResBlock3D_Adaptive(in_channels=128, out_channels=64)
+        self.upsample3 = nn.Upsample(scale_factor=(1, 2, 2))
+        self.resblock4 = ResBlock3D_Adaptive(in_channels=64, out_channels=32)
+        self.upsample4 = nn.Upsample(scale_factor=(1, 2, 2))
+        self.conv3x3x3 = nn.Conv3d(32, 3, kernel_size=3, padding=1)
+        self.gn = nn.GroupNorm(1, 3)
+        self.tanh = nn.Tanh()
+
+    def forward(self, zs, adaptive_gamma=0, adaptive_beta=0):  # last two ignored, as in the reference
+        _no_autograd(zs, module=self)
+        b = zs.shape[0]
+        s = zs.reshape(b, 512)
+        w = self.conv1x1.weight
+        x = ops.add_matmul(s, None, w.reshape(2048, 512), self.conv1x1.bias, trans=True)
+        x = x.view(b, 512, 4, 1, 1)  # model.py:425: channel c*4+d -> (c,d)
+        for blk, up in zip((self.resblock1, self.resblock2, self.resblock3, self.resblock4), self._UPS):
+            x = ops.upsample_nearest(blk(x), up)
+        x = ops.conv3d(x, _packs.get(self.conv3x3x3))
+        st = ops.groupnorm_stats(x, 1, self.gn.eps)
+        x = ops.groupnorm_apply(x, st, self.gn.weight, self.gn.bias, 1, relu=True, tanh=True)
+        assert x.shape[1] == 3, f"Expected 3 channels after conv3x3x3, got {x.shape[1]}"
+        return x
+
+
+class _WarpGenerator(nn.Module):
+    _INVERT = False
+
+    def __init__(self, num_channels):
+        super().__init__()
+        self.flowfield = FlowField()
+        self.num_channels = COMPRESS_DIM
+        # Registered parameters on every device (the reference's `nn.Parameter(...).to(device)` only
+        # registers them on CPU hosts, model.py:934-935; load_gbase_state_dict() accepts both layouts).
+        self.adaptive_matrix_gamma = nn.Parameter(torch.randn(self.num_channels, self.num_channels))
+        self.adaptive_matrix_beta = nn.Parameter(torch.randn(self.num_channels, self.num_channels))
+
+    def forward(self, R, t, z, e):
+        assert R.shape == (z.shape[0], 3), f"Expected R shape (batch_size, 3), got {R.shape}"
+        assert t.shape == (z.shape[0], 3), f"Expected t shape (batch_size, 3), got {t.shape}"
+        assert z.shape == e.shape, f"Expected z and e to have the same shape, got {z.shape} and {e.shape}"
+        _no_autograd(R, t, z, e, module=self)
+        s = ops.add_matmul(z, e, self.adaptive_matrix_gamma)  # (z+e) @ Gamma, model.py:945-957
+        em = self.flowfield(s.unsqueeze(-1).unsqueeze(-1), 0, 0)
+        theta = ops.rt_theta(R, t, self._INVERT)
+        return ops.warp_field_compose(theta, em, 64)
+
+
+class WarpGeneratorS2C(_WarpGenerator):
+    """model.py:927-975 (rigid part inverted)."""
+    _INVERT = True
+
+
+class WarpGeneratorC2D(_WarpGenerator):
+    """model.py:978-1024."""
+    _INVERT = False
+
+
+class ResBlock3D(nn.Module):
+    """model.py:500-528."""
+
+    def __init__(self, in_channels, out_channels, upsample=False, scale_factors=(1, 1, 1)):
+        super().__init__()
+        if upsample:
+            raise NotImplementedError("ResBlock3D(upsample=True) is not used by G3d")
+        self.upsample = upsample
+        self.scale_factors = scale_factors
+        self.conv1 = nn.Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.gn1 = nn.GroupNorm(num_groups=32, num_channels=out_channels)
+        self.conv2 = nn.Conv3d(out_channels, out_channels, kernel_size=3, padding=1)
+        self.gn2 = nn.GroupNorm(num_groups=32, num_channels=out_channels)
+        self.shortcut = nn.Conv3d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else nn.Identity()
+
+    def forward(self, x, _pool_after: bool = False):
+        _no_autograd(x, module=self)
+        identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d(x, _packs.get(self.shortcut))
+        y = ops.conv3d(x, _packs.get(self.conv1))
+        st = ops.groupnorm_stats(y, 32, self.gn1.eps)
+        a = ops.groupnorm_apply(y, st, self.gn1.weight, self.gn1.bias, 32, relu=True)
+        y = ops.conv3d(a, _packs.get(self.conv2))
+        st = ops.groupnorm_stats(y, 32, self.gn2.eps)
+        return ops.groupnorm_apply(y, st, self.gn2.weight, self.gn2.bias, 32, residual=identity, relu=True,
+                                   pool2=_pool_after)
+
+
+class G3d(nn.Module):
+    """model.py:571-597.  nn.Sequential indices give the reference's state-dict names."""
+
+    def __init__(self, in_channels):
+        super().__init__()
+        self.downsampling = nn.Sequential(
+            ResBlock3D(in_channels, 96), nn.AvgPool3d(kernel_size=2, stride=2),
+            ResBlock3D(96, 192), nn.AvgPool3d(kernel_size=2, stride=2),
+            ResBlock3D(192, 384), nn.AvgPool3d(kernel_size=2, stride=2),
+            ResBlock3D(384, 768),
+        )
+        self.upsampling = nn.Sequential(
+            ResBlock3D(768, 384), nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True),
+            ResBlock3D(384, 192), nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True),
+            ResBlock3D(192, 96), nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True),
+        )
+        self.final_conv = nn.Conv3d(96, 96, kernel_size=3, padding=1)
+
+    def forward(self, x):
+        _no_autograd(x, module=self)
+        d = self.downsampling
+        x = d[0](x, _pool_after=True)   # AvgPool3d fused into the block's last elementwise pass
+        x = d[2](x, _pool_after=True)
+        x = d[4](x, _pool_after=True)
+        x = d[6](x)
+        u = self.upsampling
+        x = ops.upsample_trilinear2(u[0](x))
+        x = ops.upsample_trilinear2(u[2](x))
+        x = ops.upsample_trilinear2(u[4](x))
+        return ops.conv3d(x, _packs.get(self.final_conv))
+
+
+class GbaseHotSlice(nn.Module):
+    """The slice of Gbase.forward between the 2D encoders and G2d (model.py:1151-1171), with the
+    reference's attribute names so a Gbase checkpoint's `warp_generator_s2c.*`,
+    `warp_generator_c2d.*` and `G3d.*` keys load unchanged."""
+
+    def __init__(self):
+        super().__init__()
+        self.warp_generator_s2c = WarpGeneratorS2C(num_channels=512)
+        self.warp_generator_c2d = WarpGeneratorC2D(num_channels=512)
+        self.G3d = G3d(in_channels=96)
+
+    def forward(self, vs, es, Rs, ts, zs, Rd, td, zd):
+        w_s2c = self.warp_generator_s2c(Rs, ts, zs, es)
+        vc = apply_warping_field(vs, w_s2c)
+        assert vc.shape[1:] == (96, 16, 64, 64), f"Expected vc shape (_, 96, 16, 64, 64), got {vc.shape}"
+        vc2d = self.G3d(vc)
+        w_c2d = self.warp_generator_c2d(Rd, td, zd, es)
+        # apply_warping_field + torch.sum(dim=2) (model.py:1167-1171) in one kernel (K3)
+        return ops.warp_volume_dsum(vc2d, w_c2d)
+
+    def forward_any_size(self, vs, es, Rs, ts, zs, Rd, td, zd):
+        """Same graph without the 512^2-only shape assert (small parity cases)."""
+        w_s2c = self.warp_generator_s2c(Rs, ts, zs, es)
+        vc2d = self.G3d(apply_warping_field(vs, w_s2c))
+        return ops.warp_volume_dsum(vc2d, self.warp_generator_c2d(Rd, td, zd, es))
+
+
+def load_hot_state_dict(module: nn.Module, state_dict, strict: bool = True):
+    """Loads a (sub)set of a reference Gbase state-dict.  Reference checkpoints built on a GPU host
+    lack `adaptive_matrix_gamma/beta` (model.py:934-935 quirk): those keys are then left at their
+    current values and reported."""
+    own = module.state_dict()
+    filtered = {k: v for k, v in state_dict.items() if k in own}
+    missing = [k for k in own if k not in filtered]
+    tolerated = [k for k in missing if "adaptive_matrix_" in k]
+    hard_missing = [k for k in missing if k not in tolerated]
+    if strict and hard_missing:
+        raise KeyError(f"missing keys: {hard_missing[:8]}{'...' if len(hard_missing) > 8 else ''}")
+    module.load_state_dict(filtered, strict=False)
+    if tolerated:
+        logging.warning("checkpoint has no %s (GPU-built reference model); kept current values", tolerated)
+    return hard_missing, tolerated

@@ -1,0 +1,241 @@
+"""Functional wrappers: torch CUDA tensors in/out, HIP kernels (libmphip.so, C ABI) in between.
+
+PyTorch is used here only for device memory (tensor allocation through its caching allocator,
+which is stream-ordered) and for the current HIP stream.  Every function requires float32,
+contiguous CUDA tensors and raises otherwise — there is no eager/CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+_P = ctypes.c_void_p
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else _P(t.data_ptr())
+
+
+def _stream():
+    return _P(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a CUDA tensor (the HIP path has no CPU fallback), got "
+                           f"{type(t).__name__} on {getattr(t, 'device', None)}")
+    if t.dtype != dtype:
+        raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ------------------------------------------------------------------ host-built tables
+_tables = {}
+
+
+def linspace_table(n: int, device) -> torch.Tensor:
+    """torch.linspace(-1,1,n) evaluated by the HOST CPU kernel (model.py:1040-1042 on a CPU
+    host), uploaded once.  ATen's linspace has no closed form, so the
+    table is data, not recomputed on the GPU."""
+    key = ("lin", n, str(device))
+    if key not in _tables:
+        _tables[key] = torch.linspace(-1, 1, n, dtype=torch.float32).to(device)
+    return _tables[key]
+
+
+def affine_base_table(g: int, device) -> torch.Tensor:
+    """Base coordinates of F.affine_grid(..., align_corners=False): linspace(-1,1,G)*(G-1)/G."""
+    key = ("aff", g, str(device))
+    if key not in _tables:
+        _tables[key] = (torch.linspace(-1, 1, g, dtype=torch.float32) * (g - 1) / g).to(device)
+    return _tables[key]
+
+
+# ------------------------------------------------------------------ K0 / K1
+def rt_theta(rotation_deg: torch.Tensor, translation: torch.Tensor, invert: bool) -> torch.Tensor:
+    rotation_deg = _req(rotation_deg, "rotation")
+    translation = _req(translation, "translation")
+    b = rotation_deg.shape[0]
+    if rotation_deg.shape != (b, 3) or translation.shape != (b, 3):
+        raise RuntimeError(f"rt_theta: expected [B,3] and [B,3], got {tuple(rotation_deg.shape)} {tuple(translation.shape)}")
+    theta = torch.empty((b, 3, 4), dtype=torch.float32, device=rotation_deg.device)
+    lib = _lib.load()
+    _lib.check(lib.mphip_rt_theta(_ptr(rotation_deg), _ptr(translation), _ptr(theta), b, int(bool(invert)), _stream()),
+               "mphip_rt_theta")
+    return theta
+
+
+def warp_field_compose(theta: torch.Tensor, em: torch.Tensor, grid_size: int = 64, parts: bool = False):
+    theta = _req(theta, "theta")
+    em = _req(em, "em")
+    b = theta.shape[0]
+    if theta.shape != (b, 3, 4) or em.dim() != 5 or em.shape[0] != b or em.shape[1] != 3:
+        raise RuntimeError(f"warp_field_compose: bad shapes theta={tuple(theta.shape)} em={tuple(em.shape)}")
+    g = grid_size
+    w = torch.empty((b, 3, g, g, g), dtype=torch.float32, device=theta.device)
+    rt = torch.empty_like(w) if parts else None
+    e64 = torch.empty_like(w) if parts else None
+    lib = _lib.load()
+    _lib.check(lib.mphip_warp_field_compose(_ptr(theta), _ptr(em), _ptr(affine_base_table(g, theta.device)), _ptr(w),
+                                            _ptr(rt), _ptr(e64), b, em.shape[2], em.shape[3], em.shape[4], g, _stream()),
+               "mphip_warp_field_compose")
+    return (w, rt, e64) if parts else w
+
+
+# ------------------------------------------------------------------ K2 / K3
+def warp_volume(v: torch.Tensor, field: torch.Tensor, return_coords: bool = False):
+    v = _req(v, "v")
+    field = _req(field, "warp_field")
+    if v.dim() != 5 or field.dim() != 5 or field.shape[0] != v.shape[0] or field.shape[1] != 3:
+        raise RuntimeError(f"warp_volume: bad shapes v={tuple(v.shape)} field={tuple(field.shape)}")
+    b, c, d, h, w = v.shape
+    out = torch.empty_like(v)
+    coords = idx = None
+    if return_coords:
+        coords = torch.empty((b, d, h, w, 3), dtype=torch.float32, device=v.device)
+        idx = torch.empty((b, d, h, w, 3), dtype=torch.int32, device=v.device)
+    dev = v.device
+    lib = _lib.load()
+    _lib.check(lib.mphip_warp_volume(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
+                                     _ptr(linspace_table(w, dev)), _ptr(out), _ptr(coords), _ptr(idx), b, c, d, h, w,
+                                     field.shape[2], field.shape[3], field.shape[4], _stream()), "mphip_warp_volume")
+    return (out, coords, idx) if return_coords else out
+
+
+def warp_volume_dsum(v: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
+    v = _req(v, "v")
+    field = _req(field, "warp_field")
+    if v.dim() != 5 or field.dim() != 5 or field.shape[0] != v.shape[0] or field.shape[1] != 3:
+        raise RuntimeError(f"warp_volume_dsum: bad shapes v={tuple(v.shape)} field={tuple(field.shape)}")
+    b, c, d, h, w = v.shape
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=v.device)
+    dev = v.device
+    lib = _lib.load()
+    _lib.check(lib.mphip_warp_volume_dsum(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
+                                          _ptr(linspace_table(w, dev)), _ptr(out), b, c, d, h, w, field.shape[2],
+                                          field.shape[3], field.shape[4], _stream()), "mphip_warp_volume_dsum")
+    return out
+
+
+# ------------------------------------------------------------------ K4 / K5
+class PackedConv:
+    """Packed weights of one Conv3d/1x1 Conv2d ([k^3][CiP][CoP], see include/mphip.h) + bias."""
+
+    __slots__ = ("wp", "bias", "co", "ci", "k")
+
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+        weight = _req(weight.detach(), "conv weight")
+        co, ci = weight.shape[0], weight.shape[1]
+        k = weight.shape[2]
+        if weight.dim() == 4:  # Conv2d 1x1 (model.py:425)
+            if tuple(weight.shape[2:]) != (1, 1):
+                raise RuntimeError("PackedConv: only 1x1 Conv2d is on the hot path")
+        elif weight.dim() != 5 or tuple(weight.shape[2:]) != (k, k, k) or k not in (1, 3):
+            raise RuntimeError(f"PackedConv: unsupported weight shape {tuple(weight.shape)}")
+        lib = _lib.load()
+        n = lib.mphip_packed_weight_elems(co, ci, k)
+        self.wp = torch.empty(n, dtype=torch.float32, device=weight.device)
+        _lib.check(lib.mphip_pack_conv_weight(_ptr(weight), _ptr(self.wp), co, ci, k, _stream()), "mphip_pack_conv_weight")
+        self.bias = None if bias is None else _req(bias.detach(), "conv bias").clone()
+        self.co, self.ci, self.k = co, ci, k
+
+
+def conv3d(x: torch.Tensor, pc: PackedConv, precision: int = 0) -> torch.Tensor:
+    x = _req(x, "x")
+    if x.dim() != 5 or x.shape[1] != pc.ci:
+        raise RuntimeError(f"conv3d: input {tuple(x.shape)} does not match Ci={pc.ci}")
+    n, ci, d, h, w = x.shape
+    y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
+    _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(pc.wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, precision,
+                                    _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
+    return y
+
+
+# ------------------------------------------------------------------ K6
+def groupnorm_stats(x: torch.Tensor, groups: int, eps: float = 1e-5) -> torch.Tensor:
+    x = _req(x, "x")
+    n, c = x.shape[0], x.shape[1]
+    s = x.numel() // (n * c)
+    stats = torch.empty((n * groups, 2), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    ws_bytes = lib.mphip_groupnorm_workspace_bytes(n, c, s, groups)
+    if ws_bytes == 0:
+        raise RuntimeError(f"groupnorm_stats: bad dims C={c} G={groups}")
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=x.device)
+    _lib.check(lib.mphip_groupnorm_stats(_ptr(x), _ptr(stats), n, c, s, groups, eps, _ptr(ws), ws_bytes, _stream()),
+               "mphip_groupnorm_stats")
+    return stats
+
+
+def groupnorm_apply(x, stats, gamma, beta, groups: int, w2=None, b2=None, residual=None, relu=False, tanh=False,
+                    pool2=False) -> torch.Tensor:
+    x = _req(x, "x")
+    if x.dim() != 5:
+        raise RuntimeError("groupnorm_apply: expected a 5-D NCDHW tensor")
+    n, c, d, h, w = x.shape
+    gamma, beta = _req(gamma.detach(), "gamma"), _req(beta.detach(), "beta")
+    if w2 is not None:
+        w2, b2 = _req(w2.detach(), "w2").reshape(-1), _req(b2.detach(), "b2").reshape(-1)
+    if residual is not None:
+        residual = _req(residual, "residual")
+        if residual.shape != x.shape:
+            raise RuntimeError("groupnorm_apply: residual shape mismatch")
+    oshape = (n, c, d // 2, h // 2, w // 2) if pool2 else (n, c, d, h, w)
+    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
+    lib = _lib.load()
+    _lib.check(lib.mphip_groupnorm_apply(_ptr(x), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(residual),
+                                         _ptr(y), n, c, d, h, w, groups, int(relu), int(tanh), int(pool2), _stream()),
+               "mphip_groupnorm_apply")
+    return y
+
+
+# ------------------------------------------------------------------ K7
+def avgpool2(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, "x")
+    n, c, d, h, w = x.shape
+    y = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mphip_avgpool2(_ptr(x), _ptr(y), n * c, d, h, w, _stream()), "mphip_avgpool2")
+    return y
+
+
+def upsample_trilinear2(x: torch.Tensor) -> torch.Tensor:
+    x = _req(x, "x")
+    n, c, d, h, w = x.shape
+    y = torch.empty((n, c, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mphip_upsample_trilinear2(_ptr(x), _ptr(y), n * c, d, h, w, _stream()),
+               "mphip_upsample_trilinear2")
+    return y
+
+
+def upsample_nearest(x: torch.Tensor, scale: Tuple[int, int, int]) -> torch.Tensor:
+    x = _req(x, "x")
+    n, c, d, h, w = x.shape
+    sd, sh, sw = scale
+    y = torch.empty((n, c, d * sd, h * sh, w * sw), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mphip_upsample_nearest(_ptr(x), _ptr(y), n * c, d, h, w, sd, sh, sw, _stream()),
+               "mphip_upsample_nearest")
+    return y
+
+
+# ------------------------------------------------------------------ K8
+def add_matmul(a: torch.Tensor, a2: Optional[torch.Tensor], m: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               trans: bool = False) -> torch.Tensor:
+    a = _req(a, "a")
+    a2 = None if a2 is None else _req(a2, "a2")
+    m = _req(m.detach(), "m")
+    bias = None if bias is None else _req(bias.detach(), "bias")
+    b, k = a.shape
+    n = m.shape[0] if trans else m.shape[1]
+    if (m.shape[1] if trans else m.shape[0]) != k:
+        raise RuntimeError(f"add_matmul: inner dims differ: a={tuple(a.shape)} m={tuple(m.shape)} trans={trans}")
+    out = torch.empty((b, n), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().mphip_add_matmul(_ptr(a), _ptr(a2), _ptr(m), _ptr(bias), _ptr(out), b, k, n, int(trans),
+                                            _stream()), "mphip_add_matmul")
+    return out

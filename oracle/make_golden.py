@@ -1,0 +1,129 @@
+"""Generates tests/golden/*.npz by running the REFERENCE ITSELF (imported from /root/reference,
+this container only) on seeded inputs/weights.  Only outputs are stored: inputs and weights are
+regenerated anywhere from the integer PRNG in oracle/hotpath_ref.py (seeded_*).
+
+    python -m oracle.make_golden            # rewrites tests/golden/
+
+TEST INFRASTRUCTURE.  Fixtures are data (tensors), never reference source.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import hotpath_ref as R
+from .import_reference import load_reference_model
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+WEIGHT_SEED = 7
+INPUT_SEED = 3
+
+
+def _load(mod, sd, prefix):
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    mod.load_state_dict(sub, strict=True)
+    return mod.eval()
+
+
+def _sha(t: torch.Tensor) -> str:
+    return hashlib.sha1(t.contiguous().numpy().tobytes()).hexdigest()
+
+
+def main():
+    m = load_reference_model()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    sd = R.seeded_gbase_hot_state_dict(WEIGHT_SEED)
+    s2c = _load(m.WarpGeneratorS2C(512), sd, "warp_generator_s2c.")
+    c2d = _load(m.WarpGeneratorC2D(512), sd, "warp_generator_c2d.")
+    g3d = _load(m.G3d(96), sd, "G3d.")
+    manifest = {"weight_seed": WEIGHT_SEED, "input_seed": INPUT_SEED, "torch": torch.__version__}
+
+    with torch.no_grad():
+        # (1) compute_rt_warp, model.py:777-809 — 8 poses x {invert}, grid 8 full + grid 64 strided
+        rot = R.seeded_tensor((8, 3), 101, scale=30.0)
+        tr = R.seeded_tensor((8, 3), 102, scale=0.17)
+        np.savez(os.path.join(OUT, "rt_warp.npz"),
+                 g8=m.compute_rt_warp(rot, tr, invert=False, grid_size=8).numpy(),
+                 g8_inv=m.compute_rt_warp(rot, tr, invert=True, grid_size=8).numpy(),
+                 g64_s8=m.compute_rt_warp(rot, tr, invert=False, grid_size=64)[:, :, ::8, ::8, ::8].contiguous().numpy(),
+                 g64_inv_s8=m.compute_rt_warp(rot, tr, invert=True, grid_size=64)[:, :, ::8, ::8, ::8].contiguous().numpy())
+
+        # (2) FlowField, model.py:439-471 — B=2
+        zsum = R.seeded_tensor((2, 512), 103, scale=20.0)
+        ff = s2c.flowfield(zsum.unsqueeze(-1).unsqueeze(-1), 0, 0)
+        np.savez(os.path.join(OUT, "flowfield.npz"), out=ff.numpy())
+
+        # (3) WarpGeneratorS2C / C2D, model.py:938-975 / 989-1024 — B=1, stride-4 samples
+        inp = R.seeded_hot_inputs(1, INPUT_SEED)
+        w_s2c = s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
+        w_c2d = c2d(inp["Rd"], inp["td"], inp["zd"], inp["es"])
+        np.savez(os.path.join(OUT, "warp_generator.npz"),
+                 s2c_s4=w_s2c[:, :, ::4, ::4, ::4].contiguous().numpy(), c2d_s4=w_c2d[:, :, ::4, ::4, ::4].contiguous().numpy(),
+                 s2c_sha1=_sha(w_s2c), c2d_sha1=_sha(w_c2d))
+
+        # (4) apply_warping_field, model.py:1028-1065
+        #   small: v [1,8,16,16,16] with the S2C field, full output + ramp-derived coordinates
+        v_small = R.seeded_tensor((1, 8, 16, 16, 16), 104, scale=1.7)
+        out_small = m.apply_warping_field(v_small, w_s2c)
+        ramp = torch.zeros(1, 3, 16, 16, 16)
+        ramp[:, 0] = torch.arange(16.0).view(1, 1, 1, 16)
+        ramp[:, 1] = torch.arange(16.0).view(1, 1, 16, 1)
+        ramp[:, 2] = torch.arange(16.0).view(1, 16, 1, 1)
+        coords_small = m.apply_warping_field(ramp, w_s2c).permute(0, 2, 3, 4, 1).contiguous()
+        #   wide field (covers the whole volume; the faithful field only reaches the 4^3 corner)
+        wide = R.seeded_tensor((1, 3, 64, 64, 64), 105, scale=1.0)
+        wide = (wide + 1.0) * torch.tensor([9.0, 9.0, 9.0]).view(1, 3, 1, 1, 1) - 2.0
+        out_wide = m.apply_warping_field(v_small, wide)
+        #   full-size volume: strided samples + per-channel sums + sha1
+        vs = inp["vs"]
+        vc = m.apply_warping_field(vs, w_s2c)
+        np.savez(os.path.join(OUT, "apply_warping_field.npz"), small=out_small.numpy(), coords_small=coords_small.numpy(),
+                 wide=out_wide.numpy(), full_s4=vc[:, :, ::2, ::4, ::4].contiguous().numpy(),
+                 full_chan_sum=vc.double().sum(dim=(2, 3, 4)).numpy(), full_sha1=_sha(vc))
+
+        # (5) ResBlock3D (96->96, 96->192) on 8^3; ResBlock3D_Adaptive (64->32) on 8^3
+        x8 = R.seeded_tensor((1, 96, 8, 8, 8), 106, scale=1.7)
+        rb_same = g3d.downsampling[0](x8.clone())
+        rb_wide = g3d.downsampling[2](x8.clone())
+        x64 = R.seeded_tensor((1, 64, 8, 8, 8), 107, scale=1.7)
+        rba = s2c.flowfield.resblock4(x64.clone())
+        np.savez(os.path.join(OUT, "resblocks.npz"), rb_96_96=rb_same.numpy(), rb_96_192=rb_wide.numpy(), rba_64_32=rba.numpy())
+
+        # (6) G3d: full output at 96x8x8x8; 96x16x16x16 B=2 strided; full-size strided + stats
+        g_small = g3d(x8.clone())
+        x16 = R.seeded_tensor((2, 96, 16, 16, 16), 108, scale=1.7)
+        g_mid = g3d(x16.clone())
+        vc2d = g3d(vc)
+        np.savez(os.path.join(OUT, "g3d.npz"), small=g_small.numpy(), mid_s2=g_mid[:, :, ::2, ::2, ::2].contiguous().numpy(),
+                 full_s4=vc2d[:, :, ::2, ::4, ::4].contiguous().numpy(), full_chan_mean=vc2d.double().mean(dim=(2, 3, 4)).numpy(),
+                 full_chan_absmax=vc2d.abs().amax(dim=(2, 3, 4)).numpy())
+
+        # (7) end-to-end hot slice, model.py:1151-1171, full size [1,96,64,64] + a 16^3 case
+        proj = torch.sum(m.apply_warping_field(vc2d, w_c2d), dim=2)
+        inp16 = R.seeded_hot_inputs(1, INPUT_SEED + 1, D=16, H=16, W=16)
+        w1 = s2c(inp16["Rs"], inp16["ts"], inp16["zs"], inp16["es"])
+        w2 = c2d(inp16["Rd"], inp16["td"], inp16["zd"], inp16["es"])
+        proj16 = torch.sum(m.apply_warping_field(g3d(m.apply_warping_field(inp16["vs"], w1)), w2), dim=2)
+        np.savez(os.path.join(OUT, "hot_slice.npz"), full=proj.numpy(), small16=proj16.numpy())
+
+    # (8) state-dict manifest (names/shapes are the checkpoint-layout contract)
+    manifest["state_dict"] = {
+        "warp_generator_s2c": {k: list(v.shape) for k, v in s2c.state_dict().items()},
+        "warp_generator_c2d": {k: list(v.shape) for k, v in c2d.state_dict().items()},
+        "G3d": {k: list(v.shape) for k, v in g3d.state_dict().items()},
+    }
+    with open(os.path.join(OUT, "manifest.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    for fn in sorted(os.listdir(OUT)):
+        print(fn, os.path.getsize(os.path.join(OUT, fn)))
+
+
+if __name__ == "__main__":
+    main()
