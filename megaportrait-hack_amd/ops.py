@@ -35,15 +35,37 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
 
 # ------------------------------------------------------------------ host-built tables
 _tables = {}
+_captured = None
+
+
+def _captured_tables():
+    """fp32 bit patterns of the reference host's torch.linspace tables (data/linspace_tables.json,
+    written by oracle/make_golden.py:capture_tables).  ATen's linspace has no closed form and its
+    bits depend on the host ISA; the hot-path sizes (16, 64) are therefore
+    data, which keeps the index pipeline identical on every host.  Other sizes fall back to the
+    local host's torch.linspace."""
+    global _captured
+    if _captured is None:
+        import json
+        import os
+
+        import numpy as np
+
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "linspace_tables.json")
+        with open(path) as f:
+            raw = json.load(f)
+        _captured = {kind: {int(n): torch.from_numpy(np.array(bits, dtype=np.uint32).view(np.float32).copy())
+                            for n, bits in raw[kind].items()} for kind in ("linspace", "affine_base")}
+    return _captured
 
 
 def linspace_table(n: int, device) -> torch.Tensor:
-    """torch.linspace(-1,1,n) evaluated by the HOST CPU kernel (model.py:1040-1042 on a CPU
-    host), uploaded once.  ATen's linspace has no closed form, so the
-    table is data, not recomputed on the GPU."""
+    """torch.linspace(-1,1,n) as the reference's CPU path evaluates it (model.py:1040-1042)."""
     key = ("lin", n, str(device))
     if key not in _tables:
-        _tables[key] = torch.linspace(-1, 1, n, dtype=torch.float32).to(device)
+        cap = _captured_tables()["linspace"].get(n)
+        host = cap if cap is not None else torch.linspace(-1, 1, n, dtype=torch.float32)
+        _tables[key] = host.to(device)
     return _tables[key]
 
 
@@ -51,7 +73,9 @@ def affine_base_table(g: int, device) -> torch.Tensor:
     """Base coordinates of F.affine_grid(..., align_corners=False): linspace(-1,1,G)*(G-1)/G."""
     key = ("aff", g, str(device))
     if key not in _tables:
-        _tables[key] = (torch.linspace(-1, 1, g, dtype=torch.float32) * (g - 1) / g).to(device)
+        cap = _captured_tables()["affine_base"].get(g)
+        host = cap if cap is not None else torch.linspace(-1, 1, g, dtype=torch.float32) * (g - 1) / g
+        _tables[key] = host.to(device)
     return _tables[key]
 
 

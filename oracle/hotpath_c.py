@@ -32,6 +32,36 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_TABLES = None
+
+
+def _tables():
+    """The reference host's torch.linspace tables captured as data by make_golden.capture_tables
+    (same JSON the product reads; data, not code).  Sizes not captured use the local torch."""
+    global _TABLES
+    if _TABLES is None:
+        import json
+
+        import numpy as np
+
+        path = os.path.join(os.path.dirname(_HERE), "megaportrait-hack_amd", "data", "linspace_tables.json")
+        with open(path) as f:
+            raw = json.load(f)
+        _TABLES = {kind: {int(n): torch.from_numpy(np.array(b, dtype=np.uint32).view(np.float32).copy())
+                          for n, b in raw[kind].items()} for kind in ("linspace", "affine_base")}
+    return _TABLES
+
+
+def linspace(n):
+    t = _tables()["linspace"].get(n)
+    return (t if t is not None else torch.linspace(-1, 1, n)).contiguous()
+
+
+def affine_base(g):
+    t = _tables()["affine_base"].get(g)
+    return (t if t is not None else torch.linspace(-1, 1, g) * (g - 1) / g).contiguous()
+
+
 def _c(t):
     assert t.dtype == torch.float32 and not t.is_cuda
     return t.contiguous()
@@ -40,7 +70,7 @@ def _c(t):
 def affine_grid3d(theta, G):
     theta = _c(theta)
     B = theta.shape[0]
-    base = (torch.linspace(-1, 1, G) * (G - 1) / G).contiguous()
+    base = affine_base(G)
     out = torch.empty(B, 3, G, G, G)
     lib().orc_affine_grid3d(_p(theta), _p(base), B, G, _p(out))
     return out
@@ -98,7 +128,7 @@ def warp_coords(warp_field, D, H, W):
     B = f.shape[0]
     coords = torch.empty(B, D, H, W, 3)
     idx = torch.empty(B, D, H, W, 3, dtype=torch.int32)
-    ld, lh, lw = (torch.linspace(-1, 1, n).contiguous() for n in (D, H, W))
+    ld, lh, lw = (linspace(n) for n in (D, H, W))
     lib().orc_warp_coords(_p(f), _p(ld), _p(lh), _p(lw), B, D, H, W, _p(coords), _p(idx))
     return coords, idx
 

@@ -35,7 +35,27 @@ def _sha(t: torch.Tensor) -> str:
     return hashlib.sha1(t.contiguous().numpy().tobytes()).hexdigest()
 
 
+def capture_tables():
+    """The host-CPU `torch.linspace` tables the reference's CPU path uses at the hot-path sizes
+    (model.py:1040-1042 identity grid; affine_grid base = linspace*(G-1)/G), captured as fp32 bit
+    patterns.  ATen's linspace is a vectorised kernel with no closed form and its bits depend on
+    the host ISA, so the tables are DATA shared by the product
+    (megaportrait-hack_amd/data/) and the oracle — both stay host-independent and pinned to the
+    container the goldens were generated in."""
+    tabs = {"torch": torch.__version__, "linspace": {}, "affine_base": {}}
+    for n in (16, 64):
+        tabs["linspace"][str(n)] = torch.linspace(-1, 1, n).numpy().view(np.uint32).tolist()
+    for g in (64,):
+        tabs["affine_base"][str(g)] = (torch.linspace(-1, 1, g) * (g - 1) / g).numpy().view(np.uint32).tolist()
+    path = os.path.join(ROOT, "megaportrait-hack_amd", "data", "linspace_tables.json")
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        json.dump(tabs, f)
+    return path
+
+
 def main():
+    capture_tables()
     m = load_reference_model()
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)

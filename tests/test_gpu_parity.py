@@ -80,8 +80,10 @@ def test_warp_field_compose_bit_exact(ops, dev, oracle_c):
     assert torch.equal(rt.cpu(), rt_ref)                       # == F.affine_grid bit for bit
     assert torch.equal(e64.cpu(), em_ref)                      # == F.interpolate(AC=False) bit for bit
     assert torch.equal(w.cpu(), rt_ref + em_ref)
-    assert torch.equal(rt_ref, F.affine_grid(theta, (3, 1, 64, 64, 64), align_corners=False).permute(0, 4, 1, 2, 3))
-    assert torch.equal(em_ref, F.interpolate(em, size=(64, 64, 64), mode="trilinear", align_corners=False))
+    # this host's ATen CPU kernels (bitwise equal to the C oracle in the build container, see
+    # tests/test_oracle.py; FMA use inside ATen depends on the host ISA, so only a tolerance here)
+    assert maxabs(rt_ref, F.affine_grid(theta, (3, 1, 64, 64, 64), align_corners=False).permute(0, 4, 1, 2, 3)) < 1e-6
+    assert maxabs(em_ref, F.interpolate(em, size=(64, 64, 64), mode="trilinear", align_corners=False)) < 1e-6
 
 
 def test_compute_rt_warp_golden(M, dev):
@@ -112,10 +114,11 @@ def test_warp_volume_indices_bit_exact(ops, dev, oracle_c, kind, shape):
     c_ref, i_ref = oracle_c.warp_coords(field, D, H, W)
     assert torch.equal(coords.cpu(), c_ref), "clipped sample coordinates differ from the oracle"
     assert torch.equal(idx.cpu(), i_ref), "floor indices differ from the oracle"
-    c_aten, i_aten = R.warp_coords(field, D, H, W)
-    assert torch.equal(c_ref, c_aten) and torch.equal(i_ref, i_aten)
+    c_aten, i_aten = R.warp_coords(field, D, H, W)   # this host's ATen: tolerance only (host-ISA dependent bits)
+    assert maxabs(c_ref, c_aten) < 1e-4 and (i_ref != i_aten).float().mean().item() < 1e-4
     want = R.apply_warping_field(v, field)
-    assert maxabs(out, want) <= 1e-6
+    assert maxabs(out, want) <= 1e-4
+    assert torch.equal(out.cpu(), oracle_c.apply_warping_field(v, field))   # values too: bit for bit vs the C oracle
     got_sum = ops.warp_volume_dsum(v.to(dev), field.to(dev))
     assert maxabs(got_sum, want.sum(dim=2)) <= 2e-5
 
@@ -123,7 +126,8 @@ def test_warp_volume_indices_bit_exact(ops, dev, oracle_c, kind, shape):
 def test_apply_warping_field_golden(ops, M, dev, hot, sd):
     g = gold("apply_warping_field")
     inp = R.seeded_hot_inputs(1, INPUT_SEED)
-    w_s2c = hot.warp_generator_s2c(inp["Rs"].to(dev), inp["ts"].to(dev), inp["zs"].to(dev), inp["es"].to(dev))
+    with torch.no_grad():
+        w_s2c = hot.warp_generator_s2c(inp["Rs"].to(dev), inp["ts"].to(dev), inp["zs"].to(dev), inp["es"].to(dev))
     v_small = R.seeded_tensor((1, 8, 16, 16, 16), 104, scale=1.7)
     out, coords, _ = ops.warp_volume(v_small.to(dev), w_s2c, return_coords=True)
     assert maxabs(out, g["small"]) < 1e-4
