@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py — Gbase hot-slice throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot slice (reference model.py:1151-1171: S2C field -> 3D warp ->
+G3d -> C2D field -> 3D warp -> depth sum) over one batch of synthetic 512x512 frames, i.e.
+B x [96,16,64,64] appearance volumes already resident in HBM.  Frames are independent, so N GPUs
+run N independent shards (weak scaling, no data-path collective); rank 0 prints ONE JSON line.
+
+Extra objects on the line:
+  roofline     — the dominant kernel (conv3d 3x3x3 96->96 @16x64x64, 60 % of hot-slice FLOPs):
+                 algorithmic FLOPs per launch / its average launch duration, measured live with
+                 HIP events on the launch stream during the timed steps, vs the dense fp32-MFMA peak.
+  cpu_baseline — the CPU oracle (oracle/hotpath_ref.py, ATen CPU ops = what the reference runs on a
+                 CPU host) timed on this host on a bounded sample, rank 0, N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
+FRAME_FLOPS = 164.1e9          # G3d 163.11 + 2 x FlowField 0.50 GFLOP per frame
+FRAME_BYTES = 309e6            # layer-wise-minimal HBM bytes per frame
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (BASELINE config 2: 8)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline sample (0 = auto, ~15 s)")
+    return ap.parse_args()
+
+
+class DominantKernelTimer:
+    """HIP events around every launch of the dominant conv during the timed region (events are
+    recorded on torch's current stream, which is the stream ops.conv3d launches on)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.events = []
+        self.active = False
+
+    def __call__(self, x, pc, launch):
+        if self.active and tuple(x.shape[1:]) == self.shape[1:] and pc.co == self.shape[0] and pc.k == 3:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            y = launch()
+            e1.record()
+            self.events.append((e0, e1))
+            return y
+        return launch()
+
+    def mean_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
+
+
+def cpu_baseline(frames):
+    """Times the CPU oracle on this host: B=1 frames through oracle.hotpath_ref.hot_slice."""
+    from oracle import hotpath_ref as R
+
+    torch.manual_seed(20240501)
+    sd = R.seeded_gbase_hot_state_dict(7)
+    inp = R.seeded_hot_inputs(1, 3)
+    threads = torch.get_num_threads()
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        R.hot_slice(sd=sd, **inp)                      # warm-up (also sizes the sample)
+        warm = time.perf_counter() - t0
+        if frames <= 0:
+            frames = max(2, min(40, int(15.0 / max(warm, 1e-3))))
+        t0 = time.perf_counter()
+        for _ in range(frames):
+            R.hot_slice(sd=sd, **inp)
+        dt = time.perf_counter() - t0
+    return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"{frames} frames (B=1, 96x16x64x64) through oracle/hotpath_ref.py hot_slice "
+                      f"(ATen CPU fp32, {threads} threads), {dt:.1f} s"}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+
+    from megaportrait_hack_amd import _lib, model as M, ops
+
+    _lib.load()  # fail loudly if libmphip.so is missing
+    B = args.batch
+    torch.manual_seed(20240501 + rank)
+    hot = M.GbaseHotSlice().to(dev).eval()   # PyTorch default init (random weights; no checkpoints offline)
+    g = torch.Generator(device="cpu").manual_seed(20240501 + rank)
+    inp = dict(
+        vs=torch.randn(B, 96, 16, 64, 64, generator=g), es=torch.randn(B, 512, generator=g),
+        zs=torch.randn(B, 512, generator=g), zd=torch.randn(B, 512, generator=g),
+        Rs=(torch.rand(B, 3, generator=g) * 60 - 30), Rd=(torch.rand(B, 3, generator=g) * 60 - 30),
+        ts=torch.randn(B, 3, generator=g) * 0.1, td=torch.randn(B, 3, generator=g) * 0.1)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+
+    dom = DominantKernelTimer((96, 96, 16, 64, 64))
+    ops.set_conv_hook(dom)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            out = hot(**inp)
+        sync_all()
+        dom.active = True
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = hot(**inp)
+        sync_all()
+        dt = time.perf_counter() - t0
+        dom.active = False
+    assert torch.isfinite(out).all()
+
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    dom_ms = dom.mean_ms()
+    dom_flops = 2.0 * B * 16 * 64 * 64 * 96 * 96 * 27
+    line = None
+    if rank == 0:
+        fps = world * B * args.steps / dt
+        achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        line = {
+            "metric": "Gbase fwd hot-slice frames/sec @512^2 (96ch 16x64x64 volume)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Gbase hot slice (model.py:1151-1171): WarpGeneratorS2C -> 3D warp -> G3d -> "
+                                   "WarpGeneratorC2D -> 3D warp + depth sum; BASELINE config 2 (inference 512x512, "
+                                   "96ch 16x64x64 volume), inputs resident in HBM, random-init weights",
+                       "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": f"dp{world} (frame shards, no collective)"},
+            "hot_slice_tflops": round(fps * FRAME_FLOPS / 1e12, 2),
+            "hot_slice_frac_of_f32_mfma_peak": round(fps * FRAME_FLOPS / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
+            "hot_slice_layerwise_GBps": round(fps * FRAME_BYTES / 1e9, 1),
+            "roofline": {"kernel": "conv3d_gather_kernel<3,3,2,1> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)",
+                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launch_ms": round(dom_ms, 4), "launches_timed": len(dom.events),
+                         "flops_per_launch": dom_flops},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

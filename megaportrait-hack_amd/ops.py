@@ -168,18 +168,32 @@ class PackedConv:
         self.co, self.ci, self.k = co, ci, k
 
 
+_conv_hook = None
+
+
+def set_conv_hook(hook) -> None:
+    """Measurement hook (bench.py): hook(x, packed_conv, launch) -> y wraps each conv launch, e.g. to
+    bracket the dominant kernel with HIP events on the launch stream.  None disables it."""
+    global _conv_hook
+    _conv_hook = hook
+
+
 def conv3d(x: torch.Tensor, pc: PackedConv, precision: int = 0) -> torch.Tensor:
     x = _req(x, "x")
     if x.dim() != 5 or x.shape[1] != pc.ci:
         raise RuntimeError(f"conv3d: input {tuple(x.shape)} does not match Ci={pc.ci}")
     n, ci, d, h, w = x.shape
-    y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
     lib = _lib.load()
     ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
-    _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(pc.wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, precision,
-                                    _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
-    return y
+    y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
+
+    def launch():
+        _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(pc.wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k,
+                                        precision, _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
+        return y
+
+    return _conv_hook(x, pc, launch) if _conv_hook is not None else launch()
 
 
 # ------------------------------------------------------------------ K6
