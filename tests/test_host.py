@@ -1,0 +1,119 @@
+"""CPU tests of the host side: the C-ABI library loads and exports every symbol include/mphip.h
+declares, argument validation returns error codes (no GPU work), the nn.Module mirror keeps the
+reference's state-dict layout, and the product path fails loudly without a GPU (no CPU fallback)."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from megaportrait_hack_amd import _lib
+
+    _lib.build()
+    return _lib.load()
+
+
+def test_header_symbols_are_exported(lib):
+    from megaportrait_hack_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "mphip.h")).read()
+    declared = set(re.findall(r"\b(mphip_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), f"{name} declared in mphip.h but not exported by libmphip.so"
+    assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with mphip.h"
+    assert lib.mphip_version() == 1
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    assert lib.mphip_warp_volume(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None) == -1
+    assert b"null pointer" in lib.mphip_last_error()
+    assert lib.mphip_conv3d_fwd(None, None, None, None, 1, 1, 1, 1, 1, 1, 3, 0, None, 0, None) == -1
+    one = ctypes.c_void_p(16)
+    assert lib.mphip_conv3d_fwd(one, one, None, one, 1, 8, 8, 4, 4, 4, 5, 0, None, 0, None) == -1
+    assert b"kernel size" in lib.mphip_last_error()
+    assert lib.mphip_conv3d_fwd(one, one, None, one, 1, 8, 8, 4, 4, 4, 3, 7, None, 0, None) == -1
+    assert lib.mphip_groupnorm_stats(one, one, 1, 30, 8, 32, ctypes.c_float(1e-5), None, 0, None) == -1
+    assert lib.mphip_avgpool2(one, one, 1, 3, 4, 4, None) == -1
+    # pure host helpers
+    assert lib.mphip_packed_weight_elems(96, 96, 3) == 27 * 96 * 96
+    assert lib.mphip_packed_weight_elems(3, 32, 3) == 27 * 32 * 32     # Co padded to 32
+    assert lib.mphip_packed_weight_elems(7, 5, 3) == 27 * 6 * 32       # Ci padded to even
+    assert lib.mphip_packed_weight_elems(4, 4, 2) == 0
+    # split-K workspace only for small volumes
+    assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3) == 0
+    assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3) > 0
+    assert lib.mphip_groupnorm_workspace_bytes(2, 96, 65536, 32) == 2 * 32 * 12 * 16
+
+
+def test_module_state_dict_layout_matches_reference():
+    from megaportrait_hack_amd import model as M
+
+    man = json.load(open(os.path.join(GOLD, "manifest.json")))["state_dict"]
+    hot = M.GbaseHotSlice()
+    ours = {k: list(v.shape) for k, v in hot.state_dict().items()}
+    want = {f"{p}.{k}": s for p, d in man.items() for k, s in d.items()}
+    assert ours == want
+    assert sum(p.numel() for p in hot.G3d.parameters()) == 48564672
+    assert sum(p.numel() for p in hot.warp_generator_s2c.parameters()) == 8807113
+
+
+def test_checkpoint_loading_quirks():
+    from megaportrait_hack_amd import model as M
+    from oracle import hotpath_ref as R
+
+    sd = R.seeded_gbase_hot_state_dict(7)
+    hot = M.GbaseHotSlice()
+    missing, tolerated = M.load_hot_state_dict(hot, sd)
+    assert not missing and not tolerated
+    assert torch.equal(hot.G3d.final_conv.weight, sd["G3d.final_conv.weight"])
+    # a GPU-built reference checkpoint has no adaptive_matrix_* keys (model.py:934-935 quirk)
+    gpu_built = {k: v for k, v in sd.items() if "adaptive_matrix" not in k}
+    missing, tolerated = M.load_hot_state_dict(M.GbaseHotSlice(), gpu_built)
+    assert not missing and len(tolerated) == 4
+    # extra keys of a full Gbase checkpoint (Eapp, G2d, ...) are ignored
+    full = dict(sd, **{"G2d.conv1.weight": torch.zeros(1), "appearanceEncoder.conv.weight": torch.zeros(1)})
+    M.load_hot_state_dict(M.GbaseHotSlice(), full)
+    with pytest.raises(KeyError):
+        M.load_hot_state_dict(M.GbaseHotSlice(), {k: v for k, v in sd.items() if "final_conv" not in k})
+
+
+def test_no_cpu_fallback():
+    from megaportrait_hack_amd import model as M, ops
+
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.warp_volume(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 3, 4, 4, 4))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        with torch.no_grad():
+            M.G3d(96)(torch.zeros(1, 96, 8, 8, 8))
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            M.apply_warping_field(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 3, 4, 4, 4))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "megaportrait-hack_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".sh")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "hotpath_c" not in txt, f
+
+
+def test_captured_tables_match_this_host_or_warn():
+    from megaportrait_hack_amd import ops
+
+    cap = ops._captured_tables()
+    assert set(cap["linspace"]) == {16, 64} and set(cap["affine_base"]) == {64}
+    for n, t in cap["linspace"].items():
+        assert t[0] == -1.0 and t[-1] == 1.0 and (t[1:] > t[:-1]).all()
+        assert (t - torch.linspace(-1, 1, n)).abs().max() < 2e-7   # same values up to the host's last-bit choices
