@@ -61,18 +61,23 @@ int mphip_warp_field_compose(const float *theta, const float *em, const float *b
  *   F.interpolate(field,(D,H,W),'trilinear',align_corners=True) + linspace identity grid
  *   + 2*g/(S-1)-1 + F.grid_sample(v, grid, 'bilinear', 'border', align_corners=True).
  * v [B,C,D,H,W], field [B,3,fD,fH,fW], lin_d/h/w = torch.linspace(-1,1,S) host-built tables
- * on the device -> out [B,C,D,H,W].  Optional (may be NULL) debug outputs for the bit-exact
- * index contract: coords_out [B,D,H,W,3] float (clipped x,y,z), idx_out [B,D,H,W,3] int32. */
+ * on the device -> out [B,C,D,H,W].  Two launches: a coordinate pass (the bit-exact index
+ * chain, 12 B per voxel into `workspace`, mphip_warp_workspace_bytes()) and the gather pass
+ * (source bounding box of each tile staged in LDS).  Optional outputs for the index contract:
+ * coords_out [B,D,H,W,3] float (clipped x,y,z; when given it replaces the workspace),
+ * idx_out [B,D,H,W,3] int32 (floor indices; requires coords_out). */
+size_t mphip_warp_workspace_bytes(int B, int D, int H, int W);
 int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
                       const float *lin_w, float *out, float *coords_out, int32_t *idx_out, int B, int C,
-                      int D, int H, int W, int fD, int fH, int fW, void *stream);
+                      int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
+                      void *stream);
 
 /* ------------------------------------------------------------------ K3  warp + depth projection
  * Replaces apply_warping_field (model.py:1167) fused with torch.sum(dim=2) (model.py:1171):
  * out [B,C,H,W] = sum_d warp(v, field)[b,c,d,h,w]; the warped volume is never written.     */
 int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
                            const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
-                           int fH, int fW, void *stream);
+                           int fH, int fW, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ K4/K5  Conv3d k=3 / k=1
  * Replaces nn.Conv3d(Ci,Co,3,padding=1) (model.py:505,507,591,374-375,458) and

@@ -25,8 +25,9 @@ SIGNATURES = {
     "mphip_last_error": (ctypes.c_char_p, []),
     "mphip_rt_theta": (_i, [_p, _p, _p, _i, _i, _p]),
     "mphip_warp_field_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
-    "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
-    "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_warp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_packed_weight_elems": (_sz, [_i, _i, _i]),
     "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _p]),
     "mphip_conv3d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),

@@ -116,116 +116,268 @@ __device__ __forceinline__ float gather8(const float *__restrict__ vol, const Ta
     return acc;
 }
 
-// K2: each thread owns VW consecutive w of one (b,d,h) row and a slice of CPB channels
-// (blockIdx.y); stores are VW*4-byte vectors, consecutive lanes -> consecutive addresses.
-template <int VW>
+// ---- coordinate pass -------------------------------------------------------------------------
+// One thread per output voxel: coords[B,D,H,W,3] = clipped (x,y,z) sample coordinates (and the
+// floor indices for the tests).  12 B per voxel (0.79 MB per 512^2 frame, 3 % of K2's traffic);
+// K2/K3 read it back instead of re-deriving the chain per channel slice.
+// INPLANE: fH==H && fW==W -> the align_corners=True resize is the identity in H,W (weights exactly
+// (1,0)), so only the depth lerp remains — bitwise the same value as the full 8-corner form.
+template <bool INPLANE>
 __global__ void __launch_bounds__(256)
-warp_volume_kernel(const float *__restrict__ v, const float *__restrict__ field, const float *__restrict__ lin_d,
-                   const float *__restrict__ lin_h, const float *__restrict__ lin_w, float *__restrict__ out,
-                   float *__restrict__ coords_out, int32_t *__restrict__ idx_out, int B, int C, int D, int H, int W,
-                   int fD, int fH, int fW, int cpb) {
-    const int WV = W / VW;
-    const size_t nthreads = (size_t)B * D * H * WV;
+warp_coords_kernel(const float *__restrict__ field, const float *__restrict__ lin_d, const float *__restrict__ lin_h,
+                   const float *__restrict__ lin_w, float *__restrict__ coords, int32_t *__restrict__ idx, int B,
+                   int D, int H, int W, int fD, int fH, int fW) {
+    const size_t n = (size_t)B * D * H * W;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
-    int wv = (int)(t % WV);
-    size_t r = t / WV;
+    if (t >= n) return;
+    int w = (int)(t % W);
+    size_t r = t / W;
     int h = (int)(r % H);
     r /= H;
     int d = (int)(r % D);
     int b = (int)(r / D);
-    const int w0 = wv * VW;
-    const size_t vol = (size_t)D * H * W;
+    Coord3 c;
+    if (INPLANE) {
+        const SrcIdx sd = src_index<true>(d, fD, D);
+        const size_t fvol = (size_t)fD * fH * fW;
+        const float *f0 = field + (size_t)b * 3 * fvol + ((size_t)sd.i0 * fH + h) * fW + w;
+        const float *f1 = field + (size_t)b * 3 * fvol + ((size_t)sd.i1 * fH + h) * fW + w;
+        c.x = coord_axis(lin_w[w], lerp2(sd.l0, f0[0], sd.l1, f1[0]), (float)(W - 1));
+        c.y = coord_axis(lin_h[h], lerp2(sd.l0, f0[fvol], sd.l1, f1[fvol]), (float)(H - 1));
+        c.z = coord_axis(lin_d[d], lerp2(sd.l0, f0[2 * fvol], sd.l1, f1[2 * fvol]), (float)(D - 1));
+    } else {
+        c = sample_coord(field, lin_d, lin_h, lin_w, b, d, h, w, D, H, W, fD, fH, fW);
+    }
+    coords[t * 3] = c.x;
+    coords[t * 3 + 1] = c.y;
+    coords[t * 3 + 2] = c.z;
+    if (idx) {
+        idx[t * 3] = (int)floorf(c.x);
+        idx[t * 3 + 1] = (int)floorf(c.y);
+        idx[t * 3 + 2] = (int)floorf(c.z);
+    }
+}
 
-    Taps taps[VW];
+// ---- gather pass -----------------------------------------------------------------------------
+// The source voxels a tile of output voxels needs form a small box when the warp is smooth (the
+// reference's own fields move samples by a few voxels: SURVEY.md §0 quirk 1).  Each workgroup
+// finds that bounding box with a wavefront-shuffle + LDS min/max reduction, stages the box for a
+// slice of channels into LDS with coalesced row reads, and does the 8-tap trilinear gather from
+// LDS (neighbouring lanes hit the same or adjacent words: broadcast, no bank conflicts).  A box
+// that does not fit (wild fields) falls back to gathering from global memory.
+constexpr int STAGE_FLOATS = 12288;  // 48 KB of LDS for the staged box
+
+struct Box {
+    int ox, oy, oz, ex, ey, ez;
+};
+
+__device__ __forceinline__ int wave_min(int v) {
 #pragma unroll
-    for (int i = 0; i < VW; ++i) {
-        Coord3 c = sample_coord(field, lin_d, lin_h, lin_w, b, d, h, w0 + i, D, H, W, fD, fH, fW);
-        taps[i] = make_taps(c, D, H, W);
-        if (blockIdx.y == 0 && coords_out) {
-            size_t o = ((((size_t)b * D + d) * H + h) * W + w0 + i) * 3;
-            coords_out[o] = c.x;
-            coords_out[o + 1] = c.y;
-            coords_out[o + 2] = c.z;
-            if (idx_out) {
-                idx_out[o] = (int)floorf(c.x);
-                idx_out[o + 1] = (int)floorf(c.y);
-                idx_out[o + 2] = (int)floorf(c.z);
-            }
+    for (int s = 32; s >= 1; s >>= 1) v = min(v, __shfl_xor(v, s, 64));
+    return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = max(v, __shfl_xor(v, s, 64));
+    return v;
+}
+
+// Block-wide bounding box of the (x0,y0,z0) corners, extended by the +1 corner and clamped.
+__device__ __forceinline__ Box block_box(int lx, int ly, int lz, int hx, int hy, int hz, int D, int H, int W,
+                                         int *red /* >= 24 ints of LDS */) {
+    lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
+    hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave * 6 + 0] = lx; red[wave * 6 + 1] = ly; red[wave * 6 + 2] = lz;
+        red[wave * 6 + 3] = hx; red[wave * 6 + 4] = hy; red[wave * 6 + 5] = hz;
+    }
+    __syncthreads();
+    Box bx;
+    bx.ox = min(min(red[0], red[6]), min(red[12], red[18]));
+    bx.oy = min(min(red[1], red[7]), min(red[13], red[19]));
+    bx.oz = min(min(red[2], red[8]), min(red[14], red[20]));
+    int mx = max(max(red[3], red[9]), max(red[15], red[21]));
+    int my = max(max(red[4], red[10]), max(red[16], red[22]));
+    int mz = max(max(red[5], red[11]), max(red[17], red[23]));
+    bx.ex = min(mx + 1, W - 1) - bx.ox + 1;
+    bx.ey = min(my + 1, H - 1) - bx.oy + 1;
+    bx.ez = min(mz + 1, D - 1) - bx.oz + 1;
+    return bx;
+}
+
+// Stage channels [c0, c0+cs) of the box into lds[c][z][y][x].  Lane -> box element (decoded once
+// per 64-element chunk), waves stride over channels.
+__device__ __forceinline__ void stage_box(const float *__restrict__ vb /* v + b*C*vol */, float *lds, const Box &bx,
+                                          int c0, int cs, int H, int W, size_t vol) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int exy = bx.ex * bx.ey, bvol = exy * bx.ez;
+    for (int r = lane; r < bvol; r += 64) {
+        int z = r / exy, r2 = r - z * exy;
+        int y = r2 / bx.ex, x = r2 - y * bx.ex;
+        const float *src = vb + (size_t)c0 * vol + ((size_t)(bx.oz + z) * H + bx.oy + y) * W + bx.ox + x;
+        float *dst = lds + r;
+        for (int c = wave; c < cs; c += 4) dst[c * bvol] = src[(size_t)c * vol];
+    }
+}
+
+__device__ __forceinline__ Taps rebase(const Taps &t, int x0, int y0, int z0, const Box &bx) {
+    Taps r = t;
+    r.base = ((z0 - bx.oz) * bx.ey + (y0 - bx.oy)) * bx.ex + (x0 - bx.ox);
+    r.dy = t.dy ? bx.ex : 0;
+    r.dz = t.dz ? bx.ex * bx.ey : 0;
+    return r;
+}
+
+// K2: a workgroup owns 1024 consecutive (h,w) positions of one (b,d) plane, 4 consecutive w per
+// thread (16-byte stores, a wave writes 1 KB contiguous), all C channels.
+__global__ void __launch_bounds__(256)
+warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out, int B,
+                   int C, int D, int H, int W) {
+    __shared__ float lds[STAGE_FLOATS];
+    __shared__ int red[24];
+    const int HW = H * W;
+    const int tiles = (HW + 1023) / 1024;
+    const int tile = blockIdx.x % tiles;
+    const int bd = blockIdx.x / tiles;
+    const int d = bd % D, b = bd / D;
+    const int p0 = tile * 1024 + threadIdx.x * 4;
+    const bool active = p0 < HW;  // W % 4 == 0 -> a thread's 4 positions share a row and validity
+    const size_t vol = (size_t)D * HW;
+
+    Taps taps[4];
+    int x0[4], y0[4], z0[4];
+    int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
+    if (active) {
+        const float *cp = coords + (((size_t)b * D + d) * HW + p0) * 3;
+        float cf[12];
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            float4 t4 = *reinterpret_cast<const float4 *>(cp + q * 4);
+            cf[q * 4] = t4.x; cf[q * 4 + 1] = t4.y; cf[q * 4 + 2] = t4.z; cf[q * 4 + 3] = t4.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Coord3 c{cf[i * 3], cf[i * 3 + 1], cf[i * 3 + 2]};
+            taps[i] = make_taps(c, D, H, W);
+            x0[i] = (int)floorf(c.x); y0[i] = (int)floorf(c.y); z0[i] = (int)floorf(c.z);
+            lx = min(lx, x0[i]); ly = min(ly, y0[i]); lz = min(lz, z0[i]);
+            hx = max(hx, x0[i]); hy = max(hy, y0[i]); hz = max(hz, z0[i]);
         }
     }
-    const int c_begin = blockIdx.y * cpb;
-    const int c_end = min(C, c_begin + cpb);
-    const size_t ooff = ((size_t)d * H + h) * W + w0;
-    for (int c = c_begin; c < c_end; ++c) {
-        const float *src = v + ((size_t)b * C + c) * vol;
-        float res[VW];
+    const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
+    const int bvol = bx.ex * bx.ey * bx.ez;
+    const int cs_max = bvol > 0 ? STAGE_FLOATS / bvol : 0;
+    const float *vb = v + (size_t)b * C * vol;
+    float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
+
+    if (cs_max >= 8 || cs_max >= C) {  // block-uniform
+        Taps lt[4];
+        if (active) {
 #pragma unroll
-        for (int i = 0; i < VW; ++i) res[i] = gather8(src, taps[i]);
-        float *dst = out + ((size_t)b * C + c) * vol + ooff;
-        if (VW == 4) {
-            *reinterpret_cast<float4 *>(dst) = make_float4(res[0], res[1], res[2], res[3]);
-        } else {
-#pragma unroll
-            for (int i = 0; i < VW; ++i) dst[i] = res[i];
+            for (int i = 0; i < 4; ++i) lt[i] = rebase(taps[i], x0[i], y0[i], z0[i], bx);
+        }
+        for (int c0 = 0; c0 < C; c0 += cs_max) {
+            const int cs = min(cs_max, C - c0);
+            if (c0) __syncthreads();
+            stage_box(vb, lds, bx, c0, cs, H, W, vol);
+            __syncthreads();
+            if (active) {
+                for (int c = 0; c < cs; ++c) {
+                    const float *src = lds + c * bvol;
+                    float4 r;
+                    r.x = gather8(src, lt[0]); r.y = gather8(src, lt[1]);
+                    r.z = gather8(src, lt[2]); r.w = gather8(src, lt[3]);
+                    *reinterpret_cast<float4 *>(ob + (size_t)(c0 + c) * vol) = r;
+                }
+            }
+        }
+    } else if (active) {
+        for (int c = 0; c < C; ++c) {
+            const float *src = vb + (size_t)c * vol;
+            float4 r;
+            r.x = gather8(src, taps[0]); r.y = gather8(src, taps[1]);
+            r.z = gather8(src, taps[2]); r.w = gather8(src, taps[3]);
+            *reinterpret_cast<float4 *>(ob + (size_t)c * vol) = r;
         }
     }
 }
 
-// K3: each thread owns VW consecutive w of one (b,h) row and CPT channels; loops the D output
-// slices accumulating the depth projection in registers (sum order d=0..D-1 like torch.sum).
-template <int VW, int CPT>
+// K3: a workgroup owns 256 consecutive (h,w) positions of one frame and CPB channels; every thread
+// walks the D output slices of its position accumulating the depth projection in registers
+// (d ascending, like torch.sum(dim=2) on the warped volume, which is never written).
+template <int CPB>
 __global__ void __launch_bounds__(256)
-warp_volume_dsum_kernel(const float *__restrict__ v, const float *__restrict__ field,
-                        const float *__restrict__ lin_d, const float *__restrict__ lin_h,
-                        const float *__restrict__ lin_w, float *__restrict__ out, int B, int C, int D, int H, int W,
-                        int fD, int fH, int fW) {
-    const int WV = W / VW;
-    const size_t nthreads = (size_t)B * H * WV;
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nthreads) return;
-    int wv = (int)(t % WV);
-    size_t r = t / WV;
-    int h = (int)(r % H);
-    int b = (int)(r / H);
-    const int w0 = wv * VW;
-    const size_t vol = (size_t)D * H * W;
-    const int c_begin = blockIdx.y * CPT;
+warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                        int B, int C, int D, int H, int W) {
+    __shared__ float lds[STAGE_FLOATS];
+    __shared__ int red[24];
+    const int HW = H * W;
+    const int tiles = (HW + 255) / 256;
+    const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
+    const int p = tile * 256 + threadIdx.x;
+    const bool active = p < HW;
+    const size_t vol = (size_t)D * HW;
+    const int c0 = blockIdx.y * CPB;
+    const int cs = min(CPB, C - c0);
+    const float *cp = coords + ((size_t)b * D * HW + p) * 3;
 
-    float sum[CPT][VW];
-#pragma unroll
-    for (int c = 0; c < CPT; ++c)
-#pragma unroll
-        for (int i = 0; i < VW; ++i) sum[c][i] = 0.0f;
+    int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
+    if (active) {
+        for (int d = 0; d < D; ++d) {
+            const float *q = cp + (size_t)d * HW * 3;
+            int x = (int)floorf(q[0]), y = (int)floorf(q[1]), z = (int)floorf(q[2]);
+            lx = min(lx, x); ly = min(ly, y); lz = min(lz, z);
+            hx = max(hx, x); hy = max(hy, y); hz = max(hz, z);
+        }
+    }
+    const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
+    const int bvol = bx.ex * bx.ey * bx.ez;
+    const bool staged = bvol * cs <= STAGE_FLOATS;  // block-uniform
+    const float *vb = v + (size_t)b * C * vol;
+    if (staged) {
+        stage_box(vb, lds, bx, c0, cs, H, W, vol);
+        __syncthreads();
+    }
+    if (!active) return;
 
+    float acc[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) acc[c] = 0.0f;
     for (int d = 0; d < D; ++d) {
-        Taps taps[VW];
+        const float *q = cp + (size_t)d * HW * 3;
+        Coord3 cc{q[0], q[1], q[2]};
+        Taps t = make_taps(cc, D, H, W);
+        if (staged) {
+            Taps lt = rebase(t, (int)floorf(cc.x), (int)floorf(cc.y), (int)floorf(cc.z), bx);
 #pragma unroll
-        for (int i = 0; i < VW; ++i) {
-            Coord3 c = sample_coord(field, lin_d, lin_h, lin_w, b, d, h, w0 + i, D, H, W, fD, fH, fW);
-            taps[i] = make_taps(c, D, H, W);
-        }
+            for (int c = 0; c < CPB; ++c)
+                if (c < cs) acc[c] += gather8(lds + c * bvol, lt);
+        } else {
 #pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-            if (c_begin + c < C) {
-                const float *src = v + ((size_t)b * C + c_begin + c) * vol;
-#pragma unroll
-                for (int i = 0; i < VW; ++i) sum[c][i] += gather8(src, taps[i]);
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) {
-        if (c_begin + c < C) {
-            float *dst = out + (((size_t)b * C + c_begin + c) * H + h) * W + w0;
-            if (VW == 4) {
-                *reinterpret_cast<float4 *>(dst) = make_float4(sum[c][0], sum[c][1], sum[c][2], sum[c][3]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < VW; ++i) dst[i] = sum[c][i];
-            }
+            for (int c = 0; c < CPB; ++c)
+                if (c < cs) acc[c] += gather8(vb + (size_t)(c0 + c) * vol, t);
         }
     }
+#pragma unroll
+    for (int c = 0; c < CPB; ++c)
+        if (c < cs) out[((size_t)b * C + c0 + c) * HW + p] = acc[c];
+}
+
+// Fallback for W % 4 != 0 (never the case on the hot path): one thread per output voxel and channel slice.
+__global__ void __launch_bounds__(256)
+warp_gather_scalar_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                          int B, int C, int D, int H, int W, int cpb) {
+    const size_t vol = (size_t)D * H * W;
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * vol) return;
+    int b = (int)(t / vol);
+    size_t r = t - (size_t)b * vol;
+    Coord3 c{coords[t * 3], coords[t * 3 + 1], coords[t * 3 + 2]};
+    Taps taps = make_taps(c, D, H, W);
+    const int c_begin = blockIdx.y * cpb, c_end = min(C, c_begin + cpb);
+    for (int ch = c_begin; ch < c_end; ++ch)
+        out[((size_t)b * C + ch) * vol + r] = gather8(v + ((size_t)b * C + ch) * vol, taps);
 }
 
 }  // namespace mphip
@@ -252,43 +404,71 @@ static int check_warp_args(const char *name, const void *v, const void *field, c
     return MPHIP_OK;
 }
 
+extern "C" size_t mphip_warp_workspace_bytes(int B, int D, int H, int W) {
+    if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)B * D * H * W * 3 * sizeof(float);
+}
+
+static int launch_coords(const float *field, const float *lin_d, const float *lin_h, const float *lin_w, float *coords,
+                         int32_t *idx, int B, int D, int H, int W, int fD, int fH, int fW, hipStream_t s) {
+    size_t n = (size_t)B * D * H * W;
+    if (fH == H && fW == W)
+        hipLaunchKernelGGL(warp_coords_kernel<true>, dim3(cdiv(n, 256)), dim3(256), 0, s, field, lin_d, lin_h, lin_w,
+                           coords, idx, B, D, H, W, fD, fH, fW);
+    else
+        hipLaunchKernelGGL(warp_coords_kernel<false>, dim3(cdiv(n, 256)), dim3(256), 0, s, field, lin_d, lin_h, lin_w,
+                           coords, idx, B, D, H, W, fD, fH, fW);
+    return check_launch("warp_coords");
+}
+
 extern "C" int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
                                  const float *lin_w, float *out, float *coords_out, int32_t *idx_out, int B, int C,
-                                 int D, int H, int W, int fD, int fH, int fW, void *stream) {
+                                 int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
+                                 void *stream) {
     int rc = check_warp_args("warp_volume", v, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
     if (rc) return rc;
     MPHIP_REQUIRE(!idx_out || coords_out, "warp_volume: idx_out requires coords_out");
-    const int cpb = C >= 48 ? 12 : C;  // channel slice per block row: re-derives coords C/cpb times
-    dim3 grid;
-    grid.y = cdiv(C, cpb);
+    float *coords = coords_out;
+    if (!coords) {
+        size_t need = mphip_warp_workspace_bytes(B, D, H, W);
+        if (!workspace || workspace_bytes < need) {
+            set_error("warp_volume: workspace %zu bytes < required %zu", workspace_bytes, need);
+            return MPHIP_EWORKSPACE;
+        }
+        coords = (float *)workspace;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
+    if (rc) return rc;
     if (W % 4 == 0) {
-        grid.x = cdiv((size_t)B * D * H * (W / 4), 256);
-        hipLaunchKernelGGL(warp_volume_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, v, field, lin_d, lin_h, lin_w,
-                           out, coords_out, idx_out, B, C, D, H, W, fD, fH, fW, cpb);
+        const int tiles = (H * W + 1023) / 1024;
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)((size_t)B * D * tiles)), dim3(256), 0, s, v, coords, out, B,
+                           C, D, H, W);
     } else {
-        grid.x = cdiv((size_t)B * D * H * W, 256);
-        hipLaunchKernelGGL(warp_volume_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, v, field, lin_d, lin_h, lin_w,
-                           out, coords_out, idx_out, B, C, D, H, W, fD, fH, fW, cpb);
+        const int cpb = C >= 48 ? 12 : C;
+        hipLaunchKernelGGL(warp_gather_scalar_kernel, dim3(cdiv((size_t)B * D * H * W, 256), cdiv(C, cpb)), dim3(256), 0, s,
+                           v, coords, out, B, C, D, H, W, cpb);
     }
     return check_launch("warp_volume");
 }
 
 extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
                                       const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
-                                      int fH, int fW, void *stream) {
+                                      int fH, int fW, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = check_warp_args("warp_volume_dsum", v, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
     if (rc) return rc;
-    constexpr int CPT = 8;
-    dim3 grid;
-    grid.y = cdiv(C, CPT);
-    if (W % 4 == 0) {
-        grid.x = cdiv((size_t)B * H * (W / 4), 256);
-        hipLaunchKernelGGL((warp_volume_dsum_kernel<4, CPT>), grid, dim3(256), 0, (hipStream_t)stream, v, field, lin_d,
-                           lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
-    } else {
-        grid.x = cdiv((size_t)B * H * W, 256);
-        hipLaunchKernelGGL((warp_volume_dsum_kernel<1, CPT>), grid, dim3(256), 0, (hipStream_t)stream, v, field, lin_d,
-                           lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
+    size_t need = mphip_warp_workspace_bytes(B, D, H, W);
+    if (!workspace || workspace_bytes < need) {
+        set_error("warp_volume_dsum: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
     }
+    hipStream_t s = (hipStream_t)stream;
+    float *coords = (float *)workspace;
+    rc = launch_coords(field, lin_d, lin_h, lin_w, coords, nullptr, B, D, H, W, fD, fH, fW, s);
+    if (rc) return rc;
+    constexpr int CPB = 16;
+    const int tiles = (H * W + 255) / 256;
+    hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles), cdiv(C, CPB)), dim3(256), 0, s, v,
+                       coords, out, B, C, D, H, W);
     return check_launch("warp_volume_dsum");
 }

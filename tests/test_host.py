@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
 
     hdr = open(os.path.join(ROOT, "include", "mphip.h")).read()
     declared = set(re.findall(r"\b(mphip_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 17
+    assert len(declared) >= 18
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in mphip.h but not exported by libmphip.so"
@@ -35,7 +35,7 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_argument_validation_needs_no_gpu(lib):
-    assert lib.mphip_warp_volume(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None) == -1
+    assert lib.mphip_warp_volume(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None, 0, None) == -1
     assert b"null pointer" in lib.mphip_last_error()
     assert lib.mphip_conv3d_fwd(None, None, None, None, 1, 1, 1, 1, 1, 1, 3, 0, None, 0, None) == -1
     one = ctypes.c_void_p(16)
@@ -53,6 +53,9 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3) == 0
     assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3) > 0
     assert lib.mphip_groupnorm_workspace_bytes(2, 96, 65536, 32) == 2 * 32 * 12 * 16
+    assert lib.mphip_warp_workspace_bytes(8, 16, 64, 64) == 8 * 65536 * 12
+    one_ = ctypes.c_void_p(16)
+    assert lib.mphip_warp_volume_dsum(one_, one_, one_, one_, one_, one_, 1, 2, 4, 4, 4, 4, 4, 4, None, 0, None) == -3   # workspace too small
 
 
 def test_module_state_dict_layout_matches_reference():
