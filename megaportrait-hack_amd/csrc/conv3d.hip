@@ -9,6 +9,8 @@
 //   A fragment = weights  A[i=lane&31][k=lane>>5] -> Wp[tap][ci+k][co0+i]   (one dword per lane)
 //   B fragment = voxels   B[k=lane>>5][j=lane&31] -> X[ci+k][vox0+j + tap]  (one dword per lane)
 //   C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
+#include <stdlib.h>
+
 #include "mphip_common.h"
 
 namespace mphip {
@@ -151,6 +153,185 @@ conv3d_gather_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled variant for the G3d levels (volume dims multiples of the tile, Co multiple of MT*32).
+// A workgroup (4 waves) owns an output tile of TD x TH x TW voxels x (MT*32) channels.  Per chunk
+// of KC input channels it stages (a) the input halo tile [KC][TD+2][TH+2][TW+2] (zero filled by
+// the buffer-load range check) and (b) the weight slab [27][KC][MT*32] into LDS, double buffered
+// through registers (loads for chunk c+1 are issued before the MFMAs of chunk c, written to the
+// other buffer after them; one barrier per chunk).  The inner loop is then 27 taps x (MT+NT)
+// ds_read_b32 with immediate offsets + MT*NT MFMAs — no address arithmetic, no global latency.
+template <int TD, int TH, int TW, int MT, int KC>
+__global__ void __launch_bounds__(256)
+conv3d_k3_tiled_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
+                       float *__restrict__ y, int N, int Ci, int CiP, int Co, int CoP, int D, int H, int W,
+                       int chunks_per_split, unsigned x_bytes) {
+    constexpr int TVOX = TD * TH * TW;
+    constexpr int NT = TVOX / 128;  // 32-voxel column tiles per wave
+    static_assert(TVOX % 128 == 0 && KC % 2 == 0, "tile shape");
+    constexpr int HD = TD + 2, HH = TH + 2, HWp = TW + 2;
+    constexpr int XS_PLANE = HD * HH * HWp;
+    constexpr int CO_T = MT * 32;
+    constexpr int XS_BUF = KC * XS_PLANE;       // floats per X buffer
+    constexpr int WS_BUF = 27 * KC * CO_T;      // floats per W buffer
+    constexpr int XE = (XS_BUF + 255) / 256;    // X elements staged per thread
+    constexpr int WE = (WS_BUF / 4 + 255) / 256;  // W float4 staged per thread
+    // buffers are padded to a whole number of per-thread pieces so staging needs no predicates
+    constexpr int XS_PAD = XE * 256, WS_PAD = WE * 256 * 4;
+    __shared__ __attribute__((aligned(16))) float smem[2 * XS_PAD + 2 * WS_PAD];
+    float *const Ws = smem;                 // [2][27][KC][CO_T]   (first: 16-byte aligned float4 stores)
+    float *const Xs = smem + 2 * WS_PAD;    // [2][KC][HD][HH][HWp]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    const int HW = H * W, DHW = D * HW;
+
+    // block -> (n, tile origin), co tile, chunk range
+    const int tiles_w = W / TW, tiles_h = H / TH, tiles_d = D / TD;
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; bid /= tiles_h;
+    const int td = bid % tiles_d;
+    const int n = bid / tiles_d;
+    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    const int co0 = blockIdx.y * CO_T;
+    const int nchunks = Ci / KC;
+    const int c_begin = blockIdx.z * chunks_per_split;
+    const int c_end = min(nchunks, c_begin + chunks_per_split);
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+
+    // staging plan (fixed per thread for the whole K loop)
+    unsigned xsrc[XE];  // byte offset in x of this thread's halo elements for ci = 0 (OOB if padding)
+#pragma unroll
+    for (int i = 0; i < XE; ++i) {
+        const int e = i * 256 + tid;
+        unsigned off = OOB;
+        if (e < XS_BUF) {
+            const int kc = e / XS_PLANE, r = e % XS_PLANE;
+            const int gd = d0 - 1 + r / (HH * HWp), gh = h0 - 1 + (r / HWp) % HH, gw = w0 - 1 + r % HWp;
+            if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+                off = (unsigned)((((long)n * Ci + kc) * DHW + (long)gd * HW + gh * W + gw) * 4);
+        }
+        xsrc[i] = off;
+    }
+    const float *wsrc[WE];  // this thread's float4 pieces of the weight slab for ci = 0
+#pragma unroll
+    for (int i = 0; i < WE; ++i) {
+        const int f = i * 256 + tid;
+        const int L = (f < WS_BUF / 4 ? f : 0) * 4;
+        const int co = L % CO_T, kc = (L / CO_T) % KC, tap = L / (CO_T * KC);
+        wsrc[i] = wp + ((size_t)tap * CiP + kc) * CoP + co0 + co;
+    }
+
+    float xr[XE];
+#define MPHIP_ISSUE_LOADS(chunk)                                                                          \
+    {                                                                                                     \
+        const int ci0_ = (chunk) * KC;                                                                    \
+        const unsigned soff_ = (unsigned)((long)ci0_ * DHW * 4);                                          \
+        _Pragma("unroll") for (int i = 0; i < XE; ++i) xr[i] = buf_load(rsrc, xsrc[i], soff_);            \
+    }
+    /* weight slab: LDS-DMA, 16 B per lane, wave-uniform destination + lane*16 (lane-linear image) */     \
+#define MPHIP_DMA_W(chunk, buf)                                                                           \
+    {                                                                                                     \
+        const size_t woff_ = (size_t)(chunk) * KC * CoP;                                                  \
+        _Pragma("unroll") for (int i = 0; i < WE; ++i) __builtin_amdgcn_global_load_lds(                  \
+            (const __attribute__((address_space(1))) void *)(wsrc[i] + woff_),                            \
+            (__attribute__((address_space(3))) void *)(Ws + (buf) * WS_PAD + (i * 256 + wave * 64) * 4), 16, 0, 0); \
+    }
+#define MPHIP_WRITE_LDS(buf)                                                                              \
+    {                                                                                                     \
+        _Pragma("unroll") for (int i = 0; i < XE; ++i) Xs[(buf) * XS_PAD + i * 256 + tid] = xr[i];        \
+    }
+
+    // fragment read bases (floats): A = Ws[tap][kc=kk][m*32 + j], B = Xs[kc=kk][voxel + tap]
+    const int a_base = kk * CO_T + j;
+    int b_base[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int v = (wave * NT + t) * 32 + j;
+        const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
+        b_base[t] = kk * XS_PLANE + (vd * HH + vh) * HWp + vw;
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+
+    if (c_begin < c_end) {
+        MPHIP_DMA_W(c_begin, 0);
+        MPHIP_ISSUE_LOADS(c_begin);
+        MPHIP_WRITE_LDS(0);
+        __syncthreads();
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        const bool more = c + 1 < c_end;
+        if (more) {
+            MPHIP_DMA_W(c + 1, buf ^ 1);
+            MPHIP_ISSUE_LOADS(c + 1);
+        }
+        const float *wsb = Ws + buf * WS_PAD + a_base;
+        const float *xsb = Xs + buf * XS_PAD;
+#pragma unroll
+        for (int kp = 0; kp < KC / 2; ++kp) {
+#pragma unroll
+            for (int tap = 0; tap < 27; ++tap) {
+                constexpr int dummy = 0;
+                (void)dummy;
+                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+                const int toff = (kd * HH + kh) * HWp + kw + kp * 2 * XS_PLANE;
+                float a[MT], b[NT];
+#pragma unroll
+                for (int m = 0; m < MT; ++m) a[m] = wsb[(tap * KC + kp * 2) * CO_T + m * 32];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) b[t] = xsb[b_base[t] + toff];
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[m][t], 0, 0, 0);
+            }
+        }
+        if (more) MPHIP_WRITE_LDS(buf ^ 1);
+        __syncthreads();
+    }
+
+#undef MPHIP_ISSUE_LOADS
+#undef MPHIP_DMA_W
+#undef MPHIP_WRITE_LDS
+    const bool direct = gridDim.z == 1;
+    float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
+    // bias for this lane's MT*16 output rows, fetched up front (one batch of loads, not one per store)
+    float bv[MT][16];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            bv[m][reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int v = (wave * NT + t) * 32 + j;
+        const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
+        float *dv = dst + (size_t)n * Co * DHW + (size_t)(d0 + vd) * HW + (h0 + vh) * W + w0 + vw;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                dv[(size_t)co * DHW] = acc[m][t][reg] + bv[m][reg];
+            }
+        }
+    }
+}
+
 // y = bias + sum_z partial[z]  (z ascending: deterministic)
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias, float *__restrict__ y,
@@ -166,8 +347,11 @@ splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict_
 struct ConvPlan {
     int MT, NT, WCO, splits, ci_per_split, CoP, CiP;
     bool skip;
+    int tiled;  // 0 = gather kernel, 4/2 = LDS-tiled kernel with a (tiled,8,8) voxel tile
     dim3 grid;
 };
+
+constexpr int TILED_KC = 2;
 
 static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
     ConvPlan p;
@@ -197,6 +381,18 @@ static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
     p.ci_per_split = p.CiP / splits;
     p.grid.z = splits;
     p.skip = (k == 3) && (D < 3 || H < 3 || W < 3);
+    p.tiled = 0;
+    if (k == 3 && Co % 96 == 0 && Ci % TILED_KC == 0 && H % 8 == 0 && W % 8 == 0 && D % 2 == 0 && !getenv("MPHIP_CONV_GATHER")) {
+        p.tiled = D % 4 == 0 ? 4 : 2;
+        const long tiles = (long)N * (D / p.tiled) * (H / 8) * (W / 8);
+        const int nchunks = Ci / TILED_KC;
+        p.grid = dim3((unsigned)tiles, Co / 96, 1);
+        int sp = 1;
+        while (tiles * (Co / 96) * sp < 512 && nchunks / (sp * 2) >= 12) sp *= 2;
+        p.splits = sp;
+        p.ci_per_split = (nchunks + sp - 1) / sp;  // chunks per split for the tiled kernel
+        p.grid.z = sp;
+    }
     return p;
 }
 
@@ -289,7 +485,13 @@ extern "C" int mphip_conv3d_fwd(const float *x, const float *w_packed, const flo
         }
         dst = (float *)workspace;
     }
-    if (k == 3) dispatch_mt<3>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
+    if (p.tiled == 4)
+        hipLaunchKernelGGL((conv3d_k3_tiled_kernel<4, 8, 8, 3, TILED_KC>), p.grid, dim3(256), 0, s, x, w_packed, bias, dst, N,
+                           Ci, p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, (unsigned)x_bytes);
+    else if (p.tiled == 2)
+        hipLaunchKernelGGL((conv3d_k3_tiled_kernel<2, 8, 8, 3, TILED_KC>), p.grid, dim3(256), 0, s, x, w_packed, bias, dst, N,
+                           Ci, p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, (unsigned)x_bytes);
+    else if (k == 3) dispatch_mt<3>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
     else dispatch_mt<1>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
     int rc = check_launch("conv3d_fwd");
     if (rc) return rc;
