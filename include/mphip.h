@@ -82,16 +82,22 @@ int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_
 /* ------------------------------------------------------------------ K4/K5  Conv3d k=3 / k=1
  * Replaces nn.Conv3d(Ci,Co,3,padding=1) (model.py:505,507,591,374-375,458) and
  * nn.Conv3d(Ci,Co,1) / nn.Conv2d 1x1 (model.py:510,380,446) — stride 1, bias.
- * Weights are used in a packed layout built once per weight version:
- *   mphip_pack_conv_weight: OIDHW [Co,Ci,k,k,k] -> [k^3][CiP][CoP] (CoP = Co rounded up to 32,
- *   CiP = Ci rounded up to 2, zero padded); size from mphip_packed_weight_elems().
- * precision: 0 = exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain).
- * x [N,Ci,D,H,W] -> y [N,Co,D,H,W].  workspace: mphip_conv3d_workspace_bytes() (split-K
- * partial sums for small volumes; 0 when not needed).                                    */
-size_t mphip_packed_weight_elems(int Co, int Ci, int k);
-int mphip_pack_conv_weight(const float *w_oidhw, float *w_packed, int Co, int Ci, int k, void *stream);
-size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
-int mphip_conv3d_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int Ci,
+ * x [N,Ci,D,H,W] fp32 -> y [N,Co,D,H,W] fp32 in both precisions.
+ * precision 0: exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), any shape.
+ * precision 1: "f16x3" — operands split into two f16 halves, 3 f16 MFMAs per product, fp32
+ *              accumulate (~2^-21 relative per term, fp32 class; needs |x| < 4094).  Only for
+ *              k=3, Ci%16==0, Co%96==0, H%8==0, W%8==0, D%2==0: ask mphip_conv3d_supported().
+ * Weights are used in a packed layout built once per weight version and per precision:
+ *   precision 0: OIDHW -> [k^3][CiP][CoP] fp32 (CoP = Co up to 32, CiP = Ci up to 2, zero padded)
+ *   precision 1: 16-byte header (1/scale, scale) + the LDS image of every (96-channel tile,
+ *                16-channel chunk, 3-tap group) slab as f16 hi/lo planes.
+ * workspace: split-K partial sums for small volumes (0 when not needed).                  */
+int mphip_conv3d_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
+size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision);
+int mphip_pack_conv_weight(const float *w_oidhw, void *w_packed, int Co, int Ci, int k, int precision,
+                           void *stream);
+size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
+int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
                      int Co, int D, int H, int W, int k, int precision, void *workspace,
                      size_t workspace_bytes, void *stream);
 

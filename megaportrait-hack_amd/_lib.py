@@ -28,9 +28,10 @@ SIGNATURES = {
     "mphip_warp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
-    "mphip_packed_weight_elems": (_sz, [_i, _i, _i]),
-    "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _p]),
-    "mphip_conv3d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "mphip_conv3d_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
+    "mphip_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
+    "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mphip_conv3d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mphip_conv3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_groupnorm_stats": (_i, [_p, _p, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),

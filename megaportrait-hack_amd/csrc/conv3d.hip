@@ -12,16 +12,15 @@
 #include <stdlib.h>
 
 #include "mphip_common.h"
+#include "mphip_conv.h"
 
 namespace mphip {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+    return buf_load_f(rsrc, voff, soff);
 }
-
-constexpr unsigned OOB = 0x80000000u;  // >= num_records -> buffer load returns 0 (zero padding)
 
 // OIDHW [Co,Ci,k,k,k] -> [k^3][CiP][CoP], zero padded.
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int CoP,
@@ -400,26 +399,43 @@ static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
 
 using namespace mphip;
 
-extern "C" size_t mphip_packed_weight_elems(int Co, int Ci, int k) {
-    if (Co <= 0 || Ci <= 0 || (k != 1 && k != 3)) return 0;
+static size_t packed_elems_f32(int Co, int Ci, int k) {
     return (size_t)k * k * k * ((Ci + 1) / 2 * 2) * ((Co + 31) / 32 * 32);
 }
 
-extern "C" int mphip_pack_conv_weight(const float *w, float *wp, int Co, int Ci, int k, void *stream) {
+extern "C" int mphip_conv3d_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
+    if ((size_t)N * Ci * D * H * W * 4 >= 0x80000000ull) return 0;
+    if (precision == 0) return 1;
+    if (precision == 1) return f16x3_supported(N, Ci, Co, D, H, W, k) ? 1 : 0;
+    return 0;
+}
+
+extern "C" size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision) {
+    if (Co <= 0 || Ci <= 0 || (k != 1 && k != 3)) return 0;
+    if (precision == 0) return packed_elems_f32(Co, Ci, k) * sizeof(float);
+    if (precision == 1 && k == 3 && Ci % 16 == 0 && Co % 96 == 0) return f16x3_packed_bytes(Co, Ci);
+    return 0;
+}
+
+extern "C" int mphip_pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, void *stream) {
     MPHIP_REQUIRE(w && wp, "pack_conv_weight: null pointer");
     MPHIP_REQUIRE(Co > 0 && Ci > 0 && (k == 1 || k == 3), "pack_conv_weight: bad dims");
-    size_t n = mphip_packed_weight_elems(Co, Ci, k);
+    MPHIP_REQUIRE(mphip_packed_weight_bytes(Co, Ci, k, precision) > 0,
+                  "pack_conv_weight: precision %d not available for Co=%d Ci=%d k=%d", precision, Co, Ci, k);
+    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, (hipStream_t)stream);
+    size_t n = packed_elems_f32(Co, Ci, k);
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, Co, Ci,
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float *)wp, Co, Ci,
                        (Co + 31) / 32 * 32, (Ci + 1) / 2 * 2, k * k * k);
     return check_launch("pack_conv_weight");
 }
 
-extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k) {
-    if (N <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
-    ConvPlan p = plan_conv(N, Ci, Co, D, H, W, k);
-    return p.splits > 1 ? (size_t)p.splits * N * Co * D * H * W * sizeof(float) : 0;
+extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    int splits = precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
+    return splits > 1 ? (size_t)splits * N * Co * D * H * W * sizeof(float) : 0;
 }
 
 template <int KS, int MT, int NT, int WCO, bool SKIP>
@@ -464,41 +480,58 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
     }
 }
 
-extern "C" int mphip_conv3d_fwd(const float *x, const float *w_packed, const float *bias, float *y, int N, int Ci,
+extern "C" int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
                                 int Co, int D, int H, int W, int k, int precision, void *workspace,
                                 size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
     MPHIP_REQUIRE(k == 1 || k == 3, "conv3d_fwd: kernel size %d not supported (1 or 3)", k);
-    MPHIP_REQUIRE(precision == 0, "conv3d_fwd: precision %d not supported", precision);
+    MPHIP_REQUIRE(precision == 0 || precision == 1, "conv3d_fwd: precision %d not supported", precision);
     const size_t x_bytes = (size_t)N * Ci * D * H * W * sizeof(float);
     MPHIP_REQUIRE(x_bytes < 0x80000000ull, "conv3d_fwd: input of %zu bytes exceeds the 2 GiB buffer-addressing limit",
                   x_bytes);
-    ConvPlan p = plan_conv(N, Ci, Co, D, H, W, k);
+    MPHIP_REQUIRE(mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision),
+                  "conv3d_fwd: precision %d not available for this shape (query mphip_conv3d_supported)", precision);
     hipStream_t s = (hipStream_t)stream;
+    ConvPlan p{};
+    F16x3Plan fp{};
+    int splits;
+    if (precision == 1) {
+        fp = f16x3_plan(N, Ci, Co, D, H, W);
+        splits = fp.splits;
+    } else {
+        p = plan_conv(N, Ci, Co, D, H, W, k);
+        splits = p.splits;
+    }
     float *dst = y;
-    if (p.splits > 1) {
-        size_t need = (size_t)p.splits * N * Co * D * H * W * sizeof(float);
+    if (splits > 1) {
+        size_t need = (size_t)splits * N * Co * D * H * W * sizeof(float);
         if (!workspace || workspace_bytes < need) {
             set_error("conv3d_fwd: workspace %zu bytes < required %zu", workspace_bytes, need);
             return MPHIP_EWORKSPACE;
         }
         dst = (float *)workspace;
     }
-    if (p.tiled == 4)
-        hipLaunchKernelGGL((conv3d_k3_tiled_kernel<4, 8, 8, 3, TILED_KC>), p.grid, dim3(256), 0, s, x, w_packed, bias, dst, N,
-                           Ci, p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, (unsigned)x_bytes);
-    else if (p.tiled == 2)
-        hipLaunchKernelGGL((conv3d_k3_tiled_kernel<2, 8, 8, 3, TILED_KC>), p.grid, dim3(256), 0, s, x, w_packed, bias, dst, N,
-                           Ci, p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, (unsigned)x_bytes);
-    else if (k == 3) dispatch_mt<3>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
-    else dispatch_mt<1>(p, x, w_packed, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
-    int rc = check_launch("conv3d_fwd");
+    int rc;
+    if (precision == 1) {
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, s);
+    } else {
+        const float *wf = (const float *)w_packed;
+        if (p.tiled == 4)
+            hipLaunchKernelGGL((conv3d_k3_tiled_kernel<4, 8, 8, 3, TILED_KC>), p.grid, dim3(256), 0, s, x, wf, bias, dst, N, Ci,
+                               p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, (unsigned)x_bytes);
+        else if (p.tiled == 2)
+            hipLaunchKernelGGL((conv3d_k3_tiled_kernel<2, 8, 8, 3, TILED_KC>), p.grid, dim3(256), 0, s, x, wf, bias, dst, N, Ci,
+                               p.CiP, Co, p.CoP, D, H, W, p.ci_per_split, (unsigned)x_bytes);
+        else if (k == 3) dispatch_mt<3>(p, x, wf, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
+        else dispatch_mt<1>(p, x, wf, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
+        rc = check_launch("conv3d_fwd");
+    }
     if (rc) return rc;
-    if (p.splits > 1) {
+    if (splits > 1) {
         size_t n_out = (size_t)N * Co * D * H * W;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, (const float *)workspace, bias,
-                           y, n_out, Co, D * H * W, p.splits);
+                           y, n_out, Co, D * H * W, splits);
         rc = check_launch("conv3d_fwd(splitk_reduce)");
     }
     return rc;

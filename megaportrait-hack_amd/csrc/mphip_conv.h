@@ -1,0 +1,25 @@
+// Shared between the conv translation units (conv3d.hip: exact fp32 kernels + C ABI; conv3d_f16x3.hip).
+#pragma once
+#include "mphip_common.h"
+
+namespace mphip {
+
+constexpr unsigned OOB = 0x80000000u;  // >= num_records -> buffer load returns 0 (zero padding)
+
+__device__ __forceinline__ float buf_load_f(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
+}
+
+struct F16x3Plan {
+    int td, splits, chunks_per_split;
+    dim3 grid;
+};
+
+bool f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
+size_t f16x3_packed_bytes(int Co, int Ci);
+F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W);
+int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, hipStream_t s);
+int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
+                 int Co, int D, int H, int W, hipStream_t s);
+
+}  // namespace mphip

@@ -152,10 +152,30 @@ def warp_volume_dsum(v: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ K4 / K5
-class PackedConv:
-    """Packed weights of one Conv3d/1x1 Conv2d ([k^3][CiP][CoP], see include/mphip.h) + bias."""
+# Conv precision: 0 = exact fp32 MFMA; 1 = "f16x3" (split-f16, 3 MFMAs per product, fp32-class
+# accuracy, ~3x faster).  "auto" uses f16x3 wherever the kernel supports the shape (all 3x3x3 convs
+# of G3d) and exact fp32 elsewhere.  Override with MPHIP_CONV_PRECISION=fp32|f16x3|auto.
+import os as _os
 
-    __slots__ = ("wp", "bias", "co", "ci", "k")
+_PRECISION_NAMES = {"fp32": 0, "exact": 0, "0": 0, "f16x3": 1, "1": 1, "auto": 1}
+_default_precision = _PRECISION_NAMES.get(_os.environ.get("MPHIP_CONV_PRECISION", "auto").lower(), 1)
+
+
+def set_conv_precision(mode) -> None:
+    """mode: 'fp32' | 'f16x3' | 'auto' (or 0/1)."""
+    global _default_precision
+    _default_precision = _PRECISION_NAMES[str(mode).lower()]
+
+
+def get_conv_precision() -> int:
+    return _default_precision
+
+
+class PackedConv:
+    """One Conv3d / 1x1 Conv2d: OIDHW fp32 weight + bias, packed lazily per precision into the
+    kernel layouts described in include/mphip.h."""
+
+    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed")
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
         weight = _req(weight.detach(), "conv weight")
@@ -166,12 +186,27 @@ class PackedConv:
                 raise RuntimeError("PackedConv: only 1x1 Conv2d is on the hot path")
         elif weight.dim() != 5 or tuple(weight.shape[2:]) != (k, k, k) or k not in (1, 3):
             raise RuntimeError(f"PackedConv: unsupported weight shape {tuple(weight.shape)}")
-        lib = _lib.load()
-        n = lib.mphip_packed_weight_elems(co, ci, k)
-        self.wp = torch.empty(n, dtype=torch.float32, device=weight.device)
-        _lib.check(lib.mphip_pack_conv_weight(_ptr(weight), _ptr(self.wp), co, ci, k, _stream()), "mphip_pack_conv_weight")
+        self.weight = weight
         self.bias = None if bias is None else _req(bias.detach(), "conv bias").clone()
         self.co, self.ci, self.k = co, ci, k
+        self._packed = {}
+
+    def packed(self, precision: int) -> torch.Tensor:
+        wp = self._packed.get(precision)
+        if wp is None:
+            lib = _lib.load()
+            nbytes = lib.mphip_packed_weight_bytes(self.co, self.ci, self.k, precision)
+            if nbytes == 0:
+                raise RuntimeError(f"PackedConv: precision {precision} not available for Co={self.co} Ci={self.ci} k={self.k}")
+            wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.weight.device)
+            _lib.check(lib.mphip_pack_conv_weight(_ptr(self.weight), _ptr(wp), self.co, self.ci, self.k, precision, _stream()),
+                       "mphip_pack_conv_weight")
+            self._packed[precision] = wp
+        return wp
+
+    @property
+    def wp(self) -> torch.Tensor:  # exact-fp32 packing (kept for tools/tests)
+        return self.packed(0)
 
 
 _conv_hook = None
@@ -184,19 +219,23 @@ def set_conv_hook(hook) -> None:
     _conv_hook = hook
 
 
-def conv3d(x: torch.Tensor, pc: PackedConv, precision: int = 0) -> torch.Tensor:
+def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None) -> torch.Tensor:
     x = _req(x, "x")
     if x.dim() != 5 or x.shape[1] != pc.ci:
         raise RuntimeError(f"conv3d: input {tuple(x.shape)} does not match Ci={pc.ci}")
     n, ci, d, h, w = x.shape
     lib = _lib.load()
-    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k)
+    prec = _default_precision if precision is None else precision
+    if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc.co, d, h, w, pc.k, prec):
+        prec = 0  # shape outside the fast kernel's tiling: the exact fp32 kernel handles every shape
+    wp = pc.packed(prec)
+    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, prec)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
     y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
 
     def launch():
-        _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(pc.wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k,
-                                        precision, _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
+        _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, prec,
+                                        _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
         return y
 
     return _conv_hook(x, pc, launch) if _conv_hook is not None else launch()

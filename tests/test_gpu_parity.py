@@ -40,6 +40,13 @@ def ops():
 
 
 @pytest.fixture(scope="module")
+def _libmod():
+    from megaportrait_hack_amd import _lib
+
+    return _lib
+
+
+@pytest.fixture(scope="module")
 def M():
     from megaportrait_hack_amd import model
 
@@ -165,9 +172,42 @@ def test_conv3d(ops, dev, case):
     wt = R.seeded_tensor((Co, Ci, k, k, k), 402, scale=fan ** -0.5)
     bias = R.seeded_tensor((Co,), 403, scale=fan ** -0.5)
     pc = ops.PackedConv(wt.to(dev), bias.to(dev))
-    got = ops.conv3d(x.to(dev), pc)
     want = F.conv3d(x, wt, bias, padding=k // 2)
-    assert maxabs(got, want) < 2e-5
+    assert maxabs(ops.conv3d(x.to(dev), pc, precision=0), want) < 2e-5      # exact fp32 MFMA
+    assert maxabs(ops.conv3d(x.to(dev), pc, precision=1), want) < 2e-5      # f16x3 where supported, else fp32
+
+
+F16X3_CASES = [(2, 96, 96, 4, 8, 8), (1, 96, 192, 8, 16, 16), (2, 192, 96, 2, 8, 8), (1, 768, 768, 2, 8, 8),
+               (1, 384, 192, 4, 16, 16), (1, 96, 96, 16, 64, 64)]
+
+
+@pytest.mark.parametrize("stress", [False, True], ids=["plain", "outliers"])
+@pytest.mark.parametrize("case", F16X3_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_f16x3_is_fp32_class(ops, _libmod, dev, case, stress):
+    """The split-f16 kernel must be fp32-class against the fp64 truth.
+    plain:    O(1) data -> error no worse than the exact-fp32 MFMA kernel's own rounding (same order).
+    outliers: a 300.0 activation, a 1.5 weight (75x the rest), f16-subnormal-lo values and zeros in one
+              receptive field.  The f16 MFMA aligns the 16 products of an instruction to the largest one,
+              so — like a running fp32 sum — the error scales with the largest partial sum: bounded
+              relative to max|y| (2^-20), not per term."""
+    N, Ci, Co, D, H, W = case
+    assert _libmod.load().mphip_conv3d_supported(N, Ci, Co, D, H, W, 3, 1) == 1
+    x = R.seeded_tensor((N, Ci, D, H, W), 421, scale=1.7)
+    wt = R.seeded_tensor((Co, Ci, 3, 3, 3), 422, scale=(Ci * 27) ** -0.5)
+    if stress:
+        x[0, 0, 0, 0, :4] = torch.tensor([300.0, -1e-4, 3e-6, 0.0])
+        wt[0, 0, 1, 1, :3] = torch.tensor([1.5, -2e-5, 0.0])
+    bias = R.seeded_tensor((Co,), 423, scale=0.1)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    truth = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    e32 = maxabs(ops.conv3d(x.to(dev), pc, precision=0), truth)
+    e16 = maxabs(ops.conv3d(x.to(dev), pc, precision=1), truth)
+    scale = truth.abs().max().item()
+    print(f"max-abs vs fp64: fp32-MFMA {e32:.2e}, f16x3 {e16:.2e} (max|y| = {scale:.1f})")
+    if stress:
+        assert e16 / scale < 1e-6 and e32 / scale < 1e-6
+    else:
+        assert e16 < 2 * e32 + 1e-6 and e16 < 1e-5
 
 
 def test_conv3d_vs_c_oracle(ops, dev, oracle_c):

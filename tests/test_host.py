@@ -45,13 +45,21 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mphip_groupnorm_stats(one, one, 1, 30, 8, 32, ctypes.c_float(1e-5), None, 0, None) == -1
     assert lib.mphip_avgpool2(one, one, 1, 3, 4, 4, None) == -1
     # pure host helpers
-    assert lib.mphip_packed_weight_elems(96, 96, 3) == 27 * 96 * 96
-    assert lib.mphip_packed_weight_elems(3, 32, 3) == 27 * 32 * 32     # Co padded to 32
-    assert lib.mphip_packed_weight_elems(7, 5, 3) == 27 * 6 * 32       # Ci padded to even
-    assert lib.mphip_packed_weight_elems(4, 4, 2) == 0
+    assert lib.mphip_packed_weight_bytes(96, 96, 3, 0) == 27 * 96 * 96 * 4
+    assert lib.mphip_packed_weight_bytes(3, 32, 3, 0) == 27 * 32 * 32 * 4     # Co padded to 32
+    assert lib.mphip_packed_weight_bytes(7, 5, 3, 0) == 27 * 6 * 32 * 4       # Ci padded to even
+    assert lib.mphip_packed_weight_bytes(4, 4, 2, 0) == 0
+    assert lib.mphip_packed_weight_bytes(96, 96, 3, 1) == 16 + 27 * 96 * 96 * 2 * 2   # f16 hi + lo planes + header
+    assert lib.mphip_packed_weight_bytes(3, 32, 3, 1) == 0                     # f16x3 needs Co%96, Ci%16
+    assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 3, 1) == 1
+    assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 1, 1) == 0
+    assert lib.mphip_conv3d_supported(8, 32, 3, 16, 16, 16, 3, 1) == 0
+    assert lib.mphip_conv3d_supported(8, 32, 3, 16, 16, 16, 3, 0) == 1
     # split-K workspace only for small volumes
-    assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3) == 0
-    assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3) > 0
+    assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3, 0) == 0
+    assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3, 1) == 0
+    assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3, 0) > 0
+    assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3, 1) > 0
     assert lib.mphip_groupnorm_workspace_bytes(2, 96, 65536, 32) == 2 * 32 * 12 * 16
     assert lib.mphip_warp_workspace_bytes(8, 16, 64, 64) == 8 * 65536 * 12
     one_ = ctypes.c_void_p(16)
