@@ -53,6 +53,54 @@ gn_partial_kernel(const float *__restrict__ x, double *__restrict__ partial, siz
     }
 }
 
+// Single-launch variant for groups of <= GN_DIRECT_MAX floats (every tensor below the two largest
+// G3d levels): one workgroup walks the whole (sample,group) span and writes (mean, rstd) itself.
+constexpr int GN_DIRECT_CHUNKS = 4;
+__global__ void __launch_bounds__(256)
+gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, size_t cnt, float eps) {
+    const int grp = blockIdx.x;
+    const float *p = x + (size_t)grp * cnt;
+    double ds = 0.0, dss = 0.0;
+    const bool vec = (cnt & 3) == 0 && (((size_t)p) & 15) == 0;
+    for (size_t begin = 0; begin < cnt; begin += GN_CHUNK) {   // same per-chunk fp32 partials as the 2-stage path
+        const size_t end = begin + GN_CHUNK < cnt ? begin + GN_CHUNK : cnt;
+        float s = 0.0f, ss = 0.0f;
+        if (vec) {
+            for (size_t i = begin + (size_t)threadIdx.x * 4; i < end; i += 1024) {
+                float4 v = *reinterpret_cast<const float4 *>(p + i);
+                s += (v.x + v.y) + (v.z + v.w);
+                ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+        } else {
+            for (size_t i = begin + threadIdx.x; i < end; i += 256) {
+                float v = p[i];
+                s += v;
+                ss += v * v;
+            }
+        }
+        ds += (double)s;
+        dss += (double)ss;
+    }
+    ds = wave_sum(ds);
+    dss = wave_sum(dss);
+    __shared__ double red[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = ds;
+        red[wave * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = (red[0] + red[2]) + (red[4] + red[6]);
+        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        double mean = a / (double)cnt;
+        double var = b / (double)cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[grp * 2] = (float)mean;
+        stats[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
 // Stage 2: (mean, rstd) per (sample,group); biased variance, eps inside the sqrt.
 __global__ void gn_finalize_kernel(const double *__restrict__ partial, float *__restrict__ stats, int ngroups,
                                    int chunks, double cnt, float eps) {
@@ -171,9 +219,53 @@ __global__ void __launch_bounds__(256) avgpool2_kernel(const float *__restrict__
     y[t] = s / 8.0f;
 }
 
-// nn.Upsample(scale_factor=2, trilinear, align_corners=True): src = dst*(in-1)/(out-1).
-__global__ void __launch_bounds__(256) upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y,
-                                                                  int D, int H, int W, size_t total) {
+// nn.Upsample(scale_factor=2, trilinear, align_corners=True): src = dst*scale, scale = (in-1)/(out-1)
+// evaluated once in fp32 on the host (the same single division ATen performs).  One thread makes 4
+// consecutive outputs along w (one 16-byte store); the d/h source rows are shared by the four.
+__device__ __forceinline__ SrcIdx src_index_scaled(int dst, int in, float scale) {
+    float src = scale * (float)dst;
+    SrcIdx r;
+    r.i0 = min((int)src, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = src - (float)r.i0;
+    r.l0 = 1.0f - r.l1;
+    return r;
+}
+
+__global__ void __launch_bounds__(256)
+upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, int D, int H, int W, float sD, float sH,
+                           float sW, size_t total4) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total4) return;
+    const int oD = 2 * D, oH = 2 * H, oW4 = W / 2;  // 2W/4 float4 per output row
+    int ow = (int)(t % oW4) * 4;
+    size_t r = t / oW4;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    const SrcIdx sd = src_index_scaled(od, D, sD), sh = src_index_scaled(oh, H, sH);
+    const float *p = x + plane * D * H * W;
+    const float *r00 = p + ((size_t)sd.i0 * H + sh.i0) * W, *r01 = p + ((size_t)sd.i0 * H + sh.i1) * W;
+    const float *r10 = p + ((size_t)sd.i1 * H + sh.i0) * W, *r11 = p + ((size_t)sd.i1 * H + sh.i1) * W;
+    float o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const SrcIdx sw = src_index_scaled(ow + i, W, sW);
+        float a00 = lerp2(sw.l0, r00[sw.i0], sw.l1, r00[sw.i1]);
+        float a01 = lerp2(sw.l0, r01[sw.i0], sw.l1, r01[sw.i1]);
+        float a10 = lerp2(sw.l0, r10[sw.i0], sw.l1, r10[sw.i1]);
+        float a11 = lerp2(sw.l0, r11[sw.i0], sw.l1, r11[sw.i1]);
+        float b0 = lerp2(sh.l0, a00, sh.l1, a01);
+        float b1 = lerp2(sh.l0, a10, sh.l1, a11);
+        o[i] = lerp2(sd.l0, b0, sd.l1, b1);
+    }
+    *reinterpret_cast<float4 *>(y + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+
+// generic (odd W) fallback: one output per thread
+__global__ void __launch_bounds__(256) upsample_trilinear2_scalar_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                                         int D, int H, int W, size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     const int oD = 2 * D, oH = 2 * H, oW = 2 * W;
@@ -318,6 +410,10 @@ extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C,
     size_t cnt = (size_t)(C / G) * S;
     int chunks = (int)((cnt + GN_CHUNK - 1) / GN_CHUNK);
     hipStream_t s = (hipStream_t)stream;
+    if (chunks <= GN_DIRECT_CHUNKS) {
+        hipLaunchKernelGGL(gn_stats_direct_kernel, dim3(N * G), dim3(256), 0, s, x, stats, cnt, eps);
+        return check_launch("groupnorm_stats");
+    }
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N * G), dim3(256), 0, s, x, (double *)workspace, cnt, chunks);
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const double *)workspace, stats,
                        N * G, chunks, (double)cnt, eps);
@@ -360,8 +456,17 @@ extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D
     MPHIP_REQUIRE(x && y, "upsample_trilinear2: null pointer");
     MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0, "upsample_trilinear2: bad dims");
     size_t total = (size_t)NC * D * H * W * 8;
-    hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D, H,
-                       W, total);
+    if (W % 2 == 0) {
+        // align_corners=True scale, one fp32 division per axis exactly as ATen computes it
+        const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
+        const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
+        const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
+        hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D,
+                           H, W, sD, sH, sW, total / 4);
+    } else {
+        hipLaunchKernelGGL(upsample_trilinear2_scalar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
+                           D, H, W, total);
+    }
     return check_launch("upsample_trilinear2");
 }
 
