@@ -11,7 +11,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmphip.so")
+LIB_PATH = os.environ.get("MPHIP_LIB", os.path.join(_HERE, "libmphip.so"))  # MPHIP_LIB: dev override (ablation builds)
 BUILD_SCRIPT = os.path.join(_HERE, "csrc", "build.sh")
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as raw addresses

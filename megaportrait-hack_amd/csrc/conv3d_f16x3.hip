@@ -18,6 +18,8 @@
 // MFMA: v_mfma_f32_32x32x16_f16, A = weights [32 co x 16 ci], B = voxels [16 ci x 32 vox]
 //   lane l holds 8 consecutive k (ci) of row/col (l&31):  k = 8*(l>>5) .. +7   (one 16-byte LDS read)
 //   C/D: col j = lane&31 (voxel), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (co)
+#include <stdlib.h>
+
 #include "mphip_common.h"
 #include "mphip_conv.h"
 
@@ -30,7 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr float X_SCALE = 16.0f;          // activations: |x| < 4094 stays finite in f16; lo subnormal only below |x| ~ 8e-3
 constexpr float F16_CLAMP = 65000.0f;
 constexpr int F16X3_KC = 16;              // input channels per chunk = K of one MFMA
-constexpr int F16X3_TG = 3;               // taps per weight slab
+constexpr int F16X3_TG = 3;               // taps per packed weight slab
+constexpr int F16X3_NG = 27 / F16X3_TG;   // slabs per 16-channel chunk
 constexpr int F16X3_COT = 96;             // output channels per workgroup (3 MFMA row tiles)
 constexpr int SLAB_HALFS = 2 * F16X3_TG * 2 * F16X3_COT * 8;  // [part][tap][kg][co][8] = 9216 halfs = 18432 B
 
@@ -59,25 +62,25 @@ __device__ __forceinline__ float weight_scale(unsigned maxbits) {
     return ldexpf(1.0f, 15 - e);  // m*scale < 2^15 = 32768
 }
 
-// OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*9 + g][part][tap][kg][co][8] f16 (after the header)
+// OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*NG + g][part][tap][kg][co][8] f16 (after the header)
 __global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in,
                                   float *__restrict__ hdr_out, int Co, int Ci) {
     const float scale = weight_scale(hdr_in[2]);
     const int nchunks = Ci / F16X3_KC;
-    const size_t n = (size_t)(Co / F16X3_COT) * nchunks * 9 * (SLAB_HALFS / 2);  // one thread per (hi,lo) pair
+    const size_t n = (size_t)(Co / F16X3_COT) * nchunks * F16X3_NG * (SLAB_HALFS / 2);  // one thread per (hi,lo) pair
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         size_t r = i;
         const int e = (int)(r % 8); r /= 8;
         const int co = (int)(r % F16X3_COT); r /= F16X3_COT;
         const int kg = (int)(r % 2); r /= 2;
         const int tg = (int)(r % F16X3_TG); r /= F16X3_TG;
-        const int g = (int)(r % 9); r /= 9;
+        const int g = (int)(r % F16X3_NG); r /= F16X3_NG;
         const int chunk = (int)(r % nchunks);
         const int cot = (int)(r / nchunks);
         const int ci = chunk * F16X3_KC + kg * 8 + e, tap = g * F16X3_TG + tg, cog = cot * F16X3_COT + co;
         _Float16 hi, lo;
         split_f16(w[((size_t)cog * Ci + ci) * 27 + tap] * scale, hi, lo);
-        const size_t slab = ((size_t)cot * nchunks + chunk) * 9 + g;
+        const size_t slab = ((size_t)cot * nchunks + chunk) * F16X3_NG + g;
         const size_t inner = (((size_t)tg * 2 + kg) * F16X3_COT + co) * 8 + e;
         out[slab * SLAB_HALFS + inner] = hi;
         out[slab * SLAB_HALFS + SLAB_HALFS / 2 + inner] = lo;
@@ -89,20 +92,27 @@ __global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restr
 }
 
 // ---- the conv kernel ---------------------------------------------------------------------------
-template <int TD, int TH, int TW>
-__global__ void __launch_bounds__(256)
+// GS = packed slabs (of 3 taps) streamed per barrier interval: 3 -> 4 barriers per chunk and 110 KB of
+// weight buffers (one workgroup per CU), 1 -> 10 barriers per chunk and 37 KB.
+template <int TD, int TH, int TW, int NWAVES, int GS>
+__global__ void __launch_bounds__(NWAVES * 64)
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes) {
     constexpr int MT = 3, KC = F16X3_KC;
     constexpr int TVOX = TD * TH * TW;
-    constexpr int NT = TVOX / 128;
+    constexpr int NTHR = NWAVES * 64;
+    constexpr int NT = TVOX / (32 * NWAVES);          // 32-voxel column tiles per wave
+    static_assert(NT >= 1 && TVOX % (32 * NWAVES) == 0, "tile/wave shape");
     constexpr int HD = TD + 2, HH = TH + 2, HWp = TW + 2;
     constexpr int XV = HD * HH * HWp;                 // halo voxels
     constexpr int X_PART = 2 * XV * 8;                // halfs per part (hi or lo): [kg][vox][8]
-    constexpr int XI = (8 * XV + 255) / 256;          // (channel pair, voxel) items per thread
-    constexpr int W_BUF = SLAB_HALFS;                 // halfs per weight buffer
-    constexpr int W_PIECES = SLAB_HALFS * 2 / 1024;   // 1-KiB DMA pieces per slab (18)
+    constexpr int XI = (8 * XV + NTHR - 1) / NTHR;    // (channel pair, voxel) items per thread
+    constexpr int W_BUF = GS * SLAB_HALFS;            // halfs per weight buffer (GS consecutive slabs)
+    constexpr int W_PIECES = W_BUF * 2 / 1024;        // 1-KiB DMA pieces per group (18 per slab)
+    constexpr int NGRP = F16X3_NG / GS;               // barrier intervals per chunk
+    constexpr int GT = GS * F16X3_TG;                 // taps per interval
+    static_assert(F16X3_NG % GS == 0, "group size");
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * W_BUF + 2 * X_PART];
     _Float16 *const Ws = smem;               // [2 buffers][part][tap][kg][co][8]
     _Float16 *const Xs = smem + 2 * W_BUF;   // [part][kg][vox][8]
@@ -128,54 +138,54 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
 
-    // X staging plan: item e = i*256+tid -> (channel pair p = e / XV, halo voxel = e % XV)
-    unsigned xsrc[XI];   // byte offset of (ci = 2p, voxel) for chunk 0, OOB when padding / beyond the item count
-    int xdst[XI];        // half index in a part: ((kg*XV + vox)*8 + (p%4)*2), -1 when unused
-#pragma unroll
-    for (int i = 0; i < XI; ++i) {
-        const int e = i * 256 + tid;
-        unsigned off = OOB;
-        int dsti = -1;
-        if (e < 8 * XV) {
-            const int p = e / XV, r = e % XV;
-            const int gd = d0 - 1 + r / (HH * HWp), gh = h0 - 1 + (r / HWp) % HH, gw = w0 - 1 + r % HWp;
-            if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-                off = (unsigned)((((long)n * Ci + 2 * p) * DHW + (long)gd * HW + gh * W + gw) * 4);
-            dsti = (((p / 4) * XV + r) * 8) + (p % 4) * 2;
-        }
-        xsrc[i] = off;
-        xdst[i] = dsti;
-    }
+    // X staging: item e = i*256+tid -> (channel pair p = e / XV, halo voxel r = e % XV); the source
+    // offset / LDS slot of an item are recomputed when needed instead of living in 2*XI registers.
     const unsigned chan_stride = (unsigned)DHW * 4u;
+    const long nbase = (long)n * Ci * DHW;
+    auto x_src = [&](int i, int tid_) -> unsigned {
+        const int e = i * NTHR + tid_;
+        if (e >= 8 * XV) return OOB;
+        const int p = e / XV, r = e % XV;
+        const int gd = d0 - 1 + r / (HH * HWp), gh = h0 - 1 + (r / HWp) % HH, gw = w0 - 1 + r % HWp;
+        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+            return (unsigned)((nbase + (long)(2 * p) * DHW + (long)gd * HW + gh * W + gw) * 4);
+        return OOB;
+    };
 
     float xr0[XI], xr1[XI];
 #define F16X3_LOAD_X(chunk)                                                                       \
     {                                                                                             \
         const unsigned soff_ = (unsigned)((long)(chunk) * KC * DHW * 4);                          \
+        int tid_ = tid;                                                                           \
+        asm volatile("" : "+v"(tid_)); /* opaque: keeps the plan out of registers across the K loop */ \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                          \
-            xr0[i] = buf_load_f(rsrc, xsrc[i], soff_);                                            \
-            xr1[i] = buf_load_f(rsrc, xsrc[i] == OOB ? OOB : xsrc[i] + chan_stride, soff_);       \
+            const unsigned o_ = x_src(i, tid_);                                                   \
+            xr0[i] = buf_load_f(rsrc, o_, soff_);                                                 \
+            xr1[i] = buf_load_f(rsrc, o_ == OOB ? OOB : o_ + chan_stride, soff_);                 \
         }                                                                                         \
     }
 #define F16X3_WRITE_X()                                                                           \
     {                                                                                             \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                          \
-            if (xdst[i] >= 0) {                                                                   \
+            const int e_ = i * NTHR + tid;                                                        \
+            if (e_ < 8 * XV) {                                                                    \
+                const int p_ = e_ / XV, r_ = e_ % XV;                                             \
+                const int dst_ = (((p_ / 4) * XV + r_) * 8) + (p_ % 4) * 2;                       \
                 _Float16 h0_, l0_, h1_, l1_;                                                      \
                 split_f16(xr0[i] * X_SCALE, h0_, l0_);                                            \
                 split_f16(xr1[i] * X_SCALE, h1_, l1_);                                            \
                 half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                        \
-                *reinterpret_cast<half2v *>(Xs + xdst[i]) = hv_;                                  \
-                *reinterpret_cast<half2v *>(Xs + X_PART + xdst[i]) = lv_;                         \
+                *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                     \
+                *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                            \
             }                                                                                     \
         }                                                                                         \
     }
     // weight slab (chunk, group) -> buffer: W_PIECES 1-KiB pieces, wave w takes pieces w, w+4, ...
 #define F16X3_DMA_W(chunk, grp, wbuf)                                                             \
     {                                                                                             \
-        const _Float16 *src_ = wslabs + (((size_t)cot * nchunks + (chunk)) * 9 + (grp)) * SLAB_HALFS + lane * 8; \
-        _Pragma("unroll") for (int q = 0; q < (W_PIECES + 3) / 4; ++q) {                          \
-            const int piece_ = q * 4 + wave;                                                      \
+        const _Float16 *src_ = wslabs + (((size_t)cot * nchunks + (chunk)) * F16X3_NG + (grp) * GS) * SLAB_HALFS + lane * 8; \
+        _Pragma("unroll") for (int q = 0; q < (W_PIECES + NWAVES - 1) / NWAVES; ++q) {            \
+            const int piece_ = q * NWAVES + wave;                                                 \
             if (piece_ < W_PIECES)                                                                \
                 __builtin_amdgcn_global_load_lds(                                                 \
                     (const __attribute__((address_space(1))) void *)(src_ + piece_ * 512),        \
@@ -183,12 +193,18 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         }                                                                                         \
     }
 
+    // ds_read_b128 is serviced in 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (per half-wave):
+    // give every group two whole 8-voxel rows (2 x 128 contiguous bytes) instead of row fragments of
+    // four different rows, which removes the 2-3 way bank conflicts of the natural j -> voxel order.
+    const int jg = ((j >> 2) & 1) ^ ((j >> 3) & 1) ^ ((j >> 4) & 1);  // hardware group of lane j: 0 or 1
+    const int jpos = j < 4 ? j : j < 12 ? j - 4 : j < 20 ? j - 8 : j < 28 ? j - 12 : j - 16;
+    const int jv = jg * 16 + jpos;  // column (voxel slot) of lane j inside its 32-voxel tile
     // fragment bases (halfs)
-    const int a_base = (kg * F16X3_COT + j) * 8;           // + ((part*3 + tap)*2*96 + m*32)*8
+    const int a_base = (kg * F16X3_COT + j) * 8;           // + ((part*TG + tap)*2*96 + m*32)*8
     int b_base[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int v = (wave * NT + t) * 32 + j;
+        const int v = (wave * NT + t) * 32 + jv;
         const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
         b_base[t] = (kg * XV + (vd * HH + vh) * HWp + vw) * 8;
     }
@@ -210,48 +226,79 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     int wb = 0;
     for (int c = c_begin; c < c_end; ++c) {
         const bool more = c + 1 < c_end;
+#ifndef MPHIP_ABL_NOX
         if (more) F16X3_LOAD_X(c + 1);
+#endif
 #pragma unroll
-        for (int g = 0; g < 9; ++g) {
-            // stream the next slab while this one is consumed
-            if (g < 8) {
+        for (int g = 0; g < NGRP; ++g) {
+            // stream the next group of slabs while this one is consumed
+#ifndef MPHIP_ABL_NOW
+            if (g < NGRP - 1) {
                 F16X3_DMA_W(c, g + 1, wb ^ 1);
             } else if (more) {
                 F16X3_DMA_W(c + 1, 0, wb ^ 1);
             }
+#endif
             const _Float16 *wsb = Ws + wb * W_BUF + a_base;
+            // Fragments are double buffered in registers by hand: the 10 ds_read_b128 of tap tg+1 are
+            // issued before the 18 MFMAs of tap tg, so LDS latency hides under 576 MFMA cycles (left to
+            // itself hipcc reloads one 28-register set and waits lgkmcnt(0) five times per tap).
+            half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
+#define F16X3_LOAD_FRAGS(set, tg_)                                                                        \
+    {                                                                                                     \
+        const int tap_ = g * GT + (tg_);                                                                  \
+        const int toff_ = (((tap_ / 9) * HH + (tap_ / 3) % 3) * HWp + tap_ % 3) * 8;                      \
+        const int woff_ = ((tg_) / F16X3_TG) * SLAB_HALFS + (((tg_) % F16X3_TG) * 2 * F16X3_COT) * 8;     \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                  \
+            ah[set][m] = *reinterpret_cast<const half8 *>(wsb + woff_ + m * 32 * 8);                      \
+            al[set][m] = *reinterpret_cast<const half8 *>(wsb + woff_ + SLAB_HALFS / 2 + m * 32 * 8);     \
+        }                                                                                                 \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                  \
+            bh[set][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t] + toff_);                        \
+            bl[set][t] = *reinterpret_cast<const half8 *>(Xs + X_PART + b_base[t] + toff_);               \
+        }                                                                                                 \
+    }
+            F16X3_LOAD_FRAGS(0, 0);
 #pragma unroll
-            for (int tg = 0; tg < F16X3_TG; ++tg) {
-                const int tap = g * F16X3_TG + tg;
-                const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
-                const int toff = ((kd * HH + kh) * HWp + kw) * 8;
-                half8 ah[MT], al[MT], bh[NT], bl[NT];
-#pragma unroll
-                for (int m = 0; m < MT; ++m) {
-                    ah[m] = *reinterpret_cast<const half8 *>(wsb + (tg * 2 * F16X3_COT + m * 32) * 8);
-                    al[m] = *reinterpret_cast<const half8 *>(wsb + SLAB_HALFS / 2 + (tg * 2 * F16X3_COT + m * 32) * 8);
-                }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    bh[t] = *reinterpret_cast<const half8 *>(Xs + b_base[t] + toff);
-                    bl[t] = *reinterpret_cast<const half8 *>(Xs + X_PART + b_base[t] + toff);
-                }
+            for (int tg = 0; tg < GT; ++tg) {
+                const int cur = tg & 1;
+                if (tg + 1 < GT) F16X3_LOAD_FRAGS(cur ^ 1, tg + 1);
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this tap's MFMAs
+                // three passes over the 6 accumulators: consecutive MFMAs never share an accumulator
+#ifdef MPHIP_ABL_NOMFMA
+                asm volatile("" ::"v"(ah[cur][0]), "v"(al[cur][0]), "v"(bh[cur][0]), "v"(bl[cur][0]), "v"(ah[cur][MT - 1]),
+                             "v"(al[cur][MT - 1]), "v"(bh[cur][NT - 1]), "v"(bl[cur][NT - 1]));
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, x_, y_, z_) (c_)
+#endif
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t) {
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[t], acc[m][t], 0, 0, 0);
-                    }
+                    for (int t = 0; t < NT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][m], bh[cur][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][m], bl[cur][t], acc[m][t], 0, 0, 0);
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][m], bh[cur][t], acc[m][t], 0, 0, 0);
             }
+#undef F16X3_LOAD_FRAGS
+#ifdef MPHIP_ABL_NOMFMA
+#undef __builtin_amdgcn_mfma_f32_32x32x16_f16
+#endif
             __syncthreads();  // slab (g+1) landed (DMA drained by the barrier's vmcnt(0)); slab g free
             wb ^= 1;
         }
+#ifndef MPHIP_ABL_NOX
         if (more) {
             F16X3_WRITE_X();  // every wave is past its last read of the X tile (barrier above)
             __syncthreads();
         }
+#endif
     }
 #undef F16X3_LOAD_X
 #undef F16X3_WRITE_X
@@ -269,7 +316,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             bv[m][reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg] : 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int v = (wave * NT + t) * 32 + j;
+        const int v = (wave * NT + t) * 32 + jv;
         const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
         float *dv = dst + (size_t)n * Co * DHW + (size_t)(d0 + vd) * HW + (h0 + vh) * W + w0 + vw;
 #pragma unroll
@@ -289,13 +336,17 @@ bool f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k) {
 }
 
 size_t f16x3_packed_bytes(int Co, int Ci) {
-    return 16 + (size_t)(Co / F16X3_COT) * (Ci / F16X3_KC) * 9 * SLAB_HALFS * sizeof(_Float16);
+    return 16 + (size_t)(Co / F16X3_COT) * (Ci / F16X3_KC) * F16X3_NG * SLAB_HALFS * sizeof(_Float16);
 }
 
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     F16x3Plan p;
     p.td = D % 4 == 0 ? 4 : 2;
-    const long tiles = (long)N * (D / p.td) * (H / 8) * (W / 8);
+    // variant: 0 = (td,8,8) tile; 1 = (4,8,16) tile, 512 voxels per workgroup (halves the weight stream per MFMA)
+    static const char *force = getenv("MPHIP_F16X3_TILE");
+    p.variant = (p.td == 4 && W % 16 == 0) ? 1 : 0;
+    if (force && force[0] == '0') p.variant = 0;
+    const long tiles = (long)N * (D / p.td) * (H / 8) * (W / (p.variant ? 16 : 8));
     const int nchunks = Ci / F16X3_KC;
     int sp = 1;
     while (tiles * (Co / F16X3_COT) * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
@@ -324,12 +375,15 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const float *hdr = (const float *)wpacked;
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
-    if (p.td == 4)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H,
-                           W, p.chunks_per_split, xb);
+    if (p.variant == 1)
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
+                           D, H, W, p.chunks_per_split, xb);
+    else if (p.td == 4)
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
+                           H, W, p.chunks_per_split, xb);
     else
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H,
-                           W, p.chunks_per_split, xb);
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
+                           H, W, p.chunks_per_split, xb);
     return check_launch("conv3d_fwd(f16x3)");
 }
 

@@ -11,7 +11,7 @@ __device__ __forceinline__ float buf_load_f(__amdgpu_buffer_rsrc_t rsrc, unsigne
 }
 
 struct F16x3Plan {
-    int td, splits, chunks_per_split;
+    int td, variant, splits, chunks_per_split;
     dim3 grid;
 };
 
