@@ -101,6 +101,15 @@ int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, fl
                      int Co, int D, int H, int W, int k, int precision, void *workspace,
                      size_t workspace_bytes, void *stream);
 
+/* conv + the statistics of the GroupNorm that follows it (nn.Conv3d -> nn.GroupNorm pairs at
+ * model.py:505-508, 390-399, 458-460): same y as mphip_conv3d_fwd plus gn_stats [N*gn_groups][2] =
+ * (mean, rstd) of y, identical to mphip_groupnorm_stats(y) — one host call for the conv -> GN pair. */
+size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
+                                       int gn_groups);
+int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias, float *y, float *gn_stats,
+                        int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups,
+                        float gn_eps, void *workspace, size_t workspace_bytes, void *stream);
+
 /* ------------------------------------------------------------------ K6  GroupNorm
  * Replaces nn.GroupNorm(G,C) eps=1e-5 (model.py:506,508,460,309) and what the reference
  * applies right after it.  Two steps so the global per-(sample,group) reduction is explicit:

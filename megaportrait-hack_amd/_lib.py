@@ -33,6 +33,8 @@ SIGNATURES = {
     "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_conv3d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mphip_conv3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_conv3d_gn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
+    "mphip_conv3d_gn_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
     "mphip_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_groupnorm_stats": (_i, [_p, _p, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
     "mphip_groupnorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

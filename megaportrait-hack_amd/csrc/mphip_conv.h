@@ -22,4 +22,10 @@ int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, hipStream_t s);
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, hipStream_t s);
 
+
+// norm.hip: GroupNorm statistics of x [N,C,S] -> stats [N*G][2] (workspace sized by groupnorm_ws_bytes)
+size_t groupnorm_ws_bytes(int N, int C, int S, int G);
+int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, int G, float eps, void *workspace,
+                           hipStream_t s);
+
 }  // namespace mphip

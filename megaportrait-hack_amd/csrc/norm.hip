@@ -3,6 +3,7 @@
 // ReLU/residual 517-523, 390-403; AvgPool3d 576-580; nn.Upsample 427-433, 585-589;
 // (z+e)@Gamma 945-957; 1x1 Conv2d 446; relu+tanh 462-465.
 #include "mphip_common.h"
+#include "mphip_conv.h"
 #include "mphip_resample.h"
 
 namespace mphip {
@@ -391,25 +392,18 @@ extern "C" int mphip_rt_theta(const float *rot, const float *tr, float *theta, i
     return check_launch("rt_theta");
 }
 
-extern "C" size_t mphip_groupnorm_workspace_bytes(int N, int C, int S, int G) {
+namespace mphip {
+size_t groupnorm_ws_bytes(int N, int C, int S, int G) {
     if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return 0;
     size_t cnt = (size_t)(C / G) * S;
     size_t chunks = (cnt + GN_CHUNK - 1) / GN_CHUNK;
     return (size_t)N * G * chunks * 2 * sizeof(double);
 }
 
-extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C, int S, int G, float eps,
-                                     void *workspace, size_t workspace_bytes, void *stream) {
-    MPHIP_REQUIRE(x && stats, "groupnorm_stats: null pointer");
-    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_stats: bad dims (C=%d G=%d)", C, G);
-    size_t need = mphip_groupnorm_workspace_bytes(N, C, S, G);
-    if (!workspace || workspace_bytes < need) {
-        set_error("groupnorm_stats: workspace %zu bytes < required %zu", workspace_bytes, need);
-        return MPHIP_EWORKSPACE;
-    }
+int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, int G, float eps, void *workspace,
+                           hipStream_t s) {
     size_t cnt = (size_t)(C / G) * S;
     int chunks = (int)((cnt + GN_CHUNK - 1) / GN_CHUNK);
-    hipStream_t s = (hipStream_t)stream;
     if (chunks <= GN_DIRECT_CHUNKS) {
         hipLaunchKernelGGL(gn_stats_direct_kernel, dim3(N * G), dim3(256), 0, s, x, stats, cnt, eps);
         return check_launch("groupnorm_stats");
@@ -418,6 +412,21 @@ extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C,
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const double *)workspace, stats,
                        N * G, chunks, (double)cnt, eps);
     return check_launch("groupnorm_stats");
+}
+}  // namespace mphip
+
+extern "C" size_t mphip_groupnorm_workspace_bytes(int N, int C, int S, int G) { return groupnorm_ws_bytes(N, C, S, G); }
+
+extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C, int S, int G, float eps,
+                                     void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(x && stats, "groupnorm_stats: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_stats: bad dims (C=%d G=%d)", C, G);
+    size_t need = groupnorm_ws_bytes(N, C, S, G);
+    if (!workspace || workspace_bytes < need) {
+        set_error("groupnorm_stats: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    return groupnorm_stats_launch(x, stats, N, C, S, G, eps, workspace, (hipStream_t)stream);
 }
 
 extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,

@@ -219,7 +219,10 @@ def set_conv_hook(hook) -> None:
     _conv_hook = hook
 
 
-def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None) -> torch.Tensor:
+def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_groups: Optional[int] = None,
+           gn_eps: float = 1e-5):
+    """y = conv(x).  With gn_groups, also returns the (mean, rstd) statistics of y for the GroupNorm that
+    follows (one fused pass for split-K convs): -> (y, stats)."""
     x = _req(x, "x")
     if x.dim() != 5 or x.shape[1] != pc.ci:
         raise RuntimeError(f"conv3d: input {tuple(x.shape)} does not match Ci={pc.ci}")
@@ -229,16 +232,27 @@ def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None) -> 
     if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc.co, d, h, w, pc.k, prec):
         prec = 0  # shape outside the fast kernel's tiling: the exact fp32 kernel handles every shape
     wp = pc.packed(prec)
-    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, prec)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device) if ws_bytes else None
+    if gn_groups:
+        ws_bytes = lib.mphip_conv3d_gn_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, prec, gn_groups)
+        stats = torch.empty((n * gn_groups, 2), dtype=torch.float32, device=x.device)
+    else:
+        ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, prec)
+        stats = None
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
     y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
 
     def launch():
-        _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, prec,
-                                        _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
+        if gn_groups:
+            _lib.check(lib.mphip_conv3d_gn_fwd(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(stats), n, ci, pc.co, d, h, w,
+                                               pc.k, prec, gn_groups, gn_eps, _ptr(ws), ws_bytes, _stream()),
+                       "mphip_conv3d_gn_fwd")
+        else:
+            _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, prec,
+                                            _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
         return y
 
-    return _conv_hook(x, pc, launch) if _conv_hook is not None else launch()
+    y = _conv_hook(x, pc, launch) if _conv_hook is not None else launch()
+    return (y, stats) if gn_groups else y
 
 
 # ------------------------------------------------------------------ K6
