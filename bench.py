@@ -74,6 +74,19 @@ class DominantKernelTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            table = json.load(f)
+        for name, rec in table.items():
+            if name.startswith(kernel_prefix):
+                return rec["traffic_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(frames):
     """Times the CPU oracle on this host: B=1 frames through oracle.hotpath_ref.hot_slice."""
     from oracle import hotpath_ref as R
@@ -191,7 +204,7 @@ def main():
         fps = world * B * args.steps / dt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         if f16x3:
-            dom_name = "conv3d_k3_f16x3_kernel<4,8,8> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)"
+            dom_name = "conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)"
             peak, dtype = PEAK_F16_MFMA_TFLOPS, "f16x3 (fp32 in/out, operands split into 2 f16 halves, 3 f16 MFMAs per product, fp32 accumulate)"
         else:
             dom_name = "conv3d_k3_tiled_kernel<4,8,8,3,2> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)"
@@ -211,7 +224,8 @@ def main():
             "hot_slice_vs_f32_mfma_peak": round(fps * FRAME_FLOPS / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "hot_slice_layerwise_GBps": round(fps * FRAME_BYTES / 1e9, 1),
             "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                         "traffic": pmc_traffic("conv3d_k3_f16x3_kernel") if (f16x3 and B == 8) else None,
                          "launch_ms": round(dom_ms, 4), "launches_timed": len(dom.events),
                          "flops_per_launch": dom_flops,
                          "note": ("algorithmic (fp32-equivalent) FLOPs; the kernel issues 3x that on the f16 pipe: "

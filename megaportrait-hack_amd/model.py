@@ -235,6 +235,30 @@ class G3d(nn.Module):
         return ops.conv3d(x, _packs.get(self.final_conv))
 
 
+class Eapp3DTail(nn.Module):
+    """Next scope row: the 3D tail of Eapp, model.py:217-226 + 271-290.  Attribute names are
+    the reference Eapp's, so `appearanceEncoder.resblock3D_*` checkpoint keys load into this module directly.
+    The reference assigns `resblock3D_96_2` twice (model.py:218,225): five blocks exist, one is applied twice."""
+
+    _ORDER = ("resblock3D_96", "resblock3D_96_2", "resblock3D_96_1", "resblock3D_96_1_2", "resblock3D_96_2",
+              "resblock3D_96_2_2")
+
+    def __init__(self):
+        super().__init__()
+        self.resblock3D_96 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
+        self.resblock3D_96_1 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
+        self.resblock3D_96_1_2 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
+        self.resblock3D_96_2 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
+        self.resblock3D_96_2_2 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
+
+    def forward(self, out):
+        """out: Eapp's conv_1 output [B,1536,H,W] (model.py:268) or the reshaped volume [B,96,16,H,W]."""
+        vs = out.view(out.size(0), 96, 16, *out.shape[2:]) if out.dim() == 4 else out  # model.py:271
+        for name in self._ORDER:
+            vs = getattr(self, name)(vs)
+        return vs
+
+
 class GbaseHotSlice(nn.Module):
     """The slice of Gbase.forward between the 2D encoders and G2d (model.py:1151-1171), with the
     reference's attribute names so a Gbase checkpoint's `warp_generator_s2c.*`,

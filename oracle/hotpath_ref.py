@@ -14,7 +14,7 @@ calls the same ATen CPU primitives the reference would hit on a CPU host.  A
 second, ATen-free restatement of the same ops in plain C (oracle/hotpath_c.c,
 wrapped by oracle/hotpath_c.py) pins the bit-level index pipeline.
 
-Pinning: tests/test_oracle_vs_reference.py checks every function here against
+Pinning: tests/test_oracle.py checks every function here against
 the imported reference (this container only) and tests/golden/*.npz holds the
 outputs the reference produced for seeded inputs (generator:
 oracle/make_golden.py), so the oracle stays pinned on the GPU box where
@@ -193,6 +193,36 @@ def g3d(x, sd: SD, prefix: str = "G3d.") -> torch.Tensor:
     x = resblock3d(x, sd, prefix + "upsampling.4.")
     x = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
     return F.conv3d(x, sd[prefix + "final_conv.weight"], sd[prefix + "final_conv.bias"], padding=1)
+
+
+# --------------------------------------------------------------------------- f1 (next row)
+_EAPP_TAIL_ORDER = ("resblock3D_96", "resblock3D_96_2", "resblock3D_96_1", "resblock3D_96_1_2", "resblock3D_96_2",
+                    "resblock3D_96_2_2")   # model.py:276-290 — `resblock3D_96_2` is assigned twice (218,225) and applied twice
+
+
+def eapp_tail3d(feat: torch.Tensor, sd: SD, prefix: str = "appearanceEncoder.") -> torch.Tensor:
+    """Eapp's 3D tail, model.py:271-290: [B,1536,H,W] -> view [B,96,16,H,W] -> six applications of five
+    ResBlock3D_Adaptive(96,96) blocks.  Accepts the 1536-channel map or an already reshaped volume."""
+    vs = feat.view(feat.size(0), 96, 16, *feat.shape[2:]) if feat.dim() == 4 else feat
+    for name in _EAPP_TAIL_ORDER:
+        vs = resblock3d_adaptive(vs, sd, f"{prefix}{name}.")
+    return vs
+
+
+def eapp_tail_shapes() -> Dict[str, tuple]:
+    sh = {}
+    for name in sorted(set(_EAPP_TAIL_ORDER)):
+        p = name + "."
+        sh[p + "conv1.weight"] = (96, 96, 3, 3, 3)
+        sh[p + "conv1.bias"] = (96,)
+        sh[p + "conv2.weight"] = (96, 96, 3, 3, 3)
+        sh[p + "conv2.bias"] = (96,)
+        for n in ("norm1.", "norm2."):
+            sh[p + n + "weight"] = (1, 96, 1, 1, 1)
+            sh[p + n + "bias"] = (1, 96, 1, 1, 1)
+            sh[p + n + "group_norm.weight"] = (96,)
+            sh[p + n + "group_norm.bias"] = (96,)
+    return sh
 
 
 # --------------------------------------------------------------------------- a1

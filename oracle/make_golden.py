@@ -133,6 +133,23 @@ def main():
         proj16 = torch.sum(m.apply_warping_field(g3d(m.apply_warping_field(inp16["vs"], w1)), w2), dim=2)
         np.savez(os.path.join(OUT, "hot_slice.npz"), full=proj.numpy(), small16=proj16.numpy())
 
+    # (9) next-row f1: Eapp's 3D tail (model.py:271-290) on a [1,1536,16,16] map (volume 96x16x16x16)
+    with torch.no_grad():
+        tail_sd = R.seeded_state_dict(R.eapp_tail_shapes(), WEIGHT_SEED + 10, "appearanceEncoder.")
+        blocks = {}
+        for name in sorted(set(R._EAPP_TAIL_ORDER)):
+            blk = m.ResBlock3D_Adaptive(in_channels=96, out_channels=96)
+            blk.load_state_dict({k[len("appearanceEncoder." + name + "."):]: v for k, v in tail_sd.items()
+                                 if k.startswith("appearanceEncoder." + name + ".")}, strict=True)
+            blocks[name] = blk.eval()
+        feat = R.seeded_tensor((1, 1536, 16, 16), 110, scale=1.7)
+        vs_t = feat.view(1, 96, 16, 16, 16)
+        for name in R._EAPP_TAIL_ORDER:
+            vs_t = blocks[name](vs_t)
+        np.savez(os.path.join(OUT, "eapp_tail.npz"), out_s2=vs_t[:, :, ::2, ::2, ::2].contiguous().numpy(),
+                 chan_mean=vs_t.double().mean(dim=(2, 3, 4)).numpy(), sha1=_sha(vs_t))
+        assert torch.equal(vs_t, R.eapp_tail3d(feat, tail_sd))
+
     # (8) state-dict manifest (names/shapes are the checkpoint-layout contract)
     manifest["state_dict"] = {
         "warp_generator_s2c": {k: list(v.shape) for k, v in s2c.state_dict().items()},

@@ -301,6 +301,24 @@ def test_g3d_golden(dev, hot, sd):
         assert maxabs(got, R.g3d(x16, sd)) < 1e-3
 
 
+def test_eapp_tail_golden_and_full_size(M, dev):
+    """Scope row f1: Eapp's 3D tail (model.py:271-290) through the same HIP kernels, reference key names."""
+    sd_t = R.seeded_state_dict(R.eapp_tail_shapes(), WEIGHT_SEED + 10, "appearanceEncoder.")
+    tail = M.Eapp3DTail()
+    tail.load_state_dict({k[len("appearanceEncoder."):]: v for k, v in sd_t.items()}, strict=True)
+    tail = tail.to(dev).eval()
+    feat = R.seeded_tensor((1, 1536, 16, 16), 110, scale=1.7)
+    with torch.no_grad():
+        got = tail(feat.to(dev))
+        assert got.shape == (1, 96, 16, 16, 16)
+        assert maxabs(got[:, :, ::2, ::2, ::2], gold("eapp_tail")["out_s2"]) < 1e-3
+        # full 512^2 size: [1,1536,64,64] -> 96x16x64x64 volume, 391 GFLOP, vs the ATen-CPU oracle
+        feat_full = R.seeded_tensor((1, 1536, 64, 64), 111, scale=1.7)
+        err = maxabs(tail(feat_full.to(dev)), R.eapp_tail3d(feat_full, sd_t))
+        print(f"Eapp 3D tail full size max-abs vs oracle = {err:.3e}")
+        assert err < 1e-3
+
+
 def test_hot_slice_small_golden(dev, hot):
     inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, INPUT_SEED + 1, D=16, H=16, W=16).items()}
     with torch.no_grad():

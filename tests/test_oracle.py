@@ -82,6 +82,17 @@ def test_ref_hot_slice_small_golden(sd):
     assert maxabs(R.hot_slice(sd=sd, **inp), gold("hot_slice")["small16"]) < 1e-4
 
 
+def test_ref_eapp_tail_golden():
+    """Next-row f1 (Eapp 3D tail, model.py:271-290): five blocks, six applications."""
+    sd_t = R.seeded_state_dict(R.eapp_tail_shapes(), WEIGHT_SEED + 10, "appearanceEncoder.")
+    assert len({k.split(".")[1] for k in sd_t}) == 5
+    feat = R.seeded_tensor((1, 1536, 16, 16), 110, scale=1.7)
+    out = R.eapp_tail3d(feat, sd_t)
+    g = gold("eapp_tail")
+    assert out.shape == (1, 96, 16, 16, 16)
+    assert maxabs(out[:, :, ::2, ::2, ::2], g["out_s2"]) < 1e-5
+
+
 # ------------------------------------------------------------------ plain-C restatement
 def test_c_index_pipeline_matches_aten_here(oracle_c):
     """Bit-level pin of the C oracle against ATen's CPU kernels.  ATen's FMA use depends on the host
