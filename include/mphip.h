@@ -110,6 +110,15 @@ int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias,
                         int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups,
                         float gn_eps, void *workspace, size_t workspace_bytes, void *stream);
 
+/* Split-K aware chain for small volumes (G3d's 4x16x16 / 2x8x8 levels, all of FlowField): the conv leaves
+ * its result as `splits` partial slabs out[z][N,Co,D,H,W] (bias NOT added) and the GroupNorm statistics /
+ * apply kernels that consume it sum the slabs on the fly (z ascending + bias, the same order as the
+ * reduce of mphip_conv3d_fwd), so the separate reduce launch and pass disappear.
+ * mphip_conv3d_splits() == 1 means the conv is not split: out is then the plain result (bias added). */
+int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
+int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bias, float *out, int N, int Ci,
+                           int Co, int D, int H, int W, int k, int precision, void *stream);
+
 /* ------------------------------------------------------------------ K6  GroupNorm
  * Replaces nn.GroupNorm(G,C) eps=1e-5 (model.py:506,508,460,309) and what the reference
  * applies right after it.  Two steps so the global per-(sample,group) reduction is explicit:
@@ -126,6 +135,18 @@ int mphip_groupnorm_stats(const float *x, float *stats, int N, int C, int S, int
 int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,
                           const float *w2, const float *b2, const float *residual, float *y, int N, int C,
                           int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream);
+
+/* Split-aware variants (see mphip_conv3d_fwd_split): x and/or residual may be `*_splits` partial slabs with
+ * their conv bias passed separately; the output can additionally be nearest-upsampled by (uD,uH,uW) —
+ * the nn.Upsample that follows each FlowField block (model.py:427-433, 450-457) — or 2x2x2 pooled.
+ * Meant for small tensors (one thread per output element; stats: group span <= 65536 floats).        */
+int mphip_groupnorm_stats_split(const float *x, int x_splits, const float *x_bias, float *stats, int N, int C,
+                                int S, int G, float eps, void *stream);
+int mphip_groupnorm_apply_split(const float *x, int x_splits, const float *x_bias, const float *stats,
+                                const float *gamma, const float *beta, const float *w2, const float *b2,
+                                const float *residual, int res_splits, const float *res_bias, float *y, int N,
+                                int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, int uD, int uH,
+                                int uW, void *stream);
 
 /* ------------------------------------------------------------------ K7  resampling
  * avgpool2:            nn.AvgPool3d(2,2)                                   (model.py:576-580)

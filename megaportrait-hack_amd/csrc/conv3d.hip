@@ -103,30 +103,62 @@ conv3d_gather_kernel(const float *__restrict__ x, const float *__restrict__ wp, 
 
     const float *wlane = wp + (size_t)kk * CoP + co0 + j;
 
-    for (int ci = ci_begin; ci < ci_end; ci += 2) {
-        const bool ci_ok = ci + kk < Ci;  // CiP may exceed Ci by one (odd Ci)
-        const unsigned soff = (unsigned)((long)ci * DHW * 4);
-#pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            if (SKIP && !((anymask >> tap) & 1u)) continue;
-            const int kd = KS == 3 ? tap / 9 - 1 : 0, kh = KS == 3 ? (tap / 3) % 3 - 1 : 0, kw = KS == 3 ? tap % 3 - 1 : 0;
-            const int toff = (kd * HW + kh * W + kw) * 4;
-            float a[MT], b[NT];
-            const float *wrow = wlane + ((size_t)tap * CiP + ci) * CoP;
-#pragma unroll
-            for (int m = 0; m < MT; ++m) a[m] = wrow[m * 32];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                bool ok = ((vmask[t] >> tap) & 1u) && ci_ok;
-                b[t] = buf_load(rsrc, ok ? vbyte[t] + (unsigned)toff : OOB, soff);
-            }
-#pragma unroll
-            for (int m = 0; m < MT; ++m)
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[m][t], 0, 0, 0);
+    // All fragment loads of a channel pair are issued before its first MFMA, and (when the register budget
+    // allows: MT+NT <= 3) the next pair's loads are issued before this pair's MFMAs.  The small-volume
+    // layers this kernel serves (FlowField, 1x1 shortcuts) run about one wave per SIMD on cold, read-once
+    // weights: a load -> wait -> MFMA chain per tap would pay a full memory latency 27 times per pair.
+    // "Items" of one pipeline stage: the 27 taps of a channel pair (k=3), or 8 consecutive channel pairs (k=1).
+    constexpr int ITEMS = KS == 3 ? TAPS : 8;
+    constexpr int CI_STEP = KS == 3 ? 2 : 16;
+#define MPHIP_GATHER_LOAD(A_, B_, ci_)                                                                               \
+    {                                                                                                                \
+        _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                       \
+            const int tap = KS == 3 ? it : 0;                                                                        \
+            const int cc_ = (ci_) + (KS == 3 ? 0 : 2 * it);                                                          \
+            if (SKIP && !((anymask >> tap) & 1u)) continue;                                                          \
+            const bool in_ = cc_ < ci_end;               /* k=1: the last stage of a slice may be partial */         \
+            const bool ci_ok_ = in_ && (cc_ + kk < Ci);  /* CiP may exceed Ci by one (odd Ci) */                     \
+            const unsigned soff_ = (unsigned)((long)(in_ ? cc_ : ci_begin) * DHW * 4);                               \
+            const int kd = KS == 3 ? tap / 9 - 1 : 0, kh = KS == 3 ? (tap / 3) % 3 - 1 : 0, kw = KS == 3 ? tap % 3 - 1 : 0; \
+            const int toff = (kd * HW + kh * W + kw) * 4;                                                            \
+            const float *wrow = wlane + ((size_t)tap * CiP + (in_ ? cc_ : ci_begin)) * CoP;                          \
+            /* out-of-slice items read a valid (clamped) weight row: their B operand is the hardware zero fill, */   \
+            /* so the product vanishes without a branch around the load                                         */   \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m) A_[it][m] = wrow[m * 32];                                 \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                         \
+                bool ok = ((vmask[t] >> tap) & 1u) && ci_ok_;                                                        \
+                B_[it][t] = buf_load(rsrc, ok ? vbyte[t] + (unsigned)toff : OOB, soff_);                             \
+            }                                                                                                        \
+        }                                                                                                            \
+    }
+#define MPHIP_GATHER_MFMA(A_, B_)                                                                                    \
+    {                                                                                                                \
+        _Pragma("unroll") for (int it = 0; it < ITEMS; ++it) {                                                       \
+            if (SKIP && !((anymask >> (KS == 3 ? it : 0)) & 1u)) continue;                                           \
+            _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                           \
+                _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                       \
+                    acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(A_[it][m], B_[it][t], acc[m][t], 0, 0, 0);      \
+        }                                                                                                            \
+    }
+    constexpr bool DOUBLE_BUF = KS == 1 || (MT + NT) <= 3;
+    if (DOUBLE_BUF) {
+        float a0[ITEMS][MT], b0[ITEMS][NT], a1[ITEMS][MT], b1[ITEMS][NT];
+        if (ci_begin < ci_end) MPHIP_GATHER_LOAD(a0, b0, ci_begin);
+        for (int ci = ci_begin; ci < ci_end; ci += 2 * CI_STEP) {
+            if (ci + CI_STEP < ci_end) MPHIP_GATHER_LOAD(a1, b1, ci + CI_STEP);
+            MPHIP_GATHER_MFMA(a0, b0);
+            if (ci + 2 * CI_STEP < ci_end) MPHIP_GATHER_LOAD(a0, b0, ci + 2 * CI_STEP);
+            if (ci + CI_STEP < ci_end) MPHIP_GATHER_MFMA(a1, b1);
+        }
+    } else {
+        float a[ITEMS][MT], b[ITEMS][NT];
+        for (int ci = ci_begin; ci < ci_end; ci += CI_STEP) {
+            MPHIP_GATHER_LOAD(a, b, ci);
+            MPHIP_GATHER_MFMA(a, b);
         }
     }
+#undef MPHIP_GATHER_LOAD
+#undef MPHIP_GATHER_MFMA
 
     // epilogue: gridDim.z == 1 -> y (+bias); else partial slab z (bias added by the reduce kernel)
     const bool direct = gridDim.z == 1;
@@ -358,24 +390,34 @@ static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
     p.CiP = (Ci + 1) / 2 * 2;
     const long M = (long)N * D * H * W;
     const int co_tiles32 = p.CoP / 32;
-    if (co_tiles32 % 3 == 0) p.MT = 3;
-    else if (co_tiles32 % 4 == 0) p.MT = 4;
-    else if (co_tiles32 % 2 == 0) p.MT = 2;
-    else p.MT = 1;
-    p.NT = M >= 64 * 64 ? 2 : 1;
-    // waves along Co when the voxel axis is too short to feed 4 waves
+    p.NT = (M >= 64 * 64 && k == 3) ? 2 : 1;  // k=1: short K loop, favour more (lighter) waves: 2 per SIMD
     const long vox_tiles = (M + p.NT * 32 - 1) / (p.NT * 32);
+    // Largest split-K factor the channel range allows (>= 8 channels per slice, power of two, <= 32).
+    int max_splits = 1;
+    while (max_splits < 32 && p.CiP / (max_splits * 2) >= 8 && p.CiP % (max_splits * 4) == 0) max_splits *= 2;
+    // Rows of 32 output channels per wave: as many as possible (operand reuse) while the launch still
+    // offers ~one wave per SIMD (1024); small volumes trade reuse for parallelism (MT -> 1, more slices),
+    // because there a wave's serial MFMA chain, not bandwidth, is the critical path.
+    const int cands[4] = {4, 3, 2, 1};
+    p.MT = 1;
+    for (int ci = 0; ci < 4; ++ci) {
+        const int mt = cands[ci];
+        if (co_tiles32 % mt) continue;
+        if ((long)(co_tiles32 / mt) * vox_tiles * max_splits >= 1024 || mt == 1) {
+            p.MT = mt;
+            break;
+        }
+    }
     const int co_wave_tiles = co_tiles32 / p.MT;
+    // waves along Co when the voxel axis is too short to feed 4 waves
     p.WCO = 1;
     if (vox_tiles < 4 * 64 && co_wave_tiles % 4 == 0) p.WCO = 4;
     else if (vox_tiles < 4 * 64 && co_wave_tiles % 2 == 0) p.WCO = 2;
     const int wvox = 4 / p.WCO;
     p.grid.x = (unsigned)((vox_tiles + wvox - 1) / wvox);
     p.grid.y = (unsigned)((co_wave_tiles + p.WCO - 1) / p.WCO);
-    // split-K over Ci until ~2 workgroups per CU, keeping >= 8 input channels per slice
-    long blocks = (long)p.grid.x * p.grid.y;
     int splits = 1;
-    while (blocks * splits < 512 && p.CiP / (splits * 2) >= 8 && (p.CiP % (splits * 2 * 2) == 0)) splits *= 2;
+    while ((long)co_wave_tiles * vox_tiles * splits < 1024 && splits < max_splits) splits *= 2;
     p.splits = splits;
     p.ci_per_split = p.CiP / splits;
     p.grid.z = splits;
@@ -481,7 +523,7 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
 }
 
 static int conv3d_run(const float *x, const void *w_packed, const float *bias, float *y, float *gn_stats, int gn_groups,
-                      float gn_eps, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                      float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                       size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
@@ -505,7 +547,7 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
     }
     float *dst = y;
     const size_t n_out = (size_t)N * Co * D * H * W;
-    const size_t slab_bytes = splits > 1 ? (size_t)splits * n_out * sizeof(float) : 0;
+    const size_t slab_bytes = (splits > 1 && !keep_split) ? (size_t)splits * n_out * sizeof(float) : 0;
     const size_t gn_bytes = gn_stats ? groupnorm_ws_bytes(N, Co, D * H * W, gn_groups) : 0;
     if (slab_bytes + gn_bytes > 0) {
         if (!workspace || workspace_bytes < slab_bytes + gn_bytes) {
@@ -513,7 +555,11 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
             return MPHIP_EWORKSPACE;
         }
     }
-    if (splits > 1) dst = (float *)workspace;
+    if (keep_split) {
+        dst = y;  // caller-owned [splits][N,Co,D,H,W]; the kernels add the bias only when splits == 1
+    } else if (splits > 1) {
+        dst = (float *)workspace;
+    }
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
     if (precision == 1) {
@@ -532,7 +578,7 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
     }
     if (rc) return rc;
     const int S = D * H * W;
-    if (splits > 1) {
+    if (splits > 1 && !keep_split) {
         // (a reduce fused with the GroupNorm statistics was tried: one workgroup per (sample, group) span is too
         //  little parallelism for these small tensors — 4 % slower end to end than reduce + single-launch stats)
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n_out, 256)), dim3(256), 0, s, (const float *)workspace, bias, y,
@@ -547,8 +593,18 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
 extern "C" int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
                                 int Co, int D, int H, int W, int k, int precision, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-    return conv3d_run(x, w_packed, bias, y, nullptr, 0, 0.0f, N, Ci, Co, D, H, W, k, precision, workspace, workspace_bytes,
-                      stream);
+    return conv3d_run(x, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
+                      workspace_bytes, stream);
+}
+
+extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    return precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
+}
+
+extern "C" int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bias, float *out, int N, int Ci,
+                                      int Co, int D, int H, int W, int k, int precision, void *stream) {
+    return conv3d_run(x, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, nullptr, 0, stream);
 }
 
 extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
@@ -563,6 +619,6 @@ extern "C" int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const f
     MPHIP_REQUIRE(gn_stats, "conv3d_gn_fwd: null stats pointer");
     MPHIP_REQUIRE(gn_groups > 0 && Co > 0 && Co % gn_groups == 0, "conv3d_gn_fwd: Co=%d not divisible into %d groups", Co,
                   gn_groups);
-    return conv3d_run(x, w_packed, bias, y, gn_stats, gn_groups, gn_eps, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }

@@ -342,14 +342,20 @@ size_t f16x3_packed_bytes(int Co, int Ci) {
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     F16x3Plan p;
     p.td = D % 4 == 0 ? 4 : 2;
-    // variant: 0 = (td,8,8) tile; 1 = (4,8,16) tile, 512 voxels per workgroup (halves the weight stream per MFMA)
+    // variant: 0 = (td,8,8) tile, 256 voxels per workgroup; 1 = (4,8,16) tile, 512 voxels per workgroup (halves the
+    // weight stream per MFMA) — only when that still gives every CU two workgroups' worth of tiles.
     static const char *force = getenv("MPHIP_F16X3_TILE");
-    p.variant = (p.td == 4 && W % 16 == 0) ? 1 : 0;
+    const int cot = Co / F16X3_COT;
+    const long tiles1 = (p.td == 4 && W % 16 == 0) ? (long)N * (D / 4) * (H / 8) * (W / 16) : 0;
+    p.variant = (tiles1 * cot >= 512) ? 1 : 0;
     if (force && force[0] == '0') p.variant = 0;
-    const long tiles = (long)N * (D / p.td) * (H / 8) * (W / (p.variant ? 16 : 8));
+    if (force && force[0] == '1' && tiles1) p.variant = 1;
+    const long tiles = p.variant ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
+    // split-K only when the launch cannot give every CU a workgroup: each split adds a slab write + a reduce pass
     int sp = 1;
-    while (tiles * (Co / F16X3_COT) * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
+    if (tiles * cot < 256)
+        while (tiles * cot * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
     p.splits = sp;
     p.chunks_per_split = (nchunks + sp - 1) / sp;
     p.grid = dim3((unsigned)tiles, Co / F16X3_COT, sp);

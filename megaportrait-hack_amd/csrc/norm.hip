@@ -63,6 +63,7 @@ gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, s
     const float *p = x + (size_t)grp * cnt;
     double ds = 0.0, dss = 0.0;
     const bool vec = (cnt & 3) == 0 && (((size_t)p) & 15) == 0;
+    // (the split-K aware variant is gn_stats_split_kernel below)
     for (size_t begin = 0; begin < cnt; begin += GN_CHUNK) {   // same per-chunk fp32 partials as the 2-stage path
         const size_t end = begin + GN_CHUNK < cnt ? begin + GN_CHUNK : cnt;
         float s = 0.0f, ss = 0.0f;
@@ -81,6 +82,48 @@ gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, s
         }
         ds += (double)s;
         dss += (double)ss;
+    }
+    ds = wave_sum(ds);
+    dss = wave_sum(dss);
+    __shared__ double red[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = ds;
+        red[wave * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = (red[0] + red[2]) + (red[4] + red[6]);
+        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        double mean = a / (double)cnt;
+        double var = b / (double)cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[grp * 2] = (float)mean;
+        stats[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// Statistics of a conv output that is still in split-K form: value(i) = bias[c] + sum_z slab[z][i]
+// (z ascending, the order mphip_conv3d_fwd's reduce uses).  Small tensors only: one workgroup per group.
+__global__ void __launch_bounds__(256)
+gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, const float *__restrict__ bias,
+                      float *__restrict__ stats, int C, int cpg, int S, float eps) {
+    const int grp = blockIdx.x;
+    const size_t cnt = (size_t)cpg * S, base = (size_t)grp * cnt;
+    const int c0 = (int)((base / S) % (size_t)C);
+    double ds = 0.0, dss = 0.0;
+    {   // flat over the (channel, voxel) span so tiny S (FlowField's 4x1x1 level) still uses every lane
+        float s = 0.0f, ss = 0.0f;
+        for (size_t e = threadIdx.x; e < cnt; e += 256) {
+            const size_t o = base + e;
+            float v = x[o];
+            for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + o];
+            if (bias) v += bias[c0 + (int)(e / S)];
+            s += v;
+            ss += v * v;
+        }
+        ds = (double)s;
+        dss = (double)ss;
     }
     ds = wave_sum(ds);
     dss = wave_sum(dss);
@@ -197,6 +240,63 @@ __global__ void __launch_bounds__(256) gn_apply_pool_kernel(GnParams p, int D, i
     p.y[t] = s / 8.0f;
 }
 
+// General apply for small tensors: x and/or the residual may still be split-K slabs (value = bias[c] +
+// sum_z slab[z]), the output may be 2x2x2 average-pooled or nearest-upsampled by (uD,uH,uW) (the
+// nn.Upsample that follows FlowField's blocks, model.py:427-433).  One thread per OUTPUT element.
+struct GnSplitParams {
+    GnParams p;
+    int x_splits, res_splits;
+    size_t slab;  // elements per slab = N*C*D*H*W
+    const float *x_bias, *res_bias;
+    int D, H, W, pool2, uD, uH, uW;
+};
+
+__device__ __forceinline__ float split_value(const float *__restrict__ x, int splits, size_t slab, size_t o, float bias) {
+    float v = x[o];
+    for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + o];
+    return v + bias;
+}
+
+__global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const GnParams &p = q.p;
+    const int oD = q.pool2 ? q.D / 2 : q.D * q.uD, oH = q.pool2 ? q.H / 2 : q.H * q.uH, oW = q.pool2 ? q.W / 2 : q.W * q.uW;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    int c = (int)(plane % p.C);
+    int n = (int)(plane / p.C);
+    int grp = n * (p.C / p.cpg) + c / p.cpg;
+    const float mean = p.stats[grp * 2], rstd = p.stats[grp * 2 + 1];
+    const float g = p.gamma[c], b = p.beta[c];
+    const bool has2 = p.w2 != nullptr, has_res = p.residual != nullptr;
+    const float w2 = has2 ? p.w2[c] : 1.0f, b2 = has2 ? p.b2[c] : 0.0f;
+    const float xb = (q.x_splits > 1 && q.x_bias) ? q.x_bias[c] : 0.0f;
+    const float rb = (q.res_splits > 1 && q.res_bias) ? q.res_bias[c] : 0.0f;
+    const size_t pbase = plane * q.D * q.H * q.W;
+    if (q.pool2) {
+        float s = 0.0f;
+        for (int a = 0; a < 2; ++a)
+            for (int bb = 0; bb < 2; ++bb)
+                for (int cc = 0; cc < 2; ++cc) {
+                    size_t o = pbase + ((size_t)(2 * od + a) * q.H + 2 * oh + bb) * q.W + 2 * ow + cc;
+                    float xv = split_value(p.x, q.x_splits, q.slab, o, xb);
+                    float rv = has_res ? split_value(p.residual, q.res_splits, q.slab, o, rb) : 0.0f;
+                    s += gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
+                }
+        p.y[t] = s / 8.0f;
+    } else {
+        size_t o = pbase + ((size_t)(od / q.uD) * q.H + oh / q.uH) * q.W + ow / q.uW;
+        float xv = split_value(p.x, q.x_splits, q.slab, o, xb);
+        float rv = has_res ? split_value(p.residual, q.res_splits, q.slab, o, rb) : 0.0f;
+        p.y[t] = gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
+    }
+}
+
 __global__ void __launch_bounds__(256) avgpool2_kernel(const float *__restrict__ x, float *__restrict__ y, int D,
                                                        int H, int W, size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -233,35 +333,83 @@ __device__ __forceinline__ SrcIdx src_index_scaled(int dst, int in, float scale)
     return r;
 }
 
+// One thread makes a 2(d) x 2(h) x 4(w) brick of outputs (four 16-byte stores): the brick's sources are a
+// 3 x 3 x 4 neighbourhood at most, read once into registers (36 loads for 16 outputs instead of 128), and
+// every output is the same nested W->H->D lerp as the scalar form, so results stay bit-identical.
 __global__ void __launch_bounds__(256)
 upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, int D, int H, int W, float sD, float sH,
-                           float sW, size_t total4) {
+                           float sW, size_t nbricks) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total4) return;
-    const int oD = 2 * D, oH = 2 * H, oW4 = W / 2;  // 2W/4 float4 per output row
-    int ow = (int)(t % oW4) * 4;
-    size_t r = t / oW4;
-    int oh = (int)(r % oH);
-    r /= oH;
-    int od = (int)(r % oD);
-    size_t plane = r / oD;
-    const SrcIdx sd = src_index_scaled(od, D, sD), sh = src_index_scaled(oh, H, sH);
+    if (t >= nbricks) return;
+    const int oH = 2 * H, oW = 2 * W;
+    const int bw = W / 2;  // bricks per output row (2W / 4)
+    int kw = (int)(t % bw);
+    size_t r = t / bw;
+    int kh = (int)(r % H);      // output rows 2kh, 2kh+1
+    r /= H;
+    int kd = (int)(r % D);      // output slices 2kd, 2kd+1
+    size_t plane = r / D;
     const float *p = x + plane * D * H * W;
-    const float *r00 = p + ((size_t)sd.i0 * H + sh.i0) * W, *r01 = p + ((size_t)sd.i0 * H + sh.i1) * W;
-    const float *r10 = p + ((size_t)sd.i1 * H + sh.i0) * W, *r11 = p + ((size_t)sd.i1 * H + sh.i1) * W;
-    float o[4];
+    SrcIdx sd[2], sh[2], sw[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const SrcIdx sw = src_index_scaled(ow + i, W, sW);
-        float a00 = lerp2(sw.l0, r00[sw.i0], sw.l1, r00[sw.i1]);
-        float a01 = lerp2(sw.l0, r01[sw.i0], sw.l1, r01[sw.i1]);
-        float a10 = lerp2(sw.l0, r10[sw.i0], sw.l1, r10[sw.i1]);
-        float a11 = lerp2(sw.l0, r11[sw.i0], sw.l1, r11[sw.i1]);
-        float b0 = lerp2(sh.l0, a00, sh.l1, a01);
-        float b1 = lerp2(sh.l0, a10, sh.l1, a11);
-        o[i] = lerp2(sd.l0, b0, sd.l1, b1);
+    for (int i = 0; i < 2; ++i) {
+        sd[i] = src_index_scaled(2 * kd + i, D, sD);
+        sh[i] = src_index_scaled(2 * kh + i, H, sH);
     }
-    *reinterpret_cast<float4 *>(y + t * 4) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sw[i] = src_index_scaled(4 * kw + i, W, sW);
+    // distinct source indices: d in {d_lo..d_lo+2}, h likewise, w in {w_lo..w_lo+3}
+    const int d_lo = sd[0].i0, h_lo = sh[0].i0, w_lo = sw[0].i0;
+    float v[3][3][4];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const float *row = p + ((size_t)min(d_lo + a, D - 1) * H + min(h_lo + b, H - 1)) * W;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[a][b][c] = row[min(w_lo + c, W - 1)];
+        }
+    // separable evaluation, identical operand pairs to the nested form: W, then H, then D
+    auto sel3 = [](int k, float q0, float q1, float q2) -> float { return k == 0 ? q0 : (k == 1 ? q1 : q2); };
+    auto sel4 = [](int k, float q0, float q1, float q2, float q3) -> float {
+        return k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+    };
+    float wl[3][3][4];  // [src d][src h][out w]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int c0 = sw[c].i0 - w_lo, c1 = sw[c].i1 - w_lo;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                wl[a][b][c] = lerp2(sw[c].l0, sel4(c0, v[a][b][0], v[a][b][1], v[a][b][2], v[a][b][3]), sw[c].l1,
+                                    sel4(c1, v[a][b][0], v[a][b][1], v[a][b][2], v[a][b][3]));
+    }
+    float hl[3][2][4];  // [src d][out h][out w]
+#pragma unroll
+    for (int jh = 0; jh < 2; ++jh) {
+        const int b0 = sh[jh].i0 - h_lo, b1 = sh[jh].i1 - h_lo;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                hl[a][jh][c] = lerp2(sh[jh].l0, sel3(b0, wl[a][0][c], wl[a][1][c], wl[a][2][c]), sh[jh].l1,
+                                     sel3(b1, wl[a][0][c], wl[a][1][c], wl[a][2][c]));
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int a0 = sd[i].i0 - d_lo, a1 = sd[i].i1 - d_lo;
+#pragma unroll
+        for (int jh = 0; jh < 2; ++jh) {
+            float o[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                o[c] = lerp2(sd[i].l0, sel3(a0, hl[0][jh][c], hl[1][jh][c], hl[2][jh][c]), sd[i].l1,
+                             sel3(a1, hl[0][jh][c], hl[1][jh][c], hl[2][jh][c]));
+            float *dst = y + ((plane * 2 * D + 2 * kd + i) * oH + 2 * kh + jh) * (size_t)oW + 4 * kw;
+            *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
 }
 
 // generic (odd W) fallback: one output per thread
@@ -452,6 +600,35 @@ extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const f
     return check_launch("groupnorm_apply");
 }
 
+extern "C" int mphip_groupnorm_stats_split(const float *x, int x_splits, const float *x_bias, float *stats, int N, int C,
+                                           int S, int G, float eps, void *stream) {
+    MPHIP_REQUIRE(x && stats, "groupnorm_stats_split: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0 && x_splits >= 1, "groupnorm_stats_split: bad dims");
+    MPHIP_REQUIRE((size_t)(C / G) * S <= (size_t)GN_DIRECT_CHUNKS * GN_CHUNK,
+                  "groupnorm_stats_split: group span too large for the single-launch path (reduce first)");
+    hipLaunchKernelGGL(gn_stats_split_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, x, x_splits,
+                       (size_t)N * C * S, x_bias, stats, C, C / G, S, eps);
+    return check_launch("groupnorm_stats_split");
+}
+
+extern "C" int mphip_groupnorm_apply_split(const float *x, int x_splits, const float *x_bias, const float *stats,
+                                           const float *gamma, const float *beta, const float *w2, const float *b2,
+                                           const float *residual, int res_splits, const float *res_bias, float *y, int N,
+                                           int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, int uD,
+                                           int uH, int uW, void *stream) {
+    MPHIP_REQUIRE(x && stats && gamma && beta && y, "groupnorm_apply_split: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && G > 0 && C % G == 0, "groupnorm_apply_split: bad dims");
+    MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_apply_split: w2/b2 must both be set or both NULL");
+    MPHIP_REQUIRE(x_splits >= 1 && res_splits >= 1 && uD >= 1 && uH >= 1 && uW >= 1, "groupnorm_apply_split: bad split/up");
+    MPHIP_REQUIRE(!(pool2 && (uD * uH * uW != 1)), "groupnorm_apply_split: pool2 and upsampling are exclusive");
+    MPHIP_REQUIRE(!pool2 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "groupnorm_apply_split: pool2 needs even D,H,W");
+    GnSplitParams q{{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_}, x_splits, res_splits,
+                    (size_t)N * C * D * H * W, x_bias, res_bias, D, H, W, pool2, uD, uH, uW};
+    size_t total = pool2 ? (size_t)N * C * (D / 2) * (H / 2) * (W / 2) : (size_t)N * C * D * uD * H * uH * W * uW;
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, q, total);
+    return check_launch("groupnorm_apply_split");
+}
+
 extern "C" int mphip_avgpool2(const float *x, float *y, int NC, int D, int H, int W, void *stream) {
     MPHIP_REQUIRE(x && y, "avgpool2: null pointer");
     MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0,
@@ -470,8 +647,8 @@ extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D
         const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
         const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
         const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
-        hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 4, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D,
-                           H, W, sD, sH, sW, total / 4);
+        hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 16, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D,
+                           H, W, sD, sH, sW, total / 16);
     } else {
         hipLaunchKernelGGL(upsample_trilinear2_scalar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                            D, H, W, total);

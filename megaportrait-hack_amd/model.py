@@ -98,16 +98,19 @@ class ResBlock3D_Adaptive(nn.Module):
         else:
             self.residual_conv = nn.Identity()
 
-    def forward(self, x):
+    def forward(self, x, _up=(1, 1, 1)):
+        """`_up`: nearest-upsample factors fused into the block's last elementwise pass (FlowField's nn.Upsample)."""
         _no_autograd(x, module=self)
         n1, n2 = self.norm1, self.norm2
-        y, st = ops.conv3d(x, _packs.get(self.conv1), gn_groups=n1.num_groups, gn_eps=n1.group_norm.eps)
+        y = ops.conv3d_split(x, _packs.get(self.conv1))  # split-K slabs are summed by the GN kernels below
+        st = ops.groupnorm_stats(y, n1.num_groups, n1.group_norm.eps)
         a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
                                 b2=n1.bias, relu=True)
-        y, st = ops.conv3d(a, _packs.get(self.conv2), gn_groups=n2.num_groups, gn_eps=n2.group_norm.eps)
-        res = x if isinstance(self.residual_conv, nn.Identity) else ops.conv3d(x, _packs.get(self.residual_conv))
+        y = ops.conv3d_split(a, _packs.get(self.conv2))
+        st = ops.groupnorm_stats(y, n2.num_groups, n2.group_norm.eps)
+        res = x if isinstance(self.residual_conv, nn.Identity) else ops.conv3d_split(x, _packs.get(self.residual_conv))
         return ops.groupnorm_apply(y, st, n2.group_norm.weight, n2.group_norm.bias, n2.num_groups, w2=n2.weight,
-                                   b2=n2.bias, residual=res, relu=True)
+                                   b2=n2.bias, residual=res, relu=True, up=_up)
 
 
 class FlowField(nn.Module):
@@ -138,8 +141,9 @@ class FlowField(nn.Module):
         x = ops.add_matmul(s, None, w.reshape(2048, 512), self.conv1x1.bias, trans=True)
         x = x.view(b, 512, 4, 1, 1)  # model.py:425: channel c*4+d -> (c,d)
         for blk, up in zip((self.resblock1, self.resblock2, self.resblock3, self.resblock4), self._UPS):
-            x = ops.upsample_nearest(blk(x), up)
-        x, st = ops.conv3d(x, _packs.get(self.conv3x3x3), gn_groups=1, gn_eps=self.gn.eps)
+            x = blk(x, _up=up)  # nn.Upsample (nearest, model.py:450-457) fused into the block's last pass
+        x = ops.conv3d_split(x, _packs.get(self.conv3x3x3))
+        st = ops.groupnorm_stats(x, 1, self.gn.eps)
         x = ops.groupnorm_apply(x, st, self.gn.weight, self.gn.bias, 1, relu=True, tanh=True)
         assert x.shape[1] == 3, f"Expected 3 channels after conv3x3x3, got {x.shape[1]}"
         return x
@@ -195,10 +199,12 @@ class ResBlock3D(nn.Module):
 
     def forward(self, x, _pool_after: bool = False):
         _no_autograd(x, module=self)
-        identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d(x, _packs.get(self.shortcut))
-        y, st = ops.conv3d(x, _packs.get(self.conv1), gn_groups=32, gn_eps=self.gn1.eps)
+        identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d_split(x, _packs.get(self.shortcut))
+        y = ops.conv3d_split(x, _packs.get(self.conv1))
+        st = ops.groupnorm_stats(y, 32, self.gn1.eps)
         a = ops.groupnorm_apply(y, st, self.gn1.weight, self.gn1.bias, 32, relu=True)
-        y, st = ops.conv3d(a, _packs.get(self.conv2), gn_groups=32, gn_eps=self.gn2.eps)
+        y = ops.conv3d_split(a, _packs.get(self.conv2))
+        st = ops.groupnorm_stats(y, 32, self.gn2.eps)
         return ops.groupnorm_apply(y, st, self.gn2.weight, self.gn2.bias, 32, residual=identity, relu=True,
                                    pool2=_pool_after)
 
@@ -288,9 +294,11 @@ class GbaseHotSlice(nn.Module):
         side = self._side_stream(main) if self.overlap_generators else None
         if side is not None:
             side.wait_stream(main)  # inputs produced on the main stream are visible
+        # critical path first: the host issues S2C's launches before it spends time on the side stream's
+        w_s2c = self.warp_generator_s2c(Rs, ts, zs, es)
+        if side is not None:
             with torch.cuda.stream(side):
                 w_c2d = self.warp_generator_c2d(Rd, td, zd, es)
-        w_s2c = self.warp_generator_s2c(Rs, ts, zs, es)
         vc = apply_warping_field(vs, w_s2c)
         if check_shape:
             assert vc.shape[1:] == (96, 16, 64, 64), f"Expected vc shape (_, 96, 16, 64, 64), got {vc.shape}"

@@ -255,13 +255,75 @@ def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_
     return (y, stats) if gn_groups else y
 
 
+class ConvOut:
+    """A conv result that may still be in split-K form: `data` is [splits, N, Co, D, H, W] partial slabs (bias
+    not added, passed on in `bias`) when splits > 1, or the finished [N, Co, D, H, W] tensor when splits == 1."""
+
+    __slots__ = ("data", "splits", "bias", "shape")
+
+    def __init__(self, data, splits, bias, shape):
+        self.data, self.splits, self.bias, self.shape = data, splits, bias, shape
+
+
+def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None) -> ConvOut:
+    """Conv whose split-K reduction (small volumes) is left to the GroupNorm kernels that consume it."""
+    x = _req(x, "x")
+    if x.dim() != 5 or x.shape[1] != pc.ci:
+        raise RuntimeError(f"conv3d: input {tuple(x.shape)} does not match Ci={pc.ci}")
+    n, ci, d, h, w = x.shape
+    lib = _lib.load()
+    prec = _default_precision if precision is None else precision
+    if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc.co, d, h, w, pc.k, prec):
+        prec = 0
+    splits = lib.mphip_conv3d_splits(n, ci, pc.co, d, h, w, pc.k, prec)
+    shape = (n, pc.co, d, h, w)
+    if splits > 1 and n * pc.co * d * h * w > _SPLIT_CHAIN_MAX_ELEMS:
+        # mid-sized tensors (G3d's inner levels): the dedicated reduce + vectorised GN kernels are faster than the
+        # one-thread-per-element split-aware kernels (measured: -13 % end to end when those were used everywhere)
+        return ConvOut(conv3d(x, pc, precision=prec), 1, None, shape)
+    out = torch.empty((splits,) + shape if splits > 1 else shape, dtype=torch.float32, device=x.device)
+    wp = pc.packed(prec)
+
+    def launch():
+        _lib.check(lib.mphip_conv3d_fwd_split(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(out), n, ci, pc.co, d, h, w, pc.k, prec,
+                                              _stream()), "mphip_conv3d_fwd_split")
+        return out
+
+    if _conv_hook is not None:
+        _conv_hook(x, pc, launch)
+    else:
+        launch()
+    return ConvOut(out, splits, pc.bias if splits > 1 else None, shape)
+
+
+_SPLIT_CHAIN_MAX_ELEMS = 1 << 18  # conv outputs up to 1 MB keep their split-K slabs for the GN kernels (FlowField)
+_STATS_SPLIT_MAX_SPAN = 65536  # floats per (sample, group) the single-launch split-aware statistics kernel accepts
+
+
+def _finish(co: ConvOut) -> torch.Tensor:
+    """Plain tensor from a ConvOut (sums the slabs with torch when a consumer needs the finished tensor)."""
+    if co.splits == 1:
+        return co.data
+    y = co.data.sum(dim=0)
+    return y if co.bias is None else y + co.bias.view(1, -1, 1, 1, 1)
+
+
 # ------------------------------------------------------------------ K6
-def groupnorm_stats(x: torch.Tensor, groups: int, eps: float = 1e-5) -> torch.Tensor:
+def groupnorm_stats(x, groups: int, eps: float = 1e-5) -> torch.Tensor:
+    lib = _lib.load()
+    if isinstance(x, ConvOut):
+        n, c, d, h, w = x.shape
+        s = d * h * w
+        if x.splits > 1 and (c // groups) * s <= _STATS_SPLIT_MAX_SPAN:
+            stats = torch.empty((n * groups, 2), dtype=torch.float32, device=x.data.device)
+            _lib.check(lib.mphip_groupnorm_stats_split(_ptr(x.data), x.splits, _ptr(x.bias), _ptr(stats), n, c, s, groups, eps,
+                                                       _stream()), "mphip_groupnorm_stats_split")
+            return stats
+        x = _finish(x)
     x = _req(x, "x")
     n, c = x.shape[0], x.shape[1]
     s = x.numel() // (n * c)
     stats = torch.empty((n * groups, 2), dtype=torch.float32, device=x.device)
-    lib = _lib.load()
     ws_bytes = lib.mphip_groupnorm_workspace_bytes(n, c, s, groups)
     if ws_bytes == 0:
         raise RuntimeError(f"groupnorm_stats: bad dims C={c} G={groups}")
@@ -272,24 +334,44 @@ def groupnorm_stats(x: torch.Tensor, groups: int, eps: float = 1e-5) -> torch.Te
 
 
 def groupnorm_apply(x, stats, gamma, beta, groups: int, w2=None, b2=None, residual=None, relu=False, tanh=False,
-                    pool2=False) -> torch.Tensor:
-    x = _req(x, "x")
-    if x.dim() != 5:
+                    pool2=False, up=(1, 1, 1)) -> torch.Tensor:
+    """GroupNorm apply (+second affine, +residual, +ReLU, +tanh, then 2x2x2 average pool or nearest upsample).
+    `x` / `residual` may be ConvOut objects still in split-K form."""
+    lib = _lib.load()
+    xs = x.splits if isinstance(x, ConvOut) else 1
+    rs = residual.splits if isinstance(residual, ConvOut) else 1
+    xt = x.data if isinstance(x, ConvOut) else x
+    rt = residual.data if isinstance(residual, ConvOut) else residual
+    shape = x.shape if isinstance(x, ConvOut) else tuple(x.shape)
+    if len(shape) != 5:
         raise RuntimeError("groupnorm_apply: expected a 5-D NCDHW tensor")
-    n, c, d, h, w = x.shape
+    n, c, d, h, w = shape
+    xt = _req(xt, "x")
     gamma, beta = _req(gamma.detach(), "gamma"), _req(beta.detach(), "beta")
     if w2 is not None:
         w2, b2 = _req(w2.detach(), "w2").reshape(-1), _req(b2.detach(), "b2").reshape(-1)
-    if residual is not None:
-        residual = _req(residual, "residual")
-        if residual.shape != x.shape:
+    if rt is not None:
+        rt = _req(rt, "residual")
+        rshape = residual.shape if isinstance(residual, ConvOut) else tuple(residual.shape)
+        if tuple(rshape) != tuple(shape):
             raise RuntimeError("groupnorm_apply: residual shape mismatch")
-    oshape = (n, c, d // 2, h // 2, w // 2) if pool2 else (n, c, d, h, w)
-    y = torch.empty(oshape, dtype=torch.float32, device=x.device)
-    lib = _lib.load()
-    _lib.check(lib.mphip_groupnorm_apply(_ptr(x), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(residual),
-                                         _ptr(y), n, c, d, h, w, groups, int(relu), int(tanh), int(pool2), _stream()),
-               "mphip_groupnorm_apply")
+    up = tuple(int(u) for u in up)
+    general = xs > 1 or rs > 1 or up != (1, 1, 1)
+    if pool2:
+        oshape = (n, c, d // 2, h // 2, w // 2)
+    else:
+        oshape = (n, c, d * up[0], h * up[1], w * up[2])
+    y = torch.empty(oshape, dtype=torch.float32, device=xt.device)
+    if general:
+        xb = x.bias if isinstance(x, ConvOut) else None
+        rb = residual.bias if isinstance(residual, ConvOut) else None
+        _lib.check(lib.mphip_groupnorm_apply_split(_ptr(xt), xs, _ptr(xb), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2),
+                                                   _ptr(rt), rs, _ptr(rb), _ptr(y), n, c, d, h, w, groups, int(relu), int(tanh),
+                                                   int(pool2), up[0], up[1], up[2], _stream()), "mphip_groupnorm_apply_split")
+    else:
+        _lib.check(lib.mphip_groupnorm_apply(_ptr(xt), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(rt),
+                                             _ptr(y), n, c, d, h, w, groups, int(relu), int(tanh), int(pool2), _stream()),
+                   "mphip_groupnorm_apply")
     return y
 
 
