@@ -148,6 +148,15 @@ int mphip_groupnorm_apply_split(const float *x, int x_splits, const float *x_bia
                                 int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, int uD, int uH,
                                 int uW, void *stream);
 
+/* statistics + apply in ONE launch for tiny tensors (a (sample, group) span of <= 12288 floats: every FlowField
+ * layer): one workgroup per (sample, group), values cached in LDS between the two passes.  Same arguments
+ * as the split-aware pair; stats_out (optional) receives (mean, rstd).                                   */
+int mphip_groupnorm_small_fused(const float *x, int x_splits, const float *x_bias, const float *gamma,
+                                const float *beta, const float *w2, const float *b2, const float *residual,
+                                int res_splits, const float *res_bias, float *y, float *stats_out, int N, int C,
+                                int D, int H, int W, int G, float eps, int relu, int tanh_, int uD, int uH, int uW,
+                                void *stream);
+
 /* ------------------------------------------------------------------ K7  resampling
  * avgpool2:            nn.AvgPool3d(2,2)                                   (model.py:576-580)
  * upsample_trilinear2: nn.Upsample(scale_factor=2,'trilinear',align_corners=True) (:585-589)

@@ -39,6 +39,7 @@ SIGNATURES = {
     "mphip_conv3d_fwd_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mphip_groupnorm_stats_split": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, ctypes.c_float, _p]),
     "mphip_groupnorm_apply_split": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p] + [_i] * 12 + [_p]),
+    "mphip_groupnorm_small_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 6 + [ctypes.c_float] + [_i] * 5 + [_p]),
     "mphip_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_groupnorm_stats": (_i, [_p, _p, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
     "mphip_groupnorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),

@@ -297,6 +297,80 @@ __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, si
     }
 }
 
+// Tiny tensors (FlowField: a (sample, group) span of <= GN_FUSED_MAX floats): statistics AND apply in one
+// launch, one workgroup per (sample, group).  Pass 1 sums the split-K slabs (+bias) into LDS and reduces
+// sum / sum-of-squares; pass 2 normalises from LDS, adds the (possibly split) residual, applies ReLU / tanh and
+// writes every nearest-upsampled copy.  Same arithmetic as gn_stats_split_kernel + gn_apply_split_kernel.
+constexpr int GN_FUSED_MAX = 12288;  // floats of LDS cache (48 KB)
+__global__ void __launch_bounds__(256) gn_small_fused_kernel(GnSplitParams q, float eps, float *__restrict__ stats_out) {
+    __shared__ float vals[GN_FUSED_MAX];
+    __shared__ double red[8];
+    __shared__ float mr[2];
+    const GnParams &p = q.p;
+    const int grp = blockIdx.x;
+    const int S = q.D * q.H * q.W;
+    const int cnt = p.cpg * S;
+    const size_t base = (size_t)grp * cnt;
+    const int c0 = (int)((base / S) % (size_t)p.C);
+    const int shift = (S & (S - 1)) == 0 ? __ffs(S) - 1 : -1;  // S is a power of two on every hot-path layer
+    float s = 0.0f, ss = 0.0f;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int c = shift >= 0 ? (e >> shift) : e / S;
+        float v = p.x[base + e];
+        for (int z = 1; z < q.x_splits; ++z) v += p.x[(size_t)z * q.slab + base + e];
+        if (q.x_splits > 1 && q.x_bias) v += q.x_bias[c0 + c];
+        vals[e] = v;
+        s += v;
+        ss += v * v;
+    }
+    double ds = wave_sum((double)s), dss = wave_sum((double)ss);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = ds;
+        red[wave * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = (red[0] + red[2]) + (red[4] + red[6]);
+        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        double mean = a / (double)cnt;
+        double var = b / (double)cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[0] = (float)mean;
+        mr[1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (stats_out) {
+            stats_out[grp * 2] = mr[0];
+            stats_out[grp * 2 + 1] = mr[1];
+        }
+    }
+    __syncthreads();
+    const float mean = mr[0], rstd = mr[1];
+    const bool has2 = p.w2 != nullptr, has_res = p.residual != nullptr;
+    const int HW = q.H * q.W;
+    const int oH = q.H * q.uH, oW = q.W * q.uW, oD = q.D * q.uD;
+    const size_t oS = (size_t)oD * oH * oW;
+    const int n_c0 = (int)(base / S);  // global (n*C + c) index of the group's first channel plane
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+        const int c = shift >= 0 ? (e >> shift) : e / S;
+        const int i = e - c * S;
+        const int ch = c0 + c;
+        float rv = 0.0f;
+        if (has_res) {
+            rv = p.residual[base + e];
+            for (int z = 1; z < q.res_splits; ++z) rv += p.residual[(size_t)z * q.slab + base + e];
+            if (q.res_splits > 1 && q.res_bias) rv += q.res_bias[ch];
+        }
+        const float v = gn_value(p, vals[e], mean, rstd, p.gamma[ch], p.beta[ch], has2 ? p.w2[ch] : 1.0f,
+                                 has2 ? p.b2[ch] : 0.0f, has2, rv, has_res);
+        const int d = i / HW, h = (i / q.W) % q.H, w = i % q.W;
+        float *dst = p.y + (size_t)(n_c0 + c) * oS;
+        for (int a = 0; a < q.uD; ++a)
+            for (int b = 0; b < q.uH; ++b)
+                for (int cc = 0; cc < q.uW; ++cc)
+                    dst[((size_t)(d * q.uD + a) * oH + h * q.uH + b) * oW + w * q.uW + cc] = v;
+    }
+}
+
 __global__ void __launch_bounds__(256) avgpool2_kernel(const float *__restrict__ x, float *__restrict__ y, int D,
                                                        int H, int W, size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -627,6 +701,23 @@ extern "C" int mphip_groupnorm_apply_split(const float *x, int x_splits, const f
     size_t total = pool2 ? (size_t)N * C * (D / 2) * (H / 2) * (W / 2) : (size_t)N * C * D * uD * H * uH * W * uW;
     hipLaunchKernelGGL(gn_apply_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, q, total);
     return check_launch("groupnorm_apply_split");
+}
+
+extern "C" int mphip_groupnorm_small_fused(const float *x, int x_splits, const float *x_bias, const float *gamma,
+                                          const float *beta, const float *w2, const float *b2, const float *residual,
+                                          int res_splits, const float *res_bias, float *y, float *stats_out, int N, int C,
+                                          int D, int H, int W, int G, float eps, int relu, int tanh_, int uD, int uH, int uW,
+                                          void *stream) {
+    MPHIP_REQUIRE(x && gamma && beta && y, "groupnorm_small_fused: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && G > 0 && C % G == 0, "groupnorm_small_fused: bad dims");
+    MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_small_fused: w2/b2 must both be set or both NULL");
+    MPHIP_REQUIRE(x_splits >= 1 && res_splits >= 1 && uD >= 1 && uH >= 1 && uW >= 1, "groupnorm_small_fused: bad split/up");
+    MPHIP_REQUIRE((size_t)(C / G) * D * H * W <= (size_t)GN_FUSED_MAX,
+                  "groupnorm_small_fused: (sample, group) span %zu exceeds %d floats", (size_t)(C / G) * D * H * W, GN_FUSED_MAX);
+    GnSplitParams q{{x, nullptr, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_}, x_splits, res_splits,
+                    (size_t)N * C * D * H * W, x_bias, res_bias, D, H, W, 0, uD, uH, uW};
+    hipLaunchKernelGGL(gn_small_fused_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, q, eps, stats_out);
+    return check_launch("groupnorm_small_fused");
 }
 
 extern "C" int mphip_avgpool2(const float *x, float *y, int NC, int D, int H, int W, void *stream) {

@@ -103,12 +103,20 @@ class ResBlock3D_Adaptive(nn.Module):
         _no_autograd(x, module=self)
         n1, n2 = self.norm1, self.norm2
         y = ops.conv3d_split(x, _packs.get(self.conv1))  # split-K slabs are summed by the GN kernels below
-        st = ops.groupnorm_stats(y, n1.num_groups, n1.group_norm.eps)
-        a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
-                                b2=n1.bias, relu=True)
+        tiny = ops.groupnorm_fused_ok(y, n1.num_groups)  # FlowField: statistics + apply in one launch
+        if tiny:
+            a = ops.groupnorm_small(y, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, n1.group_norm.eps,
+                                    w2=n1.weight, b2=n1.bias, relu=True)
+        else:
+            st = ops.groupnorm_stats(y, n1.num_groups, n1.group_norm.eps)
+            a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
+                                    b2=n1.bias, relu=True)
         y = ops.conv3d_split(a, _packs.get(self.conv2))
-        st = ops.groupnorm_stats(y, n2.num_groups, n2.group_norm.eps)
         res = x if isinstance(self.residual_conv, nn.Identity) else ops.conv3d_split(x, _packs.get(self.residual_conv))
+        if tiny:
+            return ops.groupnorm_small(y, n2.group_norm.weight, n2.group_norm.bias, n2.num_groups, n2.group_norm.eps,
+                                       w2=n2.weight, b2=n2.bias, residual=res, relu=True, up=_up)
+        st = ops.groupnorm_stats(y, n2.num_groups, n2.group_norm.eps)
         return ops.groupnorm_apply(y, st, n2.group_norm.weight, n2.group_norm.bias, n2.num_groups, w2=n2.weight,
                                    b2=n2.bias, residual=res, relu=True, up=_up)
 
@@ -143,8 +151,11 @@ class FlowField(nn.Module):
         for blk, up in zip((self.resblock1, self.resblock2, self.resblock3, self.resblock4), self._UPS):
             x = blk(x, _up=up)  # nn.Upsample (nearest, model.py:450-457) fused into the block's last pass
         x = ops.conv3d_split(x, _packs.get(self.conv3x3x3))
-        st = ops.groupnorm_stats(x, 1, self.gn.eps)
-        x = ops.groupnorm_apply(x, st, self.gn.weight, self.gn.bias, 1, relu=True, tanh=True)
+        if ops.groupnorm_fused_ok(x, 1):
+            x = ops.groupnorm_small(x, self.gn.weight, self.gn.bias, 1, self.gn.eps, relu=True, tanh=True)
+        else:
+            st = ops.groupnorm_stats(x, 1, self.gn.eps)
+            x = ops.groupnorm_apply(x, st, self.gn.weight, self.gn.bias, 1, relu=True, tanh=True)
         assert x.shape[1] == 3, f"Expected 3 channels after conv3x3x3, got {x.shape[1]}"
         return x
 

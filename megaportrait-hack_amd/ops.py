@@ -375,6 +375,46 @@ def groupnorm_apply(x, stats, gamma, beta, groups: int, w2=None, b2=None, residu
     return y
 
 
+_GN_FUSED_MAX_SPAN = 12288  # floats per (sample, group): LDS cache of the one-launch GroupNorm
+
+
+_GN_SMALL_ENABLED = _os.environ.get("MPHIP_GN_SMALL", "1") != "0"  # dev switch for same-box A/B runs
+
+
+def groupnorm_fused_ok(x, groups: int) -> bool:
+    if not _GN_SMALL_ENABLED:
+        return False
+    shape = x.shape if isinstance(x, ConvOut) else tuple(x.shape)
+    n, c, d, h, w = shape
+    return (c // groups) * d * h * w <= _GN_FUSED_MAX_SPAN
+
+
+def groupnorm_small(x, gamma, beta, groups: int, eps: float = 1e-5, w2=None, b2=None, residual=None, relu=False,
+                    tanh=False, up=(1, 1, 1)) -> torch.Tensor:
+    """GroupNorm statistics + apply (+second affine, residual, ReLU, tanh, nearest upsample) in one launch for tiny
+    tensors; `x` / `residual` may be split-K ConvOut objects."""
+    lib = _lib.load()
+    xs = x.splits if isinstance(x, ConvOut) else 1
+    rs = residual.splits if isinstance(residual, ConvOut) else 1
+    xt = _req(x.data if isinstance(x, ConvOut) else x, "x")
+    rt = residual.data if isinstance(residual, ConvOut) else residual
+    shape = x.shape if isinstance(x, ConvOut) else tuple(x.shape)
+    n, c, d, h, w = shape
+    gamma, beta = _req(gamma.detach(), "gamma"), _req(beta.detach(), "beta")
+    if w2 is not None:
+        w2, b2 = _req(w2.detach(), "w2").reshape(-1), _req(b2.detach(), "b2").reshape(-1)
+    if rt is not None:
+        rt = _req(rt, "residual")
+    xb = x.bias if isinstance(x, ConvOut) else None
+    rb = residual.bias if isinstance(residual, ConvOut) else None
+    up = tuple(int(u) for u in up)
+    y = torch.empty((n, c, d * up[0], h * up[1], w * up[2]), dtype=torch.float32, device=xt.device)
+    _lib.check(lib.mphip_groupnorm_small_fused(_ptr(xt), xs, _ptr(xb), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(rt), rs,
+                                               _ptr(rb), _ptr(y), None, n, c, d, h, w, groups, eps, int(relu), int(tanh), up[0],
+                                               up[1], up[2], _stream()), "mphip_groupnorm_small_fused")
+    return y
+
+
 # ------------------------------------------------------------------ K7
 def avgpool2(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")
