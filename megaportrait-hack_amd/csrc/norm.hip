@@ -518,7 +518,7 @@ __global__ void __launch_bounds__(256) upsample_nearest_kernel(const float *__re
 }
 
 // out[b,n] = sum_k (a[b,k]+a2[b,k]) * M(k,n) + bias[n];  M(k,n) = m[k*N+n] (trans=0) or m[n*K+k] (trans=1).
-// One wave per output column n, all B rows at once (B <= 16 per pass) so the matrix streams once.
+// trans=1 (row-major [N][K], the Conv2d weight layout): one wave per output column n, lanes stride over k.
 template <bool TRANS>
 __global__ void __launch_bounds__(256)
 add_matmul_kernel(const float *__restrict__ a, const float *__restrict__ a2, const float *__restrict__ m,
@@ -549,6 +549,52 @@ add_matmul_kernel(const float *__restrict__ a, const float *__restrict__ a2, con
             for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
             if (lane == 0 && b0 + i < B) out[(size_t)(b0 + i) * N + n] = v + (bias ? bias[n] : 0.0f);
         }
+    }
+}
+
+// trans=0 fast path ([K][N] matrix, N contiguous): a workgroup of 16 waves owns 64 output columns (one per
+// lane, coalesced 256-byte row reads); each wave covers K/16 rows with the (a+a2) rows broadcast from LDS,
+// and the 16 partial sums per output are combined through LDS in wave order (deterministic).
+constexpr int MM_WAVES = 16, MM_BMAX = 8, MM_KMAX = 1024;
+__global__ void __launch_bounds__(MM_WAVES * 64)
+add_matmul_kn_kernel(const float *__restrict__ a, const float *__restrict__ a2, const float *__restrict__ m,
+                     const float *__restrict__ bias, float *__restrict__ out, int B, int K, int N, int b0) {
+    __shared__ float as[MM_BMAX * MM_KMAX];
+    __shared__ float part[MM_WAVES][MM_BMAX][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = min(MM_BMAX, B - b0);
+    for (int i = threadIdx.x; i < nb * K; i += MM_WAVES * 64) {
+        const int bb = i / K, k = i - bb * K;
+        float v = a[(size_t)(b0 + bb) * K + k];
+        if (a2) v += a2[(size_t)(b0 + bb) * K + k];
+        as[bb * MM_KMAX + k] = v;
+    }
+    __syncthreads();
+    const int n = blockIdx.x * 64 + lane;
+    const int kper = (K + MM_WAVES - 1) / MM_WAVES;
+    const int k0 = wave * kper, k1 = min(K, k0 + kper);
+    float acc[MM_BMAX];
+#pragma unroll
+    for (int i = 0; i < MM_BMAX; ++i) acc[i] = 0.0f;
+    if (n < N) {
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) {
+            const float mv = m[(size_t)k * N + n];
+#pragma unroll
+            for (int i = 0; i < MM_BMAX; ++i) acc[i] = fmaf(as[i * MM_KMAX + k], mv, acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MM_BMAX; ++i) part[wave][i][lane] = acc[i];
+    __syncthreads();
+    for (int o = threadIdx.x; o < nb * 64; o += MM_WAVES * 64) {
+        const int bb = o >> 6, l = o & 63;
+        const int nn = blockIdx.x * 64 + l;
+        if (nn >= N) continue;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < MM_WAVES; ++w) v += part[w][bb][l];
+        out[(size_t)(b0 + bb) * N + nn] = v + (bias ? bias[nn] : 0.0f);
     }
 }
 
@@ -762,9 +808,14 @@ extern "C" int mphip_add_matmul(const float *a, const float *a2, const float *m,
     MPHIP_REQUIRE(a && m && out, "add_matmul: null pointer");
     MPHIP_REQUIRE(B > 0 && K > 0 && N > 0, "add_matmul: bad dims");
     dim3 grid(cdiv(N, 4));
-    if (trans)
+    if (trans) {
         hipLaunchKernelGGL(add_matmul_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, a2, m, bias, out, B, K, N);
-    else
+    } else if (K <= MM_KMAX) {
+        for (int b0 = 0; b0 < B; b0 += MM_BMAX)
+            hipLaunchKernelGGL(add_matmul_kn_kernel, dim3(cdiv(N, 64)), dim3(MM_WAVES * 64), 0, (hipStream_t)stream, a, a2, m,
+                               bias, out, B, K, N, b0);
+    } else {
         hipLaunchKernelGGL(add_matmul_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, a2, m, bias, out, B, K, N);
+    }
     return check_launch("add_matmul");
 }

@@ -141,12 +141,22 @@ class FlowField(nn.Module):
         self.gn = nn.GroupNorm(1, 3)
         self.tanh = nn.Tanh()
 
+    def _conv1x1_kn(self):
+        """conv1x1.weight [2048,512,1,1] re-laid as [K=512][N=2048] (N contiguous) for the coalesced matmul kernel;
+        rebuilt when the parameter changes."""
+        w = self.conv1x1.weight
+        key = (w.data_ptr(), w._version, str(w.device))
+        hit = self.__dict__.get("_w_kn")
+        if hit is None or hit[0] != key:
+            hit = (key, w.detach().reshape(2048, 512).t().contiguous())
+            self.__dict__["_w_kn"] = hit
+        return hit[1]
+
     def forward(self, zs, adaptive_gamma=0, adaptive_beta=0):  # last two ignored, as in the reference
         _no_autograd(zs, module=self)
         b = zs.shape[0]
         s = zs.reshape(b, 512)
-        w = self.conv1x1.weight
-        x = ops.add_matmul(s, None, w.reshape(2048, 512), self.conv1x1.bias, trans=True)
+        x = ops.add_matmul(s, None, self._conv1x1_kn(), self.conv1x1.bias)  # 1x1 conv on a 1x1 map == s @ W^T + b
         x = x.view(b, 512, 4, 1, 1)  # model.py:425: channel c*4+d -> (c,d)
         for blk, up in zip((self.resblock1, self.resblock2, self.resblock3, self.resblock4), self._UPS):
             x = blk(x, _up=up)  # nn.Upsample (nearest, model.py:450-457) fused into the block's last pass
