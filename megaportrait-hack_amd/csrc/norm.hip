@@ -302,10 +302,11 @@ __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, si
 // sum / sum-of-squares; pass 2 normalises from LDS, adds the (possibly split) residual, applies ReLU / tanh and
 // writes every nearest-upsampled copy.  Same arithmetic as gn_stats_split_kernel + gn_apply_split_kernel.
 constexpr int GN_FUSED_MAX = 12288;  // floats of LDS cache (48 KB)
-__global__ void __launch_bounds__(256) gn_small_fused_kernel(GnSplitParams q, float eps, float *__restrict__ stats_out) {
+__global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, float eps, float *__restrict__ stats_out) {
     __shared__ float vals[GN_FUSED_MAX];
-    __shared__ double red[8];
+    __shared__ double red[32];
     __shared__ float mr[2];
+    const int nthr = blockDim.x, nwaves = blockDim.x >> 6;  // 256 threads, or 1024 when only a few groups exist
     const GnParams &p = q.p;
     const int grp = blockIdx.x;
     const int S = q.D * q.H * q.W;
@@ -314,7 +315,7 @@ __global__ void __launch_bounds__(256) gn_small_fused_kernel(GnSplitParams q, fl
     const int c0 = (int)((base / S) % (size_t)p.C);
     const int shift = (S & (S - 1)) == 0 ? __ffs(S) - 1 : -1;  // S is a power of two on every hot-path layer
     float s = 0.0f, ss = 0.0f;
-    for (int e = threadIdx.x; e < cnt; e += 256) {
+    for (int e = threadIdx.x; e < cnt; e += nthr) {
         const int c = shift >= 0 ? (e >> shift) : e / S;
         float v = p.x[base + e];
         for (int z = 1; z < q.x_splits; ++z) v += p.x[(size_t)z * q.slab + base + e];
@@ -331,8 +332,11 @@ __global__ void __launch_bounds__(256) gn_small_fused_kernel(GnSplitParams q, fl
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = (red[0] + red[2]) + (red[4] + red[6]);
-        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        double a = 0.0, b = 0.0;
+        for (int wv = 0; wv < nwaves; ++wv) {
+            a += red[wv * 2];
+            b += red[wv * 2 + 1];
+        }
         double mean = a / (double)cnt;
         double var = b / (double)cnt - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -350,7 +354,7 @@ __global__ void __launch_bounds__(256) gn_small_fused_kernel(GnSplitParams q, fl
     const int oH = q.H * q.uH, oW = q.W * q.uW, oD = q.D * q.uD;
     const size_t oS = (size_t)oD * oH * oW;
     const int n_c0 = (int)(base / S);  // global (n*C + c) index of the group's first channel plane
-    for (int e = threadIdx.x; e < cnt; e += 256) {
+    for (int e = threadIdx.x; e < cnt; e += nthr) {
         const int c = shift >= 0 ? (e >> shift) : e / S;
         const int i = e - c * S;
         const int ch = c0 + c;
@@ -762,7 +766,8 @@ extern "C" int mphip_groupnorm_small_fused(const float *x, int x_splits, const f
                   "groupnorm_small_fused: (sample, group) span %zu exceeds %d floats", (size_t)(C / G) * D * H * W, GN_FUSED_MAX);
     GnSplitParams q{{x, nullptr, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_}, x_splits, res_splits,
                     (size_t)N * C * D * H * W, x_bias, res_bias, D, H, W, 0, uD, uH, uW};
-    hipLaunchKernelGGL(gn_small_fused_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, q, eps, stats_out);
+    const int threads = (N * G < 64 && (size_t)(C / G) * D * H * W >= 4096) ? 1024 : 256;
+    hipLaunchKernelGGL(gn_small_fused_kernel, dim3(N * G), dim3(threads), 0, (hipStream_t)stream, q, eps, stats_out);
     return check_launch("groupnorm_small_fused");
 }
 
