@@ -110,6 +110,17 @@ int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias,
                         int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups,
                         float gn_eps, void *workspace, size_t workspace_bytes, void *stream);
 
+/* GroupNorm folded into the NEXT conv (nn.GroupNorm -> ReLU -> nn.Conv3d, model.py:506-507/517/518 and
+ * 390-396): mphip_groupnorm_affine_table turns (mean, rstd) + gamma/beta (+ AdaptiveGroupNorm's w2/b2) into
+ * table[N][C][2] = (scale, shift); mphip_conv3d_gnin_fwd applies x' = x*scale + shift (then ReLU if in_relu)
+ * to every in-volume voxel while it stages its input tile (padding stays 0), so the normalised tensor is never
+ * written.  precision 1 (f16x3) only, Ci <= 768.                                                      */
+int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const float *beta, const float *w2,
+                                 const float *b2, float *table, int N, int C, int G, void *stream);
+int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+                          const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
+                          int precision, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Split-K aware chain for small volumes (G3d's 4x16x16 / 2x8x8 levels, all of FlowField): the conv leaves
  * its result as `splits` partial slabs out[z][N,Co,D,H,W] (bias NOT added) and the GroupNorm statistics /
  * apply kernels that consume it sum the slabs on the fly (z ascending + bias, the same order as the

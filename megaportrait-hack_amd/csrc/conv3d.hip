@@ -522,8 +522,8 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
     }
 }
 
-static int conv3d_run(const float *x, const void *w_packed, const float *bias, float *y, float *gn_stats, int gn_groups,
-                      float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+static int conv3d_run(const float *x, const float *in_affine, int in_relu, const void *w_packed, const float *bias, float *y,
+                      float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                       size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
@@ -534,6 +534,7 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
                   x_bytes);
     MPHIP_REQUIRE(mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision),
                   "conv3d_fwd: precision %d not available for this shape (query mphip_conv3d_supported)", precision);
+    MPHIP_REQUIRE(!in_affine || precision == 1, "conv3d_fwd: the fused input GroupNorm needs the f16x3 kernel (precision 1)");
     hipStream_t s = (hipStream_t)stream;
     ConvPlan p{};
     F16x3Plan fp{};
@@ -563,7 +564,7 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
     if (precision == 1) {
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, s);
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, s);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -593,7 +594,7 @@ static int conv3d_run(const float *x, const void *w_packed, const float *bias, f
 extern "C" int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
                                 int Co, int D, int H, int W, int k, int precision, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-    return conv3d_run(x, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, nullptr, 0, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }
 
@@ -604,7 +605,7 @@ extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, i
 
 extern "C" int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bias, float *out, int N, int Ci,
                                       int Co, int D, int H, int W, int k, int precision, void *stream) {
-    return conv3d_run(x, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, nullptr, 0, stream);
+    return conv3d_run(x, nullptr, 0, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, nullptr, 0, stream);
 }
 
 extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
@@ -619,6 +620,14 @@ extern "C" int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const f
     MPHIP_REQUIRE(gn_stats, "conv3d_gn_fwd: null stats pointer");
     MPHIP_REQUIRE(gn_groups > 0 && Co > 0 && Co % gn_groups == 0, "conv3d_gn_fwd: Co=%d not divisible into %d groups", Co,
                   gn_groups);
-    return conv3d_run(x, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, nullptr, 0, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
+}
+
+extern "C" int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+                                     const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
+                                     int precision, void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(in_affine, "conv3d_gnin_fwd: null affine table");
+    return conv3d_run(x, in_affine, in_relu, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision,
+                      workspace, workspace_bytes, stream);
 }

@@ -98,7 +98,7 @@ template <int TD, int TH, int TW, int NWAVES, int GS>
 __global__ void __launch_bounds__(NWAVES * 64)
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
-                       int chunks_per_split, unsigned x_bytes) {
+                       int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu) {
     constexpr int MT = 3, KC = F16X3_KC;
     constexpr int TVOX = TD * TH * TW;
     constexpr int NTHR = NWAVES * 64;
@@ -113,9 +113,11 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     constexpr int NGRP = F16X3_NG / GS;               // barrier intervals per chunk
     constexpr int GT = GS * F16X3_TG;                 // taps per interval
     static_assert(F16X3_NG % GS == 0, "group size");
-    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * W_BUF + 2 * X_PART];
+    constexpr int AFF_MAX_CI = 768;          // per-channel (scale, shift) of the fused input GroupNorm, kept in LDS
+    __shared__ __attribute__((aligned(16))) _Float16 smem[2 * W_BUF + 2 * X_PART + AFF_MAX_CI * 4];
     _Float16 *const Ws = smem;               // [2 buffers][part][tap][kg][co][8]
     _Float16 *const Xs = smem + 2 * W_BUF;   // [part][kg][vox][8]
+    float *const aff = reinterpret_cast<float *>(smem + 2 * W_BUF + 2 * X_PART);  // [Ci][2] (one array: see guide §5 trap (a))
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -152,6 +154,19 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         return OOB;
     };
 
+    auto x_valid = [&](int e) -> bool {
+        const int r = e % XV;
+        const int gd = d0 - 1 + r / (HH * HWp), gh = h0 - 1 + (r / HWp) % HH, gw = w0 - 1 + r % HWp;
+        return (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
+    };
+    const bool fuse_in = in_affine != nullptr;  // block-uniform
+    if (fuse_in) {
+        // the GroupNorm (+ReLU) that precedes this conv (model.py:506-507 -> 517 -> 518) is applied while the halo
+        // tile is staged: x' = relu(x*scale[n,c] + shift[n,c]) inside the volume, 0 in the padding
+        for (int i = tid; i < Ci * 2; i += NTHR) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
+        __syncthreads();
+    }
+
     float xr0[XI], xr1[XI];
 #define F16X3_LOAD_X(chunk)                                                                       \
     {                                                                                             \
@@ -164,16 +179,26 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             xr1[i] = buf_load_f(rsrc, o_ == OOB ? OOB : o_ + chan_stride, soff_);                 \
         }                                                                                         \
     }
-#define F16X3_WRITE_X()                                                                           \
+#define F16X3_WRITE_X(chunk)                                                                      \
     {                                                                                             \
         _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                          \
             const int e_ = i * NTHR + tid;                                                        \
             if (e_ < 8 * XV) {                                                                    \
                 const int p_ = e_ / XV, r_ = e_ % XV;                                             \
                 const int dst_ = (((p_ / 4) * XV + r_) * 8) + (p_ % 4) * 2;                       \
+                float v0_ = xr0[i], v1_ = xr1[i];                                                 \
+                if (fuse_in && x_valid(e_)) {                                                     \
+                    const float4 sc_ = *reinterpret_cast<const float4 *>(aff + ((chunk) * KC + 2 * p_) * 2); \
+                    v0_ = v0_ * sc_.x + sc_.y;                                                    \
+                    v1_ = v1_ * sc_.z + sc_.w;                                                    \
+                    if (in_relu) {                                                                \
+                        v0_ = fmaxf(v0_, 0.0f);                                                   \
+                        v1_ = fmaxf(v1_, 0.0f);                                                   \
+                    }                                                                             \
+                }                                                                                 \
                 _Float16 h0_, l0_, h1_, l1_;                                                      \
-                split_f16(xr0[i] * X_SCALE, h0_, l0_);                                            \
-                split_f16(xr1[i] * X_SCALE, h1_, l1_);                                            \
+                split_f16(v0_ * X_SCALE, h0_, l0_);                                               \
+                split_f16(v1_ * X_SCALE, h1_, l1_);                                               \
                 half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                        \
                 *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                     \
                 *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                            \
@@ -220,7 +245,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     // prologue: X(chunk0) -> LDS, W(chunk0, group 0) -> buffer 0
     F16X3_DMA_W(c_begin, 0, 0);
     F16X3_LOAD_X(c_begin);
-    F16X3_WRITE_X();
+    F16X3_WRITE_X(c_begin);
     __syncthreads();
 
     int wb = 0;
@@ -295,7 +320,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         }
 #ifndef MPHIP_ABL_NOX
         if (more) {
-            F16X3_WRITE_X();  // every wave is past its last read of the X tile (barrier above)
+            F16X3_WRITE_X(c + 1);  // every wave is past its last read of the X tile (barrier above)
             __syncthreads();
         }
 #endif
@@ -377,19 +402,23 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, hipStream_t s) {
 }
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, hipStream_t s) {
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, hipStream_t s) {
+    if (in_affine && Ci > 768) {
+        set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
+        return MPHIP_EINVAL;
+    }
     const float *hdr = (const float *)wpacked;
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
     if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu);
     else if (p.td == 4)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu);
     else
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu);
     return check_launch("conv3d_fwd(f16x3)");
 }
 

@@ -20,7 +20,7 @@ size_t f16x3_packed_bytes(int Co, int Ci);
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W);
 int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, hipStream_t s);
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, hipStream_t s);
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, hipStream_t s);
 
 
 // norm.hip: GroupNorm statistics of x [N,C,S] -> stats [N*G][2] (workspace sized by groupnorm_ws_bytes)

@@ -724,6 +724,35 @@ extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const f
     return check_launch("groupnorm_apply");
 }
 
+// table[n][c] = (scale, shift) with GroupNorm(+AdaptiveGroupNorm's second affine) folded to y = x*scale + shift
+__global__ void gn_affine_table_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
+                                       const float *__restrict__ beta, const float *__restrict__ w2,
+                                       const float *__restrict__ b2, float *__restrict__ table, int N, int C, int cpg) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    const int c = i % C, n = i / C;
+    const int grp = n * (C / cpg) + c / cpg;
+    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+    float scale = rstd * gamma[c];
+    float shift = beta[c] - mean * scale;
+    if (w2) {
+        scale = scale * w2[c];
+        shift = shift * w2[c] + b2[c];
+    }
+    table[i * 2] = scale;
+    table[i * 2 + 1] = shift;
+}
+
+extern "C" int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const float *beta, const float *w2,
+                                            const float *b2, float *table, int N, int C, int G, void *stream) {
+    MPHIP_REQUIRE(stats && gamma && beta && table, "groupnorm_affine_table: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_affine_table: bad dims");
+    MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_affine_table: w2/b2 must both be set or both NULL");
+    hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma,
+                       beta, w2, b2, table, N, C, C / G);
+    return check_launch("groupnorm_affine_table");
+}
+
 extern "C" int mphip_groupnorm_stats_split(const float *x, int x_splits, const float *x_bias, float *stats, int N, int C,
                                            int S, int G, float eps, void *stream) {
     MPHIP_REQUIRE(x && stats, "groupnorm_stats_split: null pointer");

@@ -107,11 +107,17 @@ class ResBlock3D_Adaptive(nn.Module):
         if tiny:
             a = ops.groupnorm_small(y, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, n1.group_norm.eps,
                                     w2=n1.weight, b2=n1.bias, relu=True)
+            y = ops.conv3d_split(a, _packs.get(self.conv2))
         else:
             st = ops.groupnorm_stats(y, n1.num_groups, n1.group_norm.eps)
-            a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
-                                    b2=n1.bias, relu=True)
-        y = ops.conv3d_split(a, _packs.get(self.conv2))
+            pc2 = _packs.get(self.conv2)
+            if y.splits == 1 and ops.gn_in_conv_ok(y.shape, pc2):  # Eapp's 3D tail: AGN1 + ReLU inside conv2's staging
+                y = ops.ConvOut(ops.conv3d_gn_in(y.data, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, pc2,
+                                                 w2=n1.weight, b2=n1.bias), 1, None, y.shape)
+            else:
+                a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
+                                        b2=n1.bias, relu=True)
+                y = ops.conv3d_split(a, pc2)
         res = x if isinstance(self.residual_conv, nn.Identity) else ops.conv3d_split(x, _packs.get(self.residual_conv))
         if tiny:
             return ops.groupnorm_small(y, n2.group_norm.weight, n2.group_norm.bias, n2.num_groups, n2.group_norm.eps,
@@ -223,8 +229,13 @@ class ResBlock3D(nn.Module):
         identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d_split(x, _packs.get(self.shortcut))
         y = ops.conv3d_split(x, _packs.get(self.conv1))
         st = ops.groupnorm_stats(y, 32, self.gn1.eps)
-        a = ops.groupnorm_apply(y, st, self.gn1.weight, self.gn1.bias, 32, relu=True)
-        y = ops.conv3d_split(a, _packs.get(self.conv2))
+        pc2 = _packs.get(self.conv2)
+        if y.splits == 1 and ops.gn_in_conv_ok(y.shape, pc2):
+            # GN1 + ReLU folded into conv2's input staging: the normalised tensor never touches HBM
+            y = ops.ConvOut(ops.conv3d_gn_in(y.data, st, self.gn1.weight, self.gn1.bias, 32, pc2), 1, None, y.shape)
+        else:
+            a = ops.groupnorm_apply(y, st, self.gn1.weight, self.gn1.bias, 32, relu=True)
+            y = ops.conv3d_split(a, pc2)
         st = ops.groupnorm_stats(y, 32, self.gn2.eps)
         return ops.groupnorm_apply(y, st, self.gn2.weight, self.gn2.bias, 32, residual=identity, relu=True,
                                    pool2=_pool_after)

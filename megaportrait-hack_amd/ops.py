@@ -255,6 +255,43 @@ def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_
     return (y, stats) if gn_groups else y
 
 
+_GNIN_ENABLED = _os.environ.get("MPHIP_GN_IN_CONV", "1") != "0"  # dev switch for same-box A/B runs
+
+
+def gn_in_conv_ok(x_shape, pc: "PackedConv") -> bool:
+    """True when `conv(relu(groupnorm(x)))` can run as ONE conv launch (f16x3 kernel with the norm folded into its
+    input staging)."""
+    if not _GNIN_ENABLED or _default_precision != 1 or pc.k != 3 or pc.ci > 768:
+        return False
+    n, ci, d, h, w = x_shape
+    return bool(_lib.load().mphip_conv3d_supported(n, ci, pc.co, d, h, w, pc.k, 1))
+
+
+def conv3d_gn_in(x: torch.Tensor, stats: torch.Tensor, gamma, beta, groups: int, pc: "PackedConv", w2=None, b2=None,
+                 relu: bool = True) -> torch.Tensor:
+    """conv(relu(GN(x))) with the normalisation applied inside the conv's input staging (mphip_conv3d_gnin_fwd)."""
+    x = _req(x, "x")
+    n, ci, d, h, w = x.shape
+    lib = _lib.load()
+    gamma, beta = _req(gamma.detach(), "gamma"), _req(beta.detach(), "beta")
+    if w2 is not None:
+        w2, b2 = _req(w2.detach(), "w2").reshape(-1), _req(b2.detach(), "b2").reshape(-1)
+    table = torch.empty((n, ci, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphip_groupnorm_affine_table(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(table), n, ci,
+                                                groups, _stream()), "mphip_groupnorm_affine_table")
+    wp = pc.packed(1)
+    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, 1)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
+    y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
+
+    def launch():
+        _lib.check(lib.mphip_conv3d_gnin_fwd(_ptr(x), _ptr(table), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h,
+                                             w, pc.k, 1, _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_gnin_fwd")
+        return y
+
+    return _conv_hook(x, pc, launch) if _conv_hook is not None else launch()
+
+
 class ConvOut:
     """A conv result that may still be in split-K form: `data` is [splits, N, Co, D, H, W] partial slabs (bias
     not added, passed on in `bias`) when splits > 1, or the finished [N, Co, D, H, W] tensor when splits == 1."""

@@ -26,7 +26,7 @@ def test_header_symbols_are_exported(lib):
 
     hdr = open(os.path.join(ROOT, "include", "mphip.h")).read()
     declared = set(re.findall(r"\b(mphip_[a-z0-9_]+)\s*\(", hdr))
-    assert len(declared) >= 25
+    assert len(declared) >= 27
     raw = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in mphip.h but not exported by libmphip.so"
