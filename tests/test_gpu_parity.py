@@ -260,6 +260,79 @@ def test_add_matmul(ops, dev):
     assert maxabs(ops.add_matmul(a.to(dev), None, w.to(dev), b.to(dev), trans=True), F.linear(a, w, b)) < 2e-5
 
 
+def test_split_aware_groupnorm_chain(ops, dev):
+    """FlowField-sized tensors: conv left in split-K form, GroupNorm kernels sum the slabs themselves
+    (stats_split / apply_split / small_fused) — all three against the plain reduce-then-normalise chain."""
+    x = R.seeded_tensor((2, 256, 8, 2, 2), 801, scale=1.7)
+    wt = R.seeded_tensor((128, 256, 3, 3, 3), 802, scale=(256 * 27) ** -0.5)
+    bias = R.seeded_tensor((128,), 803, scale=0.1)
+    res = R.seeded_tensor((2, 128, 8, 2, 2), 804)
+    g, b = R.seeded_tensor((128,), 805, scale=0.25, shift=1.0), R.seeded_tensor((128,), 806, scale=0.25)
+    w2, b2 = R.seeded_tensor((1, 128, 1, 1, 1), 807, scale=0.25, shift=1.0), R.seeded_tensor((1, 128, 1, 1, 1), 808, scale=0.25)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    co = ops.conv3d_split(x.to(dev), pc, precision=0)
+    assert co.splits > 1, "this shape is meant to exercise split-K"
+    y_ref = F.conv3d(x, wt, bias, padding=1)
+    assert maxabs(ops._finish(co), y_ref) < 2e-5
+    st = ops.groupnorm_stats(co, 32)
+    yr = y_ref.reshape(2, 32, -1).double()
+    assert maxabs(st[:, 0], yr.mean(-1).reshape(-1)) < 1e-5
+    want = F.relu(F.group_norm(y_ref, 32, g, b, 1e-5) * w2 + b2 + res)
+    args = dict(w2=w2.to(dev), b2=b2.to(dev), residual=res.to(dev), relu=True)
+    assert maxabs(ops.groupnorm_apply(co, st, g.to(dev), b.to(dev), 32, **args), want) < 2e-5
+    up = ops.groupnorm_apply(co, st, g.to(dev), b.to(dev), 32, up=(1, 2, 2), **args)
+    assert maxabs(up, F.interpolate(want, scale_factor=(1, 2, 2), mode="nearest")) < 2e-5
+    assert ops.groupnorm_fused_ok(co, 32)
+    one = ops.groupnorm_small(co, g.to(dev), b.to(dev), 32, 1e-5, up=(2, 2, 2), **args)
+    assert maxabs(one, F.interpolate(want, scale_factor=2, mode="nearest")) < 2e-5
+    # residual that is itself a split conv output (FlowField's 1x1 residual_conv)
+    w1 = R.seeded_tensor((128, 256, 1, 1, 1), 809, scale=256 ** -0.5)
+    rco = ops.conv3d_split(x.to(dev), ops.PackedConv(w1.to(dev), bias.to(dev)), precision=0)
+    want2 = F.relu(F.group_norm(y_ref, 32, g, b, 1e-5) + F.conv3d(x, w1, bias))
+    assert maxabs(ops.groupnorm_small(co, g.to(dev), b.to(dev), 32, 1e-5, residual=rco, relu=True), want2) < 2e-5
+
+
+def test_groupnorm_folded_into_conv(ops, dev):
+    """conv(relu(GN(x))) as one launch (mphip_groupnorm_affine_table + mphip_conv3d_gnin_fwd) vs the unfused ops,
+    including AdaptiveGroupNorm's second affine and the zero padding (which must stay 0, not relu(shift))."""
+    x = R.seeded_tensor((2, 96, 4, 8, 16), 811, scale=1.7) + 0.5
+    wt = R.seeded_tensor((96, 96, 3, 3, 3), 812, scale=(96 * 27) ** -0.5)
+    bias = R.seeded_tensor((96,), 813, scale=0.1)
+    g, b = R.seeded_tensor((96,), 814, scale=0.25, shift=1.0), R.seeded_tensor((96,), 815, scale=0.25, shift=0.5)
+    w2, b2 = R.seeded_tensor((1, 96, 1, 1, 1), 816, scale=0.25, shift=1.0), R.seeded_tensor((1, 96, 1, 1, 1), 817, scale=0.25)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    ops.set_conv_precision("f16x3")
+    assert ops.gn_in_conv_ok(tuple(x.shape), pc)
+    st = ops.groupnorm_stats(x.to(dev), 32)
+    got = ops.conv3d_gn_in(x.to(dev), st, g.to(dev), b.to(dev), 32, pc)
+    want = F.conv3d(F.relu(F.group_norm(x, 32, g, b, 1e-5)), wt, bias, padding=1)
+    assert maxabs(got, want) < 2e-5
+    got = ops.conv3d_gn_in(x.to(dev), st, g.to(dev), b.to(dev), 32, pc, w2=w2.to(dev), b2=b2.to(dev))
+    want = F.conv3d(F.relu(F.group_norm(x, 32, g, b, 1e-5) * w2 + b2), wt, bias, padding=1)
+    assert maxabs(got, want) < 2e-5
+
+
+def test_cross_reenactment_equals_pairwise(M, dev, hot):
+    """BASELINE config 5 (1 source x N drivers, dp.cross_reenact): the source-side half is computed once,
+    results must equal running the hot slice on every (source, driver) pair."""
+    from megaportrait_hack_amd import dp
+
+    n_drv = 5
+    src = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 31).items()}
+    drv = {k: v.to(dev) for k, v in R.seeded_hot_inputs(n_drv, 32).items()}
+    with torch.no_grad():
+        fast = dp.cross_reenact(hot, src["vs"], src["es"], src["Rs"], src["ts"], src["zs"], drv["Rd"], drv["td"], drv["zd"], chunk=2)
+        rep = lambda t: t.expand(n_drv, *t.shape[1:]).contiguous()
+        slow = hot(vs=rep(src["vs"]), es=rep(src["es"]), Rs=rep(src["Rs"]), ts=rep(src["ts"]), zs=rep(src["zs"]),
+                   Rd=drv["Rd"], td=drv["td"], zd=drv["zd"])
+        assert fast.shape == slow.shape == (n_drv, 96, 64, 64)
+        assert (fast - slow).abs().max().item() < 2e-4
+        # sharded by driver frame over 2 ranks: concatenation of the shards == unsharded
+        parts = [dp.cross_reenact(hot, src["vs"], src["es"], src["Rs"], src["ts"], src["zs"], drv["Rd"], drv["td"], drv["zd"],
+                                  rank=r, world=2) for r in range(2)]
+        assert (torch.cat(parts, dim=0) - fast).abs().max().item() < 2e-4
+
+
 # ------------------------------------------------------------------------------- blocks / graph
 def test_resblocks_golden(M, dev, hot):
     g = gold("resblocks")
