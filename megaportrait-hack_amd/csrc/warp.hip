@@ -206,10 +206,27 @@ __device__ __forceinline__ Box block_box(int lx, int ly, int lz, int hx, int hy,
     return bx;
 }
 
-// Stage channels [c0, c0+cs) of the box into lds[c][z][y][x].  Lane -> box element (decoded once
-// per 64-element chunk), waves stride over channels.
+// Stage channels [c0, c0+cs) of the box into lds[z][y][x][c] with an odd channel pitch cs_pad: a tap's LDS
+// address is then the same for every channel up to an immediate offset (no per-channel address arithmetic in
+// the gather loop) and lanes that read different voxels hit different banks.  Lane -> box element (decoded
+// once per 64-element chunk), waves stride over channels.
 __device__ __forceinline__ void stage_box(const float *__restrict__ vb /* v + b*C*vol */, float *lds, const Box &bx,
-                                          int c0, int cs, int H, int W, size_t vol) {
+                                          int c0, int cs, int cs_pad, int H, int W, size_t vol) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int exy = bx.ex * bx.ey, bvol = exy * bx.ez;
+    for (int r = lane; r < bvol; r += 64) {
+        int z = r / exy, r2 = r - z * exy;
+        int y = r2 / bx.ex, x = r2 - y * bx.ex;
+        const float *src = vb + (size_t)c0 * vol + ((size_t)(bx.oz + z) * H + bx.oy + y) * W + bx.ox + x;
+        float *dst = lds + r * cs_pad;
+        for (int c = wave; c < cs; c += 4) dst[c] = src[(size_t)c * vol];
+    }
+}
+
+// Planar image lds[c][z][y][x] (K2: scalar taps, one pass over <= 12288/bvol channels; staging and gathers are
+// conflict-free because lanes walk consecutive box elements).
+__device__ __forceinline__ void stage_box_planar(const float *__restrict__ vb, float *lds, const Box &bx, int c0, int cs,
+                                                 int H, int W, size_t vol) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int exy = bx.ex * bx.ey, bvol = exy * bx.ez;
     for (int r = lane; r < bvol; r += 64) {
@@ -221,12 +238,65 @@ __device__ __forceinline__ void stage_box(const float *__restrict__ vb /* v + b*
     }
 }
 
-__device__ __forceinline__ Taps rebase(const Taps &t, int x0, int y0, int z0, const Box &bx) {
-    Taps r = t;
-    r.base = ((z0 - bx.oz) * bx.ey + (y0 - bx.oy)) * bx.ex + (x0 - bx.ox);
-    r.dy = t.dy ? bx.ex : 0;
-    r.dz = t.dz ? bx.ex * bx.ey : 0;
+// tap offsets of a voxel re-expressed in the staged LDS image (the 8 weights stay in the Taps)
+struct TapOff {
+    int base, dx, dy, dz;
+};
+
+__device__ __forceinline__ TapOff rebase(const Taps &t, int x0, int y0, int z0, const Box &bx, int cs_pad) {
+    TapOff r;
+    r.base = (((z0 - bx.oz) * bx.ey + (y0 - bx.oy)) * bx.ex + (x0 - bx.ox)) * cs_pad;
+    r.dx = t.dx ? cs_pad : 0;
+    r.dy = t.dy ? bx.ex * cs_pad : 0;
+    r.dz = t.dz ? bx.ex * bx.ey * cs_pad : 0;
     return r;
+}
+
+__device__ __forceinline__ float gather8_lds(const float *__restrict__ img, const TapOff &o, const float (&w)[8]) {
+    const float *p = img + o.base;
+    float acc = 0.0f;
+    acc += p[0] * w[0];
+    acc += p[o.dx] * w[1];
+    acc += p[o.dy] * w[2];
+    acc += p[o.dy + o.dx] * w[3];
+    acc += p[o.dz] * w[4];
+    acc += p[o.dz + o.dx] * w[5];
+    acc += p[o.dz + o.dy] * w[6];
+    acc += p[o.dz + o.dy + o.dx] * w[7];
+    return acc;
+}
+
+// Four channels per tap with one ds_read_b128 each (LDS image [voxel][channel], 16-byte aligned pitch): every
+// channel sees exactly the scalar op sequence of gather8 (acc=0; acc += p*w in tap order), so values stay
+// bit-identical, at a quarter of the LDS instructions.
+__device__ __forceinline__ void gather8x4(const float *__restrict__ img, const TapOff &t, const float (&tw)[8],
+                                          float out[4]) {
+    const float *p = img + t.base;
+    const float4 q0 = *reinterpret_cast<const float4 *>(p);
+    const float4 q1 = *reinterpret_cast<const float4 *>(p + t.dx);
+    const float4 q2 = *reinterpret_cast<const float4 *>(p + t.dy);
+    const float4 q3 = *reinterpret_cast<const float4 *>(p + t.dy + t.dx);
+    const float4 q4 = *reinterpret_cast<const float4 *>(p + t.dz);
+    const float4 q5 = *reinterpret_cast<const float4 *>(p + t.dz + t.dx);
+    const float4 q6 = *reinterpret_cast<const float4 *>(p + t.dz + t.dy);
+    const float4 q7 = *reinterpret_cast<const float4 *>(p + t.dz + t.dy + t.dx);
+#define MPHIP_ACC4(comp, k)                                                                        \
+    {                                                                                              \
+        float a_ = 0.0f;                                                                           \
+        a_ += q0.comp * tw[0]; a_ += q1.comp * tw[1]; a_ += q2.comp * tw[2]; a_ += q3.comp * tw[3];     \
+        a_ += q4.comp * tw[4]; a_ += q5.comp * tw[5]; a_ += q6.comp * tw[6]; a_ += q7.comp * tw[7];     \
+        out[k] = a_;                                                                               \
+    }
+    MPHIP_ACC4(x, 0) MPHIP_ACC4(y, 1) MPHIP_ACC4(z, 2) MPHIP_ACC4(w, 3)
+#undef MPHIP_ACC4
+}
+
+// channel pitch of the staged image: a multiple of 4 floats (16-byte tap reads) whose quarter is odd, so lanes
+// that read different voxels fall on different 16-byte bank slots
+__device__ __forceinline__ int lds_pitch_for(int channels) {
+    int p = (channels + 3) & ~3;
+    if (((p >> 2) & 1) == 0) p += 4;
+    return p;
 }
 
 // K2: a workgroup owns 1024 consecutive (h,w) positions of one (b,d) plane, 4 consecutive w per
@@ -234,7 +304,7 @@ __device__ __forceinline__ Taps rebase(const Taps &t, int x0, int y0, int z0, co
 __global__ void __launch_bounds__(256)
 warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out, int B,
                    int C, int D, int H, int W) {
-    __shared__ float lds[STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
     const int tiles = (HW + 1023) / 1024;
@@ -267,27 +337,27 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     }
     const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
     const int bvol = bx.ex * bx.ey * bx.ez;
-    const int cs_max = bvol > 0 ? STAGE_FLOATS / bvol : 0;
+    const int cs_max = bvol > 0 ? STAGE_FLOATS / bvol : 0;  // channels that fit one pass of the planar image
     const float *vb = v + (size_t)b * C * vol;
     float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
 
     if (cs_max >= 8 || cs_max >= C) {  // block-uniform
-        Taps lt[4];
+        TapOff lt[4];
         if (active) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lt[i] = rebase(taps[i], x0[i], y0[i], z0[i], bx);
+            for (int i = 0; i < 4; ++i) lt[i] = rebase(taps[i], x0[i], y0[i], z0[i], bx, 1);
         }
         for (int c0 = 0; c0 < C; c0 += cs_max) {
             const int cs = min(cs_max, C - c0);
             if (c0) __syncthreads();
-            stage_box(vb, lds, bx, c0, cs, H, W, vol);
+            stage_box_planar(vb, lds, bx, c0, cs, H, W, vol);
             __syncthreads();
             if (active) {
                 for (int c = 0; c < cs; ++c) {
                     const float *src = lds + c * bvol;
                     float4 r;
-                    r.x = gather8(src, lt[0]); r.y = gather8(src, lt[1]);
-                    r.z = gather8(src, lt[2]); r.w = gather8(src, lt[3]);
+                    r.x = gather8_lds(src, lt[0], taps[0].w); r.y = gather8_lds(src, lt[1], taps[1].w);
+                    r.z = gather8_lds(src, lt[2], taps[2].w); r.w = gather8_lds(src, lt[3], taps[3].w);
                     *reinterpret_cast<float4 *>(ob + (size_t)(c0 + c) * vol) = r;
                 }
             }
@@ -310,7 +380,7 @@ template <int CPB>
 __global__ void __launch_bounds__(256)
 warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                         int B, int C, int D, int H, int W) {
-    __shared__ float lds[STAGE_FLOATS];
+    __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
     const int tiles = (HW + 255) / 256;
@@ -333,10 +403,11 @@ warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ c
     }
     const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
     const int bvol = bx.ex * bx.ey * bx.ez;
-    const bool staged = bvol * cs <= STAGE_FLOATS;  // block-uniform
+    const int cs_pad = lds_pitch_for(cs);
+    const bool staged = bvol * cs_pad <= STAGE_FLOATS;  // block-uniform
     const float *vb = v + (size_t)b * C * vol;
     if (staged) {
-        stage_box(vb, lds, bx, c0, cs, H, W, vol);
+        stage_box(vb, lds, bx, c0, cs, cs_pad, H, W, vol);
         __syncthreads();
     }
     if (!active) return;
@@ -349,10 +420,20 @@ warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ c
         Coord3 cc{q[0], q[1], q[2]};
         Taps t = make_taps(cc, D, H, W);
         if (staged) {
-            Taps lt = rebase(t, (int)floorf(cc.x), (int)floorf(cc.y), (int)floorf(cc.z), bx);
+            const TapOff lt = rebase(t, (int)floorf(cc.x), (int)floorf(cc.y), (int)floorf(cc.z), bx, cs_pad);
 #pragma unroll
-            for (int c = 0; c < CPB; ++c)
-                if (c < cs) acc[c] += gather8(lds + c * bvol, lt);
+            for (int c = 0; c < CPB; c += 4) {
+                if (c + 4 <= cs) {
+                    float tmp[4];
+                    gather8x4(lds + c, lt, t.w, tmp);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[c + k] += tmp[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (c + k < cs) acc[c + k] += gather8_lds(lds + c + k, lt, t.w);
+                }
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < CPB; ++c)

@@ -31,18 +31,18 @@ def _no_autograd(*tensors, module: nn.Module):
 
 
 class _PackCache:
-    """Packed conv weights, rebuilt when the parameter changes (in-place update or .to())."""
+    """Packed conv weights, rebuilt when the parameter changes (in-place update, load_state_dict or .to()).
+    The pack lives ON the conv module (not in a global table keyed by id()), so it dies with the module and
+    can never be mistaken for another module's weights after id / address reuse."""
 
-    def __init__(self):
-        self._store = {}
-
-    def get(self, conv: nn.Module) -> ops.PackedConv:
+    @staticmethod
+    def get(conv: nn.Module) -> ops.PackedConv:
         w, b = conv.weight, conv.bias
-        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), str(w.device))
-        hit = self._store.get(id(conv))
+        key = (w.data_ptr(), w._version, tuple(w.shape), None if b is None else (b.data_ptr(), b._version), str(w.device))
+        hit = conv.__dict__.get("_mphip_pack")
         if hit is None or hit[0] != key:
             hit = (key, ops.PackedConv(w, b))
-            self._store[id(conv)] = hit
+            conv.__dict__["_mphip_pack"] = hit
         return hit[1]
 
 
