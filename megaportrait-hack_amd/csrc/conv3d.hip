@@ -369,8 +369,7 @@ splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict_
                      size_t n_out, int Co, int DHW, int splits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
-    float s = partial[i];
-    for (int z = 1; z < splits; ++z) s += partial[(size_t)z * n_out + i];
+    float s = sum_slabs(partial, splits, n_out, i);
     if (bias) s += bias[(i / DHW) % Co];
     y[i] = s;
 }

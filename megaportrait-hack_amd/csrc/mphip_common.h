@@ -40,4 +40,22 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
     return base + idx;
 }
 
+
+// value of a split-K tensor element: slab[0][o] + slab[1][o] + ... (z ascending, the reduce kernel's order).
+// The loads of 8 slabs are issued together (independent addresses) and only the adds are sequential, so a
+// 32-way split costs 4 memory round trips instead of 32.
+__device__ __forceinline__ float sum_slabs(const float *__restrict__ x, int splits, size_t slab, size_t o) {
+    float v = x[o];
+    int z = 1;
+    for (; z + 8 <= splits; z += 8) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = x[(size_t)(z + k) * slab + o];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v += t[k];
+    }
+    for (; z < splits; ++z) v += x[(size_t)z * slab + o];
+    return v;
+}
+
 }  // namespace mphip

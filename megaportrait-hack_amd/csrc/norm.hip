@@ -116,8 +116,7 @@ gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, cons
         float s = 0.0f, ss = 0.0f;
         for (size_t e = threadIdx.x; e < cnt; e += 256) {
             const size_t o = base + e;
-            float v = x[o];
-            for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + o];
+            float v = sum_slabs(x, splits, slab, o);
             if (bias) v += bias[c0 + (int)(e / S)];
             s += v;
             ss += v * v;
@@ -252,9 +251,7 @@ struct GnSplitParams {
 };
 
 __device__ __forceinline__ float split_value(const float *__restrict__ x, int splits, size_t slab, size_t o, float bias) {
-    float v = x[o];
-    for (int z = 1; z < splits; ++z) v += x[(size_t)z * slab + o];
-    return v + bias;
+    return sum_slabs(x, splits, slab, o) + bias;
 }
 
 __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, size_t total) {
@@ -317,8 +314,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
     float s = 0.0f, ss = 0.0f;
     for (int e = threadIdx.x; e < cnt; e += nthr) {
         const int c = shift >= 0 ? (e >> shift) : e / S;
-        float v = p.x[base + e];
-        for (int z = 1; z < q.x_splits; ++z) v += p.x[(size_t)z * q.slab + base + e];
+        float v = sum_slabs(p.x, q.x_splits, q.slab, base + e);
         if (q.x_splits > 1 && q.x_bias) v += q.x_bias[c0 + c];
         vals[e] = v;
         s += v;
@@ -360,8 +356,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
         const int ch = c0 + c;
         float rv = 0.0f;
         if (has_res) {
-            rv = p.residual[base + e];
-            for (int z = 1; z < q.res_splits; ++z) rv += p.residual[(size_t)z * q.slab + base + e];
+            rv = sum_slabs(p.residual, q.res_splits, q.slab, base + e);
             if (q.res_splits > 1 && q.res_bias) rv += q.res_bias[ch];
         }
         const float v = gn_value(p, vals[e], mean, rstd, p.gamma[ch], p.beta[ch], has2 ? p.w2[ch] : 1.0f,

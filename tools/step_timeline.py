@@ -6,8 +6,8 @@ rows = db.execute("select name, start, end, queue_id, grid_x, grid_y, grid_z fro
 names = [r[0] for r in rows]
 idx = [i for i, n in enumerate(names) if 'rt_theta' in n]
 # a step has 2 rt_theta launches; the last step starts a bit before the 2nd-to-last rt_theta's generator
-starts = [i for i, n in enumerate(names) if 'add_matmul_kernel<false>' in n]
-start = starts[-2]
+starts = [i for i, n in enumerate(names) if 'add_matmul_kn_kernel' in n]
+start = starts[-4]
 t0 = rows[start][1]
 end_t = max(r[2] for r in rows[start:])
 print(f"step wall {(end_t - t0)/1e3:.1f} us, kernels {len(rows)-start}")
