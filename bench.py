@@ -48,6 +48,10 @@ def parse():
                     help="conv arithmetic: fp32 = exact fp32 MFMA; f16x3/auto = split-f16 (3 f16 MFMAs per product, fp32-class "
                          "accuracy) where supported (default: MPHIP_CONV_PRECISION or auto)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline sample (0 = auto, ~15 s)")
+    ap.add_argument("--torch-gpu-baseline", action="store_true",
+                    help="also time the same graph through PyTorch-ROCm eager ops (ATen/MIOpen) on this GPU — what the "
+                         "reference's own model.py would run on an MI355X — and add it as `torch_rocm_baseline` (off by "
+                         "default: MIOpen's first-run kernel search can take minutes)")
     return ap.parse_args()
 
 
@@ -85,6 +89,40 @@ def pmc_traffic(kernel_prefix):
     except Exception:
         pass
     return None
+
+
+def torch_rocm_baseline(dev, B, steps=5):
+    """The reference-equivalent graph (oracle/hotpath_ref.py = the reference's module graph over ATen ops) run on
+    the GPU through PyTorch-ROCm eager kernels (MIOpen conv3d, ATen grid_sample / group_norm / interpolate).
+    A measured-beside baseline like cpu_baseline: never part of the product path."""
+    from oracle import hotpath_ref as R
+
+    sd = {k: v.to(dev) for k, v in R.seeded_gbase_hot_state_dict(7).items()}
+    g = torch.Generator(device="cpu").manual_seed(20240501)
+    inp = dict(vs=torch.randn(B, 96, 16, 64, 64, generator=g), es=torch.randn(B, 512, generator=g),
+               zs=torch.randn(B, 512, generator=g), zd=torch.randn(B, 512, generator=g),
+               Rs=(torch.rand(B, 3, generator=g) * 60 - 30), Rd=(torch.rand(B, 3, generator=g) * 60 - 30),
+               ts=torch.randn(B, 3, generator=g) * 0.1, td=torch.randn(B, 3, generator=g) * 0.1)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    orig_eye, orig_linspace, orig_tensor = torch.eye, torch.linspace, torch.tensor
+    # the restatement builds a few tiny constants on the default (CPU) device: route them to the GPU here
+    torch.eye = lambda *a, **k: orig_eye(*a, **{**k, "device": k.get("device", dev)})
+    torch.linspace = lambda *a, **k: orig_linspace(*a, **{**k, "device": k.get("device", dev)})
+    torch.tensor = lambda *a, **k: orig_tensor(*a, **{**k, "device": k.get("device", dev)})
+    try:
+        with torch.no_grad():
+            for _ in range(2):
+                R.hot_slice(sd=sd, **inp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                R.hot_slice(sd=sd, **inp)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        torch.eye, torch.linspace, torch.tensor = orig_eye, orig_linspace, orig_tensor
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2),
+            "kind": "PyTorch-ROCm eager (ATen/MIOpen fp32) of the same graph on the same GPU", "batch": B, "steps": steps}
 
 
 def cpu_baseline(frames):
@@ -234,6 +272,8 @@ def main():
                                   f"{round(achieved / PEAK_F32_MFMA_TFLOPS, 2)}x") if f16x3 else
                                  "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         }
+        if world == 1 and args.torch_gpu_baseline:
+            line["torch_rocm_baseline"] = torch_rocm_baseline(dev, B)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_frames)
         print(json.dumps(line), flush=True)
