@@ -184,6 +184,28 @@ int mphip_upsample_nearest(const float *x, float *y, int NC, int D, int H, int W
 int mphip_add_matmul(const float *a, const float *a2, const float *m, const float *bias, float *out, int B,
                      int K, int N, int trans, void *stream);
 
+/* ------------------------------------------------------------------ K9  backward (training, scope row f2)
+ * Gradients of the G3d building blocks as torch.autograd computes them for the reference's modules.
+ * bwd-data of a conv is mphip_conv3d_fwd on the flipped/transposed weight (host side, ops.conv3d_bwd_data).
+ * conv3d_bwd_weight: dW[co][ci][tap] = sum_{n,v} dY[n][co][v] * X[n][ci][v+tap]  (nn.Conv3d model.py:505-510, 591;
+ *                    fp32 MFMA, split over voxels, deterministic slab reduce; dbias = sum dY, optional);
+ *                    any D,H,W (1x8x8 voxel tiles, ragged edges masked); k in {1,3}.
+ * groupnorm_bwd_reduce / _apply: nn.GroupNorm (+ residual + ReLU) backward (model.py:506-523).  reduce writes
+ *                    s12[n][c] = (sum du, sum du*xhat), du = dy*(y>0) when relu; the caller folds them into
+ *                    dgamma/dbeta and ab[n][g] = (sum_c gamma*s1, sum_c gamma*s2)/count; apply writes
+ *                    dx = rstd*(gamma*du - a - xhat*b) and dres = du (dres may be NULL).  y = the forward output.
+ * avgpool2_bwd, upsample_trilinear2_bwd: adjoints of K7 (D,H,W = dims of dx).                      */
+size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
+int mphip_conv3d_bwd_weight(const float *x, const float *dy, float *dw, float *dbias, int N, int Ci, int Co, int D,
+                            int H, int W, int k, void *workspace, size_t workspace_bytes, void *stream);
+int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats, float *s12,
+                               int N, int C, int S, int G, int relu, void *stream);
+int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, const float *stats,
+                              const float *gamma, const float *ab, float *dx, float *dres, int N, int C, int S,
+                              int G, int relu, void *stream);
+int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
+int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

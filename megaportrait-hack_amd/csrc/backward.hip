@@ -1,0 +1,365 @@
+// Backward kernels of the G3d blocks (scope row f2, SURVEY.md §8f: training through the HIP path).
+// First, correctness-oriented versions: every gradient the reference's autograd produces for
+// nn.Conv3d / nn.GroupNorm+ReLU(+residual) / nn.AvgPool3d / nn.Upsample(trilinear, align_corners=True)
+// (model.py:500-528, 571-597) has a HIP kernel here; bwd-data of the convs reuses the forward conv kernels
+// on flipped/transposed weights (host side), so it already runs on the f16x3 path.
+#include "mphip_common.h"
+#include "mphip_conv.h"
+#include "mphip_resample.h"
+
+namespace mphip {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------------
+// conv3d 3x3x3 / 1x1x1 backward-weight:  dW[co][ci][tap] = sum_{n,v} dY[n][co][v] * X[n][ci][v + tap]
+// GEMM per tap: M = co, N = ci, K = voxels, on v_mfma_f32_32x32x2_f32 (exact fp32).
+// Workgroup = 3 waves, one (96-co tile, 32-ci tile, kd plane) and a slice of the voxel range; wave w owns the
+// kh = w row of the plane (3 taps x 3 co tiles = 9 accumulators).  Per 1x8x8 voxel tile the dY tile
+// [96][64] and the X halo tile [32][3][10][10] (one kd plane deep: only d+kd-1 is needed) are staged in
+// LDS with odd pitches (lanes walk channels: conflict-free).  Partial sums go to slab[blockIdx.z] and are
+// reduced in order by conv_bwd_weight_reduce_kernel (deterministic).
+constexpr int BW_VT = 64;          // voxels per staged tile (1 x 8 x 8)
+constexpr int BW_DYP = BW_VT + 1;  // dY pitch
+constexpr int BW_XV = 10 * 10;     // halo voxels of one depth slice (8+2)^2
+constexpr int BW_XP = BW_XV + 1;   // X pitch
+
+template <int KS>
+__global__ void __launch_bounds__(192)
+conv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ slabs, int N, int Ci,
+                       int Co, int D, int H, int W, int tiles_per_split, unsigned x_bytes) {
+    __shared__ float dys[96 * BW_DYP];
+    __shared__ float xs[32 * BW_XP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kk = lane >> 5;
+    const int HW = H * W, DHW = D * HW;
+    const int ci_tiles = (Ci + 31) / 32;
+    const int ci0 = (blockIdx.x % ci_tiles) * 32;
+    const int co0 = (blockIdx.x / ci_tiles) * 96;
+    const int kd = KS == 3 ? blockIdx.y : 1;            // tap plane (depth offset kd-1)
+    const int kh = KS == 3 ? wave : 1;                   // this wave's row of the plane
+    const int tiles_h = (H + 7) / 8, tiles_w = (W + 7) / 8;
+    const long ntiles = (long)N * D * tiles_h * tiles_w;
+    const long t_begin = (long)blockIdx.z * tiles_per_split;
+    const long t_end = min(ntiles, t_begin + tiles_per_split);
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+
+    constexpr int NTAP = KS == 3 ? 3 : 1;  // taps per wave (kw = 0..2)
+    f32x16 acc[NTAP][3];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.0f;
+
+    const bool wave_active = KS == 3 || wave == 0;
+    for (long tile = t_begin; tile < t_end; ++tile) {
+        long r = tile;
+        const int tw = (int)(r % tiles_w); r /= tiles_w;
+        const int th = (int)(r % tiles_h); r /= tiles_h;
+        const int d = (int)(r % D);
+        const int n = (int)(r / D);
+        const int h0 = th * 8, w0 = tw * 8;
+        __syncthreads();  // previous tile fully consumed
+        // dY tile [96 co][64 vox]
+        for (int e = tid; e < 96 * BW_VT; e += 192) {
+            const int c = e / BW_VT, v = e % BW_VT;
+            const int co = co0 + c;
+            float val = 0.0f;
+            const int gh = h0 + v / 8, gw = w0 + v % 8;  // ragged edge tiles contribute zeros
+            if (co < Co && gh < H && gw < W) val = dy[((size_t)n * Co + co) * DHW + (size_t)d * HW + gh * W + gw];
+            dys[c * BW_DYP + v] = val;
+        }
+        // X slice d+kd-1, halo 10x10, 32 channels (zero outside the volume / beyond Ci)
+        const int xd = d + kd - 1;
+        for (int e = tid; e < 32 * BW_XV; e += 192) {
+            const int c = e / BW_XV, q = e % BW_XV;
+            const int gh = h0 - 1 + q / 10, gw = w0 - 1 + q % 10;
+            const int ci = ci0 + c;
+            unsigned off = OOB;
+            if (ci < Ci && (unsigned)xd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
+                off = (unsigned)((((long)n * Ci + ci) * DHW + (long)xd * HW + gh * W + gw) * 4);
+            xs[c * BW_XP + q] = buf_load_f(rsrc, off, 0);
+        }
+        __syncthreads();
+        if (wave_active) {
+#pragma unroll 4
+            for (int ks = 0; ks < BW_VT / 2; ++ks) {
+                const int v = 2 * ks + kk;                 // this lane's voxel (k index of the MFMA)
+                const int vh = v / 8, vw = v % 8;
+                float a[3], b[NTAP];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) a[m] = dys[(m * 32 + j) * BW_DYP + v];       // A[i=co][k=vox]
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t) {
+                    const int kw = KS == 3 ? t : 1;
+                    b[t] = xs[j * BW_XP + (vh + kh) * 10 + vw + kw];                       // B[k=vox][j=ci]
+                }
+#pragma unroll
+                for (int t = 0; t < NTAP; ++t)
+#pragma unroll
+                    for (int m = 0; m < 3; ++m)
+                        acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[t][m], 0, 0, 0);
+            }
+        }
+    }
+    if (!wave_active) return;
+    // slab layout = OIDHW gradient [Co][Ci][taps]; C/D: col = lane&31 = ci, row = co
+    constexpr int TAPS = KS * KS * KS;
+    float *slab = slabs + (size_t)blockIdx.z * Co * Ci * TAPS;
+    const int ci = ci0 + j;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const int tap = KS == 3 ? (kd * 3 + kh) * 3 + t : 0;
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                if (co < Co && ci < Ci) slab[((size_t)co * Ci + ci) * TAPS + tap] = acc[t][m][reg];
+            }
+    }
+}
+
+__global__ void __launch_bounds__(256)
+slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n, int splits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out[i] = sum_slabs(slabs, splits, n, i);
+}
+
+// per-channel sum over (n, voxels):  db[c] = sum dy[n][c][:]   (one workgroup per channel)
+__global__ void __launch_bounds__(256)
+channel_sum_kernel(const float *__restrict__ dy, float *__restrict__ out, int N, int C, int S) {
+    const int c = blockIdx.x;
+    double acc = 0.0;
+    for (int n = 0; n < N; ++n) {
+        const float *p = dy + ((size_t)n * C + c) * S;
+        float s = 0.0f;
+        for (int i = threadIdx.x; i < S; i += 256) s += p[i];
+        acc += (double)s;
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+    __shared__ double red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
+}
+
+// ---------------------------------------------------------------------------------------------------
+// GroupNorm (+residual, +ReLU) backward.  Forward: xh = (x-mean)*rstd; z = xh*gamma+beta; u = z (+res); y = relu(u).
+// Pass 1 (one workgroup per (n,c) plane): du = dy * (y > 0) [no mask when relu == 0];
+//         s1[n,c] = sum du, s2[n,c] = sum du*xh.
+// (host, tiny [N,C] tensors: dbeta = sum_n s1, dgamma = sum_n s2, A[n,g] = sum_c gamma_c*s1/cnt, B[n,g] = sum_c gamma_c*s2/cnt)
+// Pass 2: dx = rstd * (gamma_c*du - A - xh*B);  dres = du.
+__global__ void __launch_bounds__(256)
+gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                     const float *__restrict__ stats, float *__restrict__ s12, int C, int cpg, int S, int relu) {
+    const int plane = blockIdx.x;  // n*C + c
+    const int c = plane % C, n = plane / C;
+    const int grp = n * (C / cpg) + c / cpg;
+    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+    const size_t base = (size_t)plane * S;
+    float s1 = 0.0f, s2 = 0.0f;
+    double d1 = 0.0, d2 = 0.0;
+    int cnt = 0;
+    for (int i = threadIdx.x; i < S; i += 256) {
+        float du = dy[base + i];
+        if (relu && !(y[base + i] > 0.0f)) du = 0.0f;
+        const float xh = (x[base + i] - mean) * rstd;
+        s1 += du;
+        s2 += du * xh;
+        if (++cnt == 64) {  // fp32 partials over 64 elements, combined in double
+            d1 += (double)s1; d2 += (double)s2; s1 = s2 = 0.0f; cnt = 0;
+        }
+    }
+    d1 += (double)s1; d2 += (double)s2;
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        d1 += __shfl_xor(d1, sft, 64);
+        d2 += __shfl_xor(d2, sft, 64);
+    }
+    __shared__ double red[8];
+    if ((threadIdx.x & 63) == 0) {
+        red[(threadIdx.x >> 6) * 2] = d1;
+        red[(threadIdx.x >> 6) * 2 + 1] = d2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s12[plane * 2] = (float)((red[0] + red[2]) + (red[4] + red[6]));
+        s12[plane * 2 + 1] = (float)((red[1] + red[3]) + (red[5] + red[7]));
+    }
+}
+
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                    const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ ab,
+                    float *__restrict__ dx, float *__restrict__ dres, int C, int cpg, int S, int relu, size_t total) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const size_t plane = i / S;
+    const int c = (int)(plane % C), n = (int)(plane / C);
+    const int grp = n * (C / cpg) + c / cpg;
+    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+    float du = dy[i];
+    if (relu && !(y[i] > 0.0f)) du = 0.0f;
+    const float xh = (x[i] - mean) * rstd;
+    dx[i] = rstd * (gamma[c] * du - ab[grp * 2] - xh * ab[grp * 2 + 1]);
+    if (dres) dres[i] = du;
+}
+
+// AvgPool3d(2,2) backward: dx[2d+a][2h+b][2w+c] = dout[d][h][w] / 8
+__global__ void __launch_bounds__(256)
+avgpool2_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over dx elements
+    if (t >= total) return;
+    const int w = (int)(t % W);
+    size_t r = t / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int d = (int)(r % D);
+    const size_t plane = r / D;
+    dx[t] = dout[((plane * (D / 2) + d / 2) * (H / 2) + h / 2) * (W / 2) + w / 2] / 8.0f;
+}
+
+// nn.Upsample(x2, trilinear, align_corners=True) backward (adjoint of upsample_trilinear2): each input voxel
+// gathers, per axis, the <= 4 outputs whose source interval touches it, with the forward's own weights
+// (deterministic, no atomics).  dx[i] = sum_o w(o,i) * dout[o].
+__device__ __forceinline__ int adj_range(int i, int in, float scale, int out, int &lo) {
+    // outputs o with i0(o) == i or i1(o) == i satisfy  i-1 < scale*o < i+1
+    if (!(scale > 0.0f)) {
+        lo = 0;
+        return out - 1;
+    }
+    lo = max(0, (int)floorf(((float)i - 1.0f) / scale) - 1);
+    int hi = min(out - 1, (int)ceilf(((float)i + 1.0f) / scale) + 1);
+    return hi;
+}
+__device__ __forceinline__ float adj_weight(int o, int i, int in, float scale) {
+    float src = scale * (float)o;
+    int i0 = min((int)src, in - 1);
+    int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    float l1 = src - (float)i0, l0 = 1.0f - l1;
+    float w = 0.0f;
+    if (i0 == i) w += l0;
+    if (i1 == i) w += l1;
+    return w;
+}
+__global__ void __launch_bounds__(256)
+upsample_trilinear2_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, float sD,
+                               float sH, float sW, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over dx (input-sized) elements
+    if (t >= total) return;
+    const int w = (int)(t % W);
+    size_t r = t / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int d = (int)(r % D);
+    const size_t plane = r / D;
+    const int oD = 2 * D, oH = 2 * H, oW = 2 * W;
+    int dlo, hlo, wlo;
+    const int dhi = adj_range(d, D, sD, oD, dlo), hhi = adj_range(h, H, sH, oH, hlo), whi = adj_range(w, W, sW, oW, wlo);
+    const float *p = dout + plane * (size_t)oD * oH * oW;
+    float acc = 0.0f;
+    for (int od = dlo; od <= dhi; ++od) {
+        const float wd = adj_weight(od, d, D, sD);
+        if (wd == 0.0f) continue;
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            const float wh = adj_weight(oh, h, H, sH);
+            if (wh == 0.0f) continue;
+            float row = 0.0f;
+            for (int ow = wlo; ow <= whi; ++ow) row += adj_weight(ow, w, W, sW) * p[((size_t)od * oH + oh) * oW + ow];
+            acc += wd * wh * row;
+        }
+    }
+    dx[t] = acc;
+}
+
+}  // namespace mphip
+
+using namespace mphip;
+
+static int bw_splits(long ntiles, int blocks_xy) {
+    int s = 1;
+    while ((long)blocks_xy * s < 1024 && ntiles / (s * 2) >= 8) s *= 2;
+    return s;
+}
+
+extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
+    const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
+    const int bxy = ((Ci + 31) / 32) * ((Co + 95) / 96) * (k == 3 ? 3 : 1);
+    return (size_t)bw_splits(ntiles, bxy) * Co * Ci * k * k * k * sizeof(float);
+}
+
+extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, float *dw, float *dbias, int N, int Ci, int Co,
+                                       int D, int H, int W, int k, void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(x && dy && dw, "conv3d_bwd_weight: null pointer");
+    MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3), "conv3d_bwd_weight: bad dims");
+    const size_t x_bytes = (size_t)N * Ci * D * H * W * sizeof(float);
+    MPHIP_REQUIRE(x_bytes < 0x80000000ull, "conv3d_bwd_weight: input exceeds the 2 GiB buffer-addressing limit");
+    const size_t need = mphip_conv3d_bwd_weight_workspace_bytes(N, Ci, Co, D, H, W, k);
+    if (!workspace || workspace_bytes < need) {
+        set_error("conv3d_bwd_weight: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
+    const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;
+    const int splits = bw_splits(ntiles, ci_tiles * co_tiles * (k == 3 ? 3 : 1));
+    const int tps = (int)((ntiles + splits - 1) / splits);
+    dim3 grid(ci_tiles * co_tiles, k == 3 ? 3 : 1, splits);
+    if (k == 3)
+        hipLaunchKernelGGL(conv_bwd_weight_kernel<3>, grid, dim3(192), 0, s, x, dy, (float *)workspace, N, Ci, Co, D, H, W, tps,
+                           (unsigned)x_bytes);
+    else
+        hipLaunchKernelGGL(conv_bwd_weight_kernel<1>, grid, dim3(192), 0, s, x, dy, (float *)workspace, N, Ci, Co, D, H, W, tps,
+                           (unsigned)x_bytes);
+    const size_t nw = (size_t)Co * Ci * k * k * k;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float *)workspace, dw, nw, splits);
+    if (dbias) hipLaunchKernelGGL(channel_sum_kernel, dim3(Co), dim3(256), 0, s, dy, dbias, N, Co, D * H * W);
+    return check_launch("conv3d_bwd_weight");
+}
+
+extern "C" int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats, float *s12,
+                                          int N, int C, int S, int G, int relu, void *stream) {
+    MPHIP_REQUIRE(x && dy && stats && s12 && (!relu || y), "groupnorm_bwd_reduce: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd_reduce: bad dims");
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, s12, C, C / G, S,
+                       relu);
+    return check_launch("groupnorm_bwd_reduce");
+}
+
+extern "C" int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, const float *stats,
+                                         const float *gamma, const float *ab, float *dx, float *dres, int N, int C, int S,
+                                         int G, int relu, void *stream) {
+    MPHIP_REQUIRE(x && dy && stats && gamma && ab && dx && (!relu || y), "groupnorm_bwd_apply: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd_apply: bad dims");
+    const size_t total = (size_t)N * C * S;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, gamma,
+                       ab, dx, dres, C, C / G, S, relu, total);
+    return check_launch("groupnorm_bwd_apply");
+}
+
+extern "C" int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream) {
+    MPHIP_REQUIRE(dout && dx, "avgpool2_bwd: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "avgpool2_bwd: bad dims");
+    const size_t total = (size_t)NC * D * H * W;
+    hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, D, H, W, total);
+    return check_launch("avgpool2_bwd");
+}
+
+extern "C" int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream) {
+    MPHIP_REQUIRE(dout && dx, "upsample_trilinear2_bwd: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0, "upsample_trilinear2_bwd: bad dims");
+    const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
+    const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
+    const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
+    const size_t total = (size_t)NC * D * H * W;
+    hipLaunchKernelGGL(upsample_trilinear2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, D, H,
+                       W, sD, sH, sW, total);
+    return check_launch("upsample_trilinear2_bwd");
+}

@@ -9,7 +9,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility
 objs=()
 pids=()
 mkdir -p "$here/build"
-for f in api warp norm conv3d conv3d_f16x3; do
+for f in api warp norm conv3d conv3d_f16x3 backward; do
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
   pids+=($!)
   objs+=("$here/build/$f.o")

@@ -7,8 +7,9 @@ arithmetic runs in libmphip.so (hand-written HIP for gfx950) through the C ABI. 
 nn.GroupNorm objects are kept purely as parameter containers (names, shapes, default init,
 .to()/.state_dict()); their own forward is never called.
 
-Forward only this round: the HIP path has no backward yet, so calling a hot
-module while autograd needs a graph raises instead of silently detaching.
+Training: ResBlock3D and G3d are differentiable — under autograd they run the same HIP ops as
+torch.autograd Functions (autograd.py) whose backward kernels live in csrc/backward.hip.  The warp generators and
+the two warps are still forward-only: under autograd they raise instead of silently detaching.
 """
 from __future__ import annotations
 
@@ -17,6 +18,7 @@ import logging
 import torch
 import torch.nn as nn
 
+from . import autograd as ag
 from . import ops
 
 COMPRESS_DIM = 512  # model.py:48
@@ -224,8 +226,19 @@ class ResBlock3D(nn.Module):
         self.gn2 = nn.GroupNorm(num_groups=32, num_channels=out_channels)
         self.shortcut = nn.Conv3d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else nn.Identity()
 
+    def _forward_train(self, x):
+        """Differentiable path (scope row f2): the same ops, unfused, as torch.autograd Functions whose forward and
+        backward both run in libmphip.so (autograd.py)."""
+        identity = x if isinstance(self.shortcut, nn.Identity) else ag.conv3d(x, self.shortcut, _packs.get(self.shortcut))
+        y = ag.conv3d(x, self.conv1, _packs.get(self.conv1))
+        y = ag.groupnorm(y, self.gn1, relu=True)
+        y = ag.conv3d(y, self.conv2, _packs.get(self.conv2))
+        return ag.groupnorm(y, self.gn2, residual=identity, relu=True)
+
     def forward(self, x, _pool_after: bool = False):
-        _no_autograd(x, module=self)
+        if ag.needs_grad(self, x):
+            y = self._forward_train(x)
+            return ag.AvgPool2Fn.apply(y) if _pool_after else y
         identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d_split(x, _packs.get(self.shortcut))
         y = ops.conv3d_split(x, _packs.get(self.conv1))
         st = ops.groupnorm_stats(y, 32, self.gn1.eps)
@@ -260,16 +273,19 @@ class G3d(nn.Module):
         self.final_conv = nn.Conv3d(96, 96, kernel_size=3, padding=1)
 
     def forward(self, x):
-        _no_autograd(x, module=self)
+        train = ag.needs_grad(self, x)
+        up = ag.UpsampleTrilinear2Fn.apply if train else ops.upsample_trilinear2
         d = self.downsampling
-        x = d[0](x, _pool_after=True)   # AvgPool3d fused into the block's last elementwise pass
+        x = d[0](x, _pool_after=True)   # AvgPool3d fused into the block's last elementwise pass (inference)
         x = d[2](x, _pool_after=True)
         x = d[4](x, _pool_after=True)
         x = d[6](x)
         u = self.upsampling
-        x = ops.upsample_trilinear2(u[0](x))
-        x = ops.upsample_trilinear2(u[2](x))
-        x = ops.upsample_trilinear2(u[4](x))
+        x = up(u[0](x))
+        x = up(u[2](x))
+        x = up(u[4](x))
+        if train:
+            return ag.conv3d(x, self.final_conv, _packs.get(self.final_conv))
         return ops.conv3d(x, _packs.get(self.final_conv))
 
 

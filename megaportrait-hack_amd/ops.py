@@ -495,3 +495,69 @@ def add_matmul(a: torch.Tensor, a2: Optional[torch.Tensor], m: torch.Tensor, bia
     _lib.check(_lib.load().mphip_add_matmul(_ptr(a), _ptr(a2), _ptr(m), _ptr(bias), _ptr(out), b, k, n, int(trans),
                                             _stream()), "mphip_add_matmul")
     return out
+
+
+# ------------------------------------------------------------------ K9  backward (scope row f2)
+def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, want_bias: bool = True):
+    """(dW [Co,Ci,k,k,k], dbias [Co] or None) of y = conv3d(x, W, b, padding=k//2) given dy."""
+    x, dy = _req(x, "x"), _req(dy, "dy")
+    n, ci, d, h, w = x.shape
+    co = dy.shape[1]
+    if tuple(dy.shape) != (n, co, d, h, w):
+        raise RuntimeError(f"conv3d_bwd_weight: dy {tuple(dy.shape)} does not match x {tuple(x.shape)}")
+    lib = _lib.load()
+    ws_bytes = lib.mphip_conv3d_bwd_weight_workspace_bytes(n, ci, co, d, h, w, k)
+    if ws_bytes == 0:
+        raise RuntimeError(f"conv3d_bwd_weight: unsupported shape {tuple(x.shape)} k={k}")
+    ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
+    dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.device)
+    db = torch.empty((co,), dtype=torch.float32, device=x.device) if want_bias else None
+    _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, ci, co, d, h, w, k, _ptr(ws), ws_bytes,
+                                           _stream()), "mphip_conv3d_bwd_weight")
+    return dw, db
+
+
+def conv_bwd_data_weight(weight: torch.Tensor) -> torch.Tensor:
+    """The conv whose forward is the bwd-data of `weight`'s conv: Wt[ci][co][a][b][c] = W[co][ci][k-1-a][k-1-b][k-1-c]."""
+    return weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
+
+
+def groupnorm_bwd(x, y, dy, stats, gamma, groups: int, relu: bool, want_res: bool):
+    """Backward of y = relu?(GroupNorm(x)*gamma+beta (+res)) -> (dx, dgamma, dbeta, dres|None).  `y` is the forward
+    output (ReLU mask); stats = the forward (mean, rstd)."""
+    x, dy = _req(x, "x"), _req(dy, "dy")
+    n, c = x.shape[0], x.shape[1]
+    s = x.numel() // (n * c)
+    cpg = c // groups
+    lib = _lib.load()
+    gamma = _req(gamma.detach(), "gamma")
+    s12 = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(s12), n, c, s, groups, int(relu),
+                                              _stream()), "mphip_groupnorm_bwd_reduce")
+    dbeta = s12[:, :, 0].sum(0)
+    dgamma = s12[:, :, 1].sum(0)
+    ab = ((s12 * gamma.view(1, c, 1)).view(n, groups, cpg, 2).sum(2) / float(cpg * s)).contiguous()
+    dx = torch.empty_like(x)
+    dres = torch.empty_like(x) if want_res else None
+    _lib.check(lib.mphip_groupnorm_bwd_apply(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(ab), _ptr(dx), _ptr(dres),
+                                             n, c, s, groups, int(relu), _stream()), "mphip_groupnorm_bwd_apply")
+    return dx, dgamma, dbeta, dres
+
+
+def avgpool2_bwd(dout: torch.Tensor) -> torch.Tensor:
+    dout = _req(dout, "dout")
+    n, c, d, h, w = dout.shape
+    dx = torch.empty((n, c, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.load().mphip_avgpool2_bwd(_ptr(dout), _ptr(dx), n * c, 2 * d, 2 * h, 2 * w, _stream()), "mphip_avgpool2_bwd")
+    return dx
+
+
+def upsample_trilinear2_bwd(dout: torch.Tensor) -> torch.Tensor:
+    dout = _req(dout, "dout")
+    n, c, d, h, w = dout.shape
+    if d % 2 or h % 2 or w % 2:
+        raise RuntimeError("upsample_trilinear2_bwd: gradient dims must be even")
+    dx = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.load().mphip_upsample_trilinear2_bwd(_ptr(dout), _ptr(dx), n * c, d // 2, h // 2, w // 2, _stream()),
+               "mphip_upsample_trilinear2_bwd")
+    return dx

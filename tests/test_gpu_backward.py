@@ -1,0 +1,185 @@
+"""GPU parity of the backward kernels (scope row f2) against torch CPU autograd of the oracle's functional
+restatement (oracle/hotpath_ref.py — the same ATen ops the reference's modules differentiate through,
+model.py:500-528, 571-597).  Bar: max-abs error <= 1e-3 of the gradient's own max-abs (north_star's float
+tolerance, applied relative to scale because gradients of sums over 10^5 voxels are not O(1)); the fp32-exact
+kernels are checked much tighter.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hotpath_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from megaportrait_hack_amd import _lib, ops
+
+    _lib.load()
+    return ops
+
+
+@pytest.fixture(scope="module")
+def M():
+    from megaportrait_hack_amd import model
+
+    return model
+
+
+def rel_err(got, want):
+    want = want.detach().double()
+    scale = max(want.abs().max().item(), 1e-30)
+    return (got.detach().cpu().double() - want).abs().max().item() / scale
+
+
+@pytest.mark.parametrize("shape", [
+    (2, 96, 96, 4, 16, 16, 3),     # G3d L0-like
+    (1, 96, 192, 2, 8, 8, 3),      # channel-changing block
+    (2, 40, 72, 3, 12, 20, 3),     # ragged channels (not multiples of 32 / 96) and H, W not multiples of 8
+    (1, 192, 96, 4, 8, 8, 1),      # 1x1x1 shortcut
+    (3, 768, 384, 2, 4, 4, 3),     # deepest level of the 256px configuration (4x4 maps)
+])
+def test_conv3d_bwd_weight(dev, ops, shape):
+    n, ci, co, d, h, w, k = shape
+    x = R.seeded_tensor((n, ci, d, h, w), 11)
+    dy = R.seeded_tensor((n, co, d, h, w), 12)
+    wt = R.seeded_tensor((co, ci, k, k, k), 13, scale=0.05).requires_grad_(True)
+    b = torch.zeros(co, requires_grad=True)
+    F.conv3d(x, wt, b, padding=k // 2).backward(dy)
+    dw, db = ops.conv3d_bwd_weight(x.to(dev), dy.to(dev), k)
+    assert dw.shape == wt.shape
+    assert rel_err(dw, wt.grad) < 2e-5     # exact fp32 products, fp32 accumulation in a different order
+    assert rel_err(db, b.grad) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 96, 4, 16, 16, 3), (1, 192, 96, 2, 8, 8, 3), (1, 96, 192, 4, 8, 8, 1),
+                                   (1, 40, 24, 3, 5, 7, 3)])
+def test_conv3d_bwd_data(dev, ops, shape):
+    """bwd-data = the forward conv on the flipped / transposed weight."""
+    n, ci, co, d, h, w, k = shape
+    x = R.seeded_tensor((n, ci, d, h, w), 21).requires_grad_(True)
+    dy = R.seeded_tensor((n, co, d, h, w), 22)
+    wt = R.seeded_tensor((co, ci, k, k, k), 23, scale=0.05)
+    F.conv3d(x, wt, None, padding=k // 2).backward(dy)
+    pc = ops.PackedConv(ops.conv_bwd_data_weight(wt.to(dev)), None)
+    dx = ops.conv3d(dy.to(dev), pc)
+    assert rel_err(dx, x.grad) < 1e-4
+
+
+@pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, False)])
+@pytest.mark.parametrize("shape", [(2, 96, 4, 8, 8), (1, 64, 2, 5, 6)])
+def test_groupnorm_bwd(dev, ops, shape, relu, res):
+    n, c, d, h, w = shape
+    x = R.seeded_tensor(shape, 31, scale=2.0, shift=0.3).requires_grad_(True)
+    r = R.seeded_tensor(shape, 32).requires_grad_(True) if res else None
+    gamma = R.seeded_tensor((c,), 33, shift=1.0).requires_grad_(True)
+    beta = R.seeded_tensor((c,), 34).requires_grad_(True)
+    dy = R.seeded_tensor(shape, 35)
+    u = F.group_norm(x, 32, gamma, beta, 1e-5)
+    if res:
+        u = u + r
+    y = F.relu(u) if relu else u
+    y.backward(dy)
+    xg = x.detach().to(dev)
+    st = ops.groupnorm_stats(xg, 32, 1e-5)
+    yg = ops.groupnorm_apply(xg, st, gamma.detach().to(dev), beta.detach().to(dev), 32,
+                             residual=None if r is None else r.detach().to(dev), relu=relu)
+    assert rel_err(yg, y) < 1e-5
+    dx, dgamma, dbeta, dres = ops.groupnorm_bwd(xg, yg, dy.to(dev), st, gamma.detach().to(dev), 32, relu, res)
+    assert rel_err(dx, x.grad) < 1e-4
+    assert rel_err(dgamma, gamma.grad) < 1e-4
+    assert rel_err(dbeta, beta.grad) < 1e-4
+    if res:
+        assert rel_err(dres, r.grad) < 1e-6
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 2, 4, 4), (1, 3, 1, 2, 3), (1, 2, 4, 16, 16)])
+def test_resample_bwd(dev, ops, shape):
+    x = R.seeded_tensor(shape, 41).requires_grad_(True)
+    up = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
+    dup = R.seeded_tensor(tuple(up.shape), 42)
+    up.backward(dup)
+    assert rel_err(ops.upsample_trilinear2_bwd(dup.to(dev)), x.grad) < 1e-5
+    if all(s % 2 == 0 for s in shape[2:]):
+        x2 = R.seeded_tensor(shape, 43).requires_grad_(True)
+        p = F.avg_pool3d(x2, 2, 2)
+        dp = R.seeded_tensor(tuple(p.shape), 44)
+        p.backward(dp)
+        assert rel_err(ops.avgpool2_bwd(dp.to(dev)), x2.grad) == 0.0
+
+
+def _grads_cpu(fn, sd, x, dy):
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    x = x.clone().requires_grad_(True)
+    y = fn(x, sd)
+    y.backward(dy)
+    return y.detach(), x.grad, {k: v.grad for k, v in sd.items()}
+
+
+@pytest.mark.parametrize("cin,cout", [(96, 96), (96, 192)])
+def test_resblock3d_backward(dev, M, cin, cout):
+    """model.py:500-528 forward + autograd backward through the HIP Functions vs CPU autograd."""
+    blk = M.ResBlock3D(cin, cout)
+    shapes = {k: tuple(v.shape) for k, v in blk.state_dict().items()}
+    sd = R.seeded_state_dict(shapes, 51)
+    blk.load_state_dict(sd)
+    blk = blk.to(dev).train()
+    x = R.seeded_tensor((2, cin, 4, 8, 8), 52)
+    dy = R.seeded_tensor((2, cout, 4, 8, 8), 53)
+    y_ref, dx_ref, g_ref = _grads_cpu(lambda t, s: R.resblock3d(t, s, ""), sd, x, dy)
+    xg = x.to(dev).requires_grad_(True)
+    y = blk(xg)
+    y.backward(dy.to(dev))
+    assert rel_err(y, y_ref) < 1e-4
+    assert rel_err(xg.grad, dx_ref) < 1e-3
+    for name, p in blk.named_parameters():
+        assert p.grad is not None, name
+        assert rel_err(p.grad, g_ref[name]) < 1e-3, name
+
+
+def test_g3d_backward(dev, M):
+    """All of G3d (model.py:571-597) at a reduced spatial size: every parameter's gradient and the input gradient."""
+    g = M.G3d(96)
+    sd = R.seeded_state_dict(R.g3d_shapes(96), 61, prefix="G3d.")
+    g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+    g = g.to(dev).train()
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 62)
+    dy = R.seeded_tensor((1, 96, 8, 16, 16), 63)
+    y_ref, dx_ref, g_ref = _grads_cpu(lambda t, s: R.g3d(t, s), sd, x, dy)
+    xg = x.to(dev).requires_grad_(True)
+    y = g(xg)
+    y.backward(dy.to(dev))
+    assert rel_err(y, y_ref) < 1e-4
+    assert rel_err(xg.grad, dx_ref) < 1e-3
+    worst = max((rel_err(p.grad, g_ref["G3d." + name]), name) for name, p in g.named_parameters())
+    assert worst[0] < 1e-3, worst
+
+
+def test_g3d_sgd_step_matches_cpu(dev, M):
+    """One optimizer step (train.py:323-326 pattern: zero_grad, backward, step) moves the HIP model's parameters
+    exactly where the CPU autograd step moves the oracle's."""
+    g = M.G3d(96)
+    sd = R.seeded_state_dict(R.g3d_shapes(96), 71, prefix="G3d.")
+    g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+    g = g.to(dev).train()
+    opt = torch.optim.SGD(g.parameters(), lr=1e-3)
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 72)
+    tgt = R.seeded_tensor((1, 96, 8, 16, 16), 73)
+    cpu = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    loss_ref = F.mse_loss(R.g3d(x, cpu), tgt)
+    loss_ref.backward()
+    opt.zero_grad()
+    loss = F.mse_loss(g(x.to(dev)), tgt.to(dev))
+    loss.backward()
+    opt.step()
+    assert abs(loss.item() - loss_ref.item()) < 1e-4 * abs(loss_ref.item())
+    for name, p in g.named_parameters():
+        want = cpu["G3d." + name].detach() - 1e-3 * cpu["G3d." + name].grad
+        assert rel_err(p, want) < 1e-5, name

@@ -399,6 +399,17 @@ def test_hot_slice_small_golden(dev, hot):
     assert maxabs(got, gold("hot_slice")["small16"]) < 1e-3
 
 
+def test_hot_slice_256px_config(dev, hot, sd):
+    """BASELINE config 1 (256x256 frames -> 96x16x32x32 volume): the reference's Gbase.forward trips its 512^2-only
+    assert there (model.py:1157); `forward_any_size` runs the same graph, checked against the CPU oracle."""
+    inp = R.seeded_hot_inputs(2, 41, D=16, H=32, W=32)
+    with torch.no_grad():
+        got = hot.forward_any_size(**{k: v.to(dev) for k, v in inp.items()})
+    want = R.hot_slice(sd=sd, **inp)
+    assert got.shape == (2, 96, 32, 32)
+    assert maxabs(got, want) < 1e-3
+
+
 def test_hot_slice_full_golden(dev, hot):
     """BASELINE config: 512^2 frame = 96x16x64x64 volume, reference output [1,96,64,64]."""
     g = gold("hot_slice")
@@ -441,9 +452,10 @@ def test_errors_are_loud(ops, M, dev):
         ops.warp_volume(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 3, 4, 4, 4))       # CPU tensors: no fallback
     with pytest.raises(RuntimeError):
         ops.conv3d(torch.zeros(1, 5, 4, 4, 4, device=dev), ops.PackedConv(torch.zeros(4, 6, 3, 3, 3, device=dev), None))
-    g3d = M.G3d(96).to(dev)
-    with pytest.raises(NotImplementedError):
-        g3d(torch.zeros(1, 96, 8, 8, 8, device=dev))   # autograd graph requested: forward-only path refuses
+    s2c = M.WarpGeneratorS2C(num_channels=512).to(dev)
+    with pytest.raises(NotImplementedError):               # still forward-only: refuses instead of silently detaching
+        s2c(torch.zeros(1, 3, device=dev), torch.zeros(1, 3, device=dev), torch.zeros(1, 512, device=dev),
+            torch.zeros(1, 512, device=dev))
     hot = M.GbaseHotSlice().to(dev)
     bad = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 1, D=8, H=8, W=8).items()}
     with torch.no_grad(), pytest.raises(AssertionError):
