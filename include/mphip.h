@@ -186,20 +186,35 @@ int mphip_add_matmul(const float *a, const float *a2, const float *m, const floa
 
 /* ------------------------------------------------------------------ K9  backward (training, scope row f2)
  * Gradients of the G3d building blocks as torch.autograd computes them for the reference's modules.
- * bwd-data of a conv is mphip_conv3d_fwd on the flipped/transposed weight (host side, ops.conv3d_bwd_data).
- * conv3d_bwd_weight: dW[co][ci][tap] = sum_{n,v} dY[n][co][v] * X[n][ci][v+tap]  (nn.Conv3d model.py:505-510, 591;
- *                    fp32 MFMA, split over voxels, deterministic slab reduce; dbias = sum dY, optional);
- *                    any D,H,W (1x8x8 voxel tiles, ragged edges masked); k in {1,3}.
- * groupnorm_bwd_reduce / _apply: nn.GroupNorm (+ residual + ReLU) backward (model.py:506-523).  reduce writes
- *                    s12[n][c] = (sum du, sum du*xhat), du = dy*(y>0) when relu; the caller folds them into
- *                    dgamma/dbeta and ab[n][g] = (sum_c gamma*s1, sum_c gamma*s2)/count; apply writes
- *                    dx = rstd*(gamma*du - a - xhat*b) and dres = du (dres may be NULL).  y = the forward output.
+ * grad_prep:         one pass over a conv's output gradient dy [N,C,S]: dbias[c] = sum dy (may be NULL) and
+ *                    scale[0..2] = (s, 1/s, max|dy|), s = the power of two with max|dy|*s in [2^13, 2^14) — the f16x3 kernels'
+ *                    operand scale for this tensor (scale: 4 floats of device memory).
+ * conv3d_bwd_data:   dx = conv(dy, Wt), Wt[ci][co][a][b][c] = W[co][ci][k-1-a][k-1-b][k-1-c] packed with
+ *                    mphip_pack_conv_weight (Ci/Co = channels of dy/dx); same kernels as mphip_conv3d_fwd.
+ * conv3d_bwd_weight: dW[co][ci][tap] = sum_{n,v} dY[n][co][v] * X[n][ci][v+tap]  (nn.Conv3d model.py:505-510, 591).
+ *                    precision 0: exact fp32 MFMA, any shape, k in {1,3}; precision 1: f16x3 (k=3, W%8==0).
+ *                    Split over voxels, deterministic slab reduce.
+ * groupnorm_bwd_reduce / _apply: nn.GroupNorm (+ residual + ReLU) backward (model.py:506-523).  reduce computes
+ *                    s1[n][c] = sum du, s2[n][c] = sum du*xhat (du = dy*(y>0) when relu) and folds them into
+ *                    dbeta[c] = sum_n s1, dgamma[c] = sum_n s2, ab[n][g] = (sum_c gamma*s1, sum_c gamma*s2)/count;
+ *                    apply writes dx = rstd*(gamma*du - a - xhat*b) and dres = du (dres may be NULL).
+ *                    y = the forward output (ReLU mask), stats = the forward (mean, rstd).
  * avgpool2_bwd, upsample_trilinear2_bwd: adjoints of K7 (D,H,W = dims of dx).                      */
-size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
-int mphip_conv3d_bwd_weight(const float *x, const float *dy, float *dw, float *dbias, int N, int Ci, int Co, int D,
-                            int H, int W, int k, void *workspace, size_t workspace_bytes, void *stream);
-int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats, float *s12,
-                               int N, int C, int S, int G, int relu, void *stream);
+size_t mphip_grad_prep_workspace_bytes(int N, int C, int S);
+int mphip_grad_prep(const float *dy, float *dbias, float *scale, int N, int C, int S, void *workspace,
+                    size_t workspace_bytes, void *stream);
+int mphip_conv3d_bwd_data(const float *dy, const void *wt_packed, float *dx, const float *dy_scale, int N, int Ci,
+                          int Co, int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
+                          void *stream);
+int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
+size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
+int mphip_conv3d_bwd_weight(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co,
+                            int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
+                            void *stream);
+size_t mphip_groupnorm_bwd_workspace_bytes(int N, int C, int S);
+int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats,
+                               const float *gamma, float *dgamma, float *dbeta, float *ab, int N, int C, int S, int G,
+                               int relu, void *workspace, size_t workspace_bytes, void *stream);
 int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, const float *stats,
                               const float *gamma, const float *ab, float *dx, float *dres, int N, int C, int S,
                               int G, int relu, void *stream);

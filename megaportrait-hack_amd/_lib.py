@@ -49,9 +49,14 @@ SIGNATURES = {
     "mphip_upsample_trilinear2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_nearest": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mphip_add_matmul": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
-    "mphip_conv3d_bwd_weight_workspace_bytes": (_sz, [_i] * 7),
-    "mphip_conv3d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 7 + [_p, _sz, _p]),
-    "mphip_groupnorm_bwd_reduce": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
+    "mphip_grad_prep_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mphip_grad_prep": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
+    "mphip_conv3d_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
+    "mphip_conv3d_bwd_weight_supported": (_i, [_i] * 8),
+    "mphip_conv3d_bwd_weight_workspace_bytes": (_sz, [_i] * 8),
+    "mphip_conv3d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
+    "mphip_groupnorm_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "mphip_groupnorm_bwd_reduce": (_i, [_p] * 8 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_groupnorm_bwd_apply": (_i, [_p] * 8 + [_i] * 5 + [_p]),
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),

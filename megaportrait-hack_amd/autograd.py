@@ -41,11 +41,12 @@ class Conv3dFn(torch.autograd.Function):
         conv = ctx.conv
         dy = dy.contiguous()
         k = conv.weight.shape[2]
-        dx = dw = db = None
+        dx = dw = None
+        db, scale = ops.grad_prep(dy, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3d(dy, _bwd_pack(conv))
-        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, db = ops.conv3d_bwd_weight(x, dy, k, want_bias=ctx.has_bias)
+            dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv3d_bwd_weight(x, dy, k, scale)
         return dx, dw, db, None, None
 
 

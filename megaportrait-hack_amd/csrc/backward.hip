@@ -46,15 +46,16 @@ conv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
 
     constexpr int NTAP = KS == 3 ? 3 : 1;  // taps per wave (kw = 0..2)
-    f32x16 acc[NTAP][3];
+    constexpr int MT = KS == 3 ? 3 : 1;    // co tiles per wave: k=3 -> all three, k=1 -> tile `wave`
+    const int m0 = KS == 3 ? 0 : wave;
+    f32x16 acc[NTAP][MT];
 #pragma unroll
     for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][m][r] = 0.0f;
 
-    const bool wave_active = KS == 3 || wave == 0;
     for (long tile = t_begin; tile < t_end; ++tile) {
         long r = tile;
         const int tw = (int)(r % tiles_w); r /= tiles_w;
@@ -84,14 +85,14 @@ conv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy
             xs[c * BW_XP + q] = buf_load_f(rsrc, off, 0);
         }
         __syncthreads();
-        if (wave_active) {
+        {
 #pragma unroll 4
             for (int ks = 0; ks < BW_VT / 2; ++ks) {
                 const int v = 2 * ks + kk;                 // this lane's voxel (k index of the MFMA)
                 const int vh = v / 8, vw = v % 8;
-                float a[3], b[NTAP];
+                float a[MT], b[NTAP];
 #pragma unroll
-                for (int m = 0; m < 3; ++m) a[m] = dys[(m * 32 + j) * BW_DYP + v];       // A[i=co][k=vox]
+                for (int m = 0; m < MT; ++m) a[m] = dys[((m0 + m) * 32 + j) * BW_DYP + v];  // A[i=co][k=vox]
 #pragma unroll
                 for (int t = 0; t < NTAP; ++t) {
                     const int kw = KS == 3 ? t : 1;
@@ -100,12 +101,11 @@ conv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy
 #pragma unroll
                 for (int t = 0; t < NTAP; ++t)
 #pragma unroll
-                    for (int m = 0; m < 3; ++m)
+                    for (int m = 0; m < MT; ++m)
                         acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[t], acc[t][m], 0, 0, 0);
             }
         }
     }
-    if (!wave_active) return;
     // slab layout = OIDHW gradient [Co][Ci][taps]; C/D: col = lane&31 = ci, row = co
     constexpr int TAPS = KS * KS * KS;
     float *slab = slabs + (size_t)blockIdx.z * Co * Ci * TAPS;
@@ -114,10 +114,10 @@ conv_bwd_weight_kernel(const float *__restrict__ x, const float *__restrict__ dy
     for (int t = 0; t < NTAP; ++t) {
         const int tap = KS == 3 ? (kd * 3 + kh) * 3 + t : 0;
 #pragma unroll
-        for (int m = 0; m < 3; ++m)
+        for (int m = 0; m < MT; ++m)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
+                const int co = co0 + (m0 + m) * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kk;
                 if (co < Co && ci < Ci) slab[((size_t)co * Ci + ci) * TAPS + tap] = acc[t][m][reg];
             }
     }
@@ -130,53 +130,48 @@ slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, siz
     out[i] = sum_slabs(slabs, splits, n, i);
 }
 
-// per-channel sum over (n, voxels):  db[c] = sum dy[n][c][:]   (one workgroup per channel)
-__global__ void __launch_bounds__(256)
-channel_sum_kernel(const float *__restrict__ dy, float *__restrict__ out, int N, int C, int S) {
-    const int c = blockIdx.x;
-    double acc = 0.0;
-    for (int n = 0; n < N; ++n) {
-        const float *p = dy + ((size_t)n * C + c) * S;
-        float s = 0.0f;
-        for (int i = threadIdx.x; i < S; i += 256) s += p[i];
-        acc += (double)s;
-    }
-#pragma unroll
-    for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
-    __shared__ double red[4];
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) out[c] = (float)((red[0] + red[1]) + (red[2] + red[3]));
-}
-
 // ---------------------------------------------------------------------------------------------------
 // GroupNorm (+residual, +ReLU) backward.  Forward: xh = (x-mean)*rstd; z = xh*gamma+beta; u = z (+res); y = relu(u).
 // Pass 1 (one workgroup per (n,c) plane): du = dy * (y > 0) [no mask when relu == 0];
 //         s1[n,c] = sum du, s2[n,c] = sum du*xh.
 // (host, tiny [N,C] tensors: dbeta = sum_n s1, dgamma = sum_n s2, A[n,g] = sum_c gamma_c*s1/cnt, B[n,g] = sum_c gamma_c*s2/cnt)
 // Pass 2: dx = rstd * (gamma_c*du - A - xh*B);  dres = du.
+constexpr int GNB_CHUNK = 8192;  // floats per workgroup of the reduce pass
 __global__ void __launch_bounds__(256)
 gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
-                     const float *__restrict__ stats, float *__restrict__ s12, int C, int cpg, int S, int relu) {
-    const int plane = blockIdx.x;  // n*C + c
+                     const float *__restrict__ stats, float *__restrict__ partial, int C, int cpg, int S, int relu, int chunks) {
+    const int plane = blockIdx.x / chunks, chunk = blockIdx.x % chunks;  // plane = n*C + c
     const int c = plane % C, n = plane / C;
     const int grp = n * (C / cpg) + c / cpg;
     const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
     const size_t base = (size_t)plane * S;
+    const int begin = chunk * GNB_CHUNK, end = min(S, begin + GNB_CHUNK);
     float s1 = 0.0f, s2 = 0.0f;
-    double d1 = 0.0, d2 = 0.0;
-    int cnt = 0;
-    for (int i = threadIdx.x; i < S; i += 256) {
-        float du = dy[base + i];
-        if (relu && !(y[base + i] > 0.0f)) du = 0.0f;
-        const float xh = (x[base + i] - mean) * rstd;
-        s1 += du;
-        s2 += du * xh;
-        if (++cnt == 64) {  // fp32 partials over 64 elements, combined in double
-            d1 += (double)s1; d2 += (double)s2; s1 = s2 = 0.0f; cnt = 0;
+    if ((S & 3) == 0) {
+        for (int i = begin + threadIdx.x * 4; i < end; i += 1024) {
+            const float4 g = *reinterpret_cast<const float4 *>(dy + base + i);
+            const float4 xv = *reinterpret_cast<const float4 *>(x + base + i);
+            float du[4] = {g.x, g.y, g.z, g.w};
+            if (relu) {
+                const float4 yv = *reinterpret_cast<const float4 *>(y + base + i);
+                if (!(yv.x > 0.0f)) du[0] = 0.0f;
+                if (!(yv.y > 0.0f)) du[1] = 0.0f;
+                if (!(yv.z > 0.0f)) du[2] = 0.0f;
+                if (!(yv.w > 0.0f)) du[3] = 0.0f;
+            }
+            const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
+            s1 += (du[0] + du[1]) + (du[2] + du[3]);
+            s2 += (du[0] * xh[0] + du[1] * xh[1]) + (du[2] * xh[2] + du[3] * xh[3]);
+        }
+    } else {
+        for (int i = begin + threadIdx.x; i < end; i += 256) {
+            float du = dy[base + i];
+            if (relu && !(y[base + i] > 0.0f)) du = 0.0f;
+            s1 += du;
+            s2 += du * ((x[base + i] - mean) * rstd);
         }
     }
-    d1 += (double)s1; d2 += (double)s2;
+    double d1 = (double)s1, d2 = (double)s2;  // <= 32 fp32 terms per thread, combined in double
 #pragma unroll
     for (int sft = 32; sft >= 1; sft >>= 1) {
         d1 += __shfl_xor(d1, sft, 64);
@@ -189,8 +184,48 @@ gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, c
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        s12[plane * 2] = (float)((red[0] + red[2]) + (red[4] + red[6]));
-        s12[plane * 2 + 1] = (float)((red[1] + red[3]) + (red[5] + red[7]));
+        partial[(size_t)blockIdx.x * 2] = (float)((red[0] + red[2]) + (red[4] + red[6]));
+        partial[(size_t)blockIdx.x * 2 + 1] = (float)((red[1] + red[3]) + (red[5] + red[7]));
+    }
+}
+
+// folds the partial sums (one workgroup): s12[n][c] = sum over chunks; dgamma[c] = sum_n s2, dbeta[c] = sum_n s1;
+// ab[n][g] = (sum_{c in g} gamma_c*s1, sum_{c in g} gamma_c*s2) / (cpg*S)
+__global__ void __launch_bounds__(1024)
+gn_bwd_fold_kernel(const float *__restrict__ partial, const float *__restrict__ gamma, float *__restrict__ s12,
+                   float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ ab, int N, int C, int cpg, int S,
+                   int chunks) {
+    for (int p = threadIdx.x; p < N * C; p += 1024) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < chunks; ++k) {
+            a += (double)partial[((size_t)p * chunks + k) * 2];
+            b += (double)partial[((size_t)p * chunks + k) * 2 + 1];
+        }
+        s12[p * 2] = (float)a;
+        s12[p * 2 + 1] = (float)b;
+    }
+    __syncthreads();  // one workgroup: its own global writes are visible after the barrier
+    for (int c = threadIdx.x; c < C; c += 1024) {
+        double a = 0.0, b = 0.0;
+        for (int n = 0; n < N; ++n) {
+            a += (double)s12[(n * C + c) * 2];
+            b += (double)s12[(n * C + c) * 2 + 1];
+        }
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+    }
+    const int G = C / cpg;
+    const double inv = 1.0 / ((double)cpg * (double)S);
+    for (int q = threadIdx.x; q < N * G; q += 1024) {
+        const int n = q / G, g = q % G;
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            const int c = g * cpg + k;
+            a += (double)gamma[c] * (double)s12[(n * C + c) * 2];
+            b += (double)gamma[c] * (double)s12[(n * C + c) * 2 + 1];
+        }
+        ab[q * 2] = (float)(a * inv);
+        ab[q * 2 + 1] = (float)(b * inv);
     }
 }
 
@@ -226,27 +261,33 @@ avgpool2_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int 
 }
 
 // nn.Upsample(x2, trilinear, align_corners=True) backward (adjoint of upsample_trilinear2): each input voxel
-// gathers, per axis, the <= 4 outputs whose source interval touches it, with the forward's own weights
+// gathers, per axis, the <= 5 outputs whose source interval touches it, with the forward's own weights
 // (deterministic, no atomics).  dx[i] = sum_o w(o,i) * dout[o].
-__device__ __forceinline__ int adj_range(int i, int in, float scale, int out, int &lo) {
-    // outputs o with i0(o) == i or i1(o) == i satisfy  i-1 < scale*o < i+1
-    if (!(scale > 0.0f)) {
-        lo = 0;
-        return out - 1;
+// per-axis adjoint taps of input index i: the outputs o with i0(o) == i or i1(o) == i lie in
+// ((i-1)/scale, (i+1)/scale): <= 5 consecutive o (scale ~ 1/2; 6 slots: one spare for rounding of the bound);
+// w[k] = the forward's weight of (lo+k -> i), 0 if none
+struct AdjTaps {
+    int lo;
+    float w[6];
+};
+__device__ __forceinline__ AdjTaps adj_taps(int i, int in, float scale, int out) {
+    AdjTaps t;
+    t.lo = scale > 0.0f ? max(0, (int)floorf(((float)i - 1.0f) / scale)) : 0;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const int o = t.lo + k;
+        float w = 0.0f;
+        if (o < out) {
+            const float src = scale * (float)o;
+            const int i0 = min((int)src, in - 1);
+            const int i1 = i0 + (i0 < in - 1 ? 1 : 0);
+            const float l1 = src - (float)i0, l0 = 1.0f - l1;
+            if (i0 == i) w += l0;
+            if (i1 == i) w += l1;
+        }
+        t.w[k] = w;
     }
-    lo = max(0, (int)floorf(((float)i - 1.0f) / scale) - 1);
-    int hi = min(out - 1, (int)ceilf(((float)i + 1.0f) / scale) + 1);
-    return hi;
-}
-__device__ __forceinline__ float adj_weight(int o, int i, int in, float scale) {
-    float src = scale * (float)o;
-    int i0 = min((int)src, in - 1);
-    int i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    float l1 = src - (float)i0, l0 = 1.0f - l1;
-    float w = 0.0f;
-    if (i0 == i) w += l0;
-    if (i1 == i) w += l1;
-    return w;
+    return t;
 }
 __global__ void __launch_bounds__(256)
 upsample_trilinear2_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, float sD,
@@ -260,20 +301,24 @@ upsample_trilinear2_bwd_kernel(const float *__restrict__ dout, float *__restrict
     const int d = (int)(r % D);
     const size_t plane = r / D;
     const int oD = 2 * D, oH = 2 * H, oW = 2 * W;
-    int dlo, hlo, wlo;
-    const int dhi = adj_range(d, D, sD, oD, dlo), hhi = adj_range(h, H, sH, oH, hlo), whi = adj_range(w, W, sW, oW, wlo);
+    const AdjTaps td = adj_taps(d, D, sD, oD), th = adj_taps(h, H, sH, oH), tw = adj_taps(w, W, sW, oW);
     const float *p = dout + plane * (size_t)oD * oH * oW;
     float acc = 0.0f;
-    for (int od = dlo; od <= dhi; ++od) {
-        const float wd = adj_weight(od, d, D, sD);
-        if (wd == 0.0f) continue;
-        for (int oh = hlo; oh <= hhi; ++oh) {
-            const float wh = adj_weight(oh, h, H, sH);
-            if (wh == 0.0f) continue;
-            float row = 0.0f;
-            for (int ow = wlo; ow <= whi; ++ow) row += adj_weight(ow, w, W, sW) * p[((size_t)od * oH + oh) * oW + ow];
-            acc += wd * wh * row;
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        if (td.w[a] == 0.0f) continue;
+        float pl = 0.0f;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+            if (th.w[b] == 0.0f) continue;
+            const float *row = p + ((size_t)(td.lo + a) * oH + th.lo + b) * oW + tw.lo;
+            float rs = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 6; ++c)
+                if (tw.w[c] != 0.0f) rs += tw.w[c] * row[c];
+            pl += th.w[b] * rs;
         }
+        acc += td.w[a] * pl;
     }
     dx[t] = acc;
 }
@@ -288,25 +333,37 @@ static int bw_splits(long ntiles, int blocks_xy) {
     return s;
 }
 
-extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k) {
+extern "C" int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (N <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0 || (k != 1 && k != 3)) return 0;
+    if (precision == 0) return 1;
+    return precision == 1 && bwd_weight_f16x3_supported(N, Ci, Co, D, H, W, k);
+}
+
+extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    if (!mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    if (precision == 1) return bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W);
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int bxy = ((Ci + 31) / 32) * ((Co + 95) / 96) * (k == 3 ? 3 : 1);
     return (size_t)bw_splits(ntiles, bxy) * Co * Ci * k * k * k * sizeof(float);
 }
 
-extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, float *dw, float *dbias, int N, int Ci, int Co,
-                                       int D, int H, int W, int k, void *workspace, size_t workspace_bytes, void *stream) {
+extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co,
+                                       int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
+                                       void *stream) {
     MPHIP_REQUIRE(x && dy && dw, "conv3d_bwd_weight: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3), "conv3d_bwd_weight: bad dims");
+    MPHIP_REQUIRE(mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision),
+                  "conv3d_bwd_weight: precision %d not available for this shape (query mphip_conv3d_bwd_weight_supported)", precision);
+    MPHIP_REQUIRE(precision == 0 || dy_scale, "conv3d_bwd_weight: the f16x3 kernel needs the gradient scale of mphip_grad_prep");
     const size_t x_bytes = (size_t)N * Ci * D * H * W * sizeof(float);
     MPHIP_REQUIRE(x_bytes < 0x80000000ull, "conv3d_bwd_weight: input exceeds the 2 GiB buffer-addressing limit");
-    const size_t need = mphip_conv3d_bwd_weight_workspace_bytes(N, Ci, Co, D, H, W, k);
+    const size_t need = mphip_conv3d_bwd_weight_workspace_bytes(N, Ci, Co, D, H, W, k, precision);
     if (!workspace || workspace_bytes < need) {
         set_error("conv3d_bwd_weight: workspace %zu bytes < required %zu", workspace_bytes, need);
         return MPHIP_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (precision == 1) return bwd_weight_f16x3_launch(x, dy, dy_scale, dw, N, Ci, Co, D, H, W, workspace, s);
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;
     const int splits = bw_splits(ntiles, ci_tiles * co_tiles * (k == 3 ? 3 : 1));
@@ -320,16 +377,30 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, float *d
                            (unsigned)x_bytes);
     const size_t nw = (size_t)Co * Ci * k * k * k;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float *)workspace, dw, nw, splits);
-    if (dbias) hipLaunchKernelGGL(channel_sum_kernel, dim3(Co), dim3(256), 0, s, dy, dbias, N, Co, D * H * W);
     return check_launch("conv3d_bwd_weight");
 }
 
-extern "C" int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats, float *s12,
-                                          int N, int C, int S, int G, int relu, void *stream) {
-    MPHIP_REQUIRE(x && dy && stats && s12 && (!relu || y), "groupnorm_bwd_reduce: null pointer");
+extern "C" size_t mphip_groupnorm_bwd_workspace_bytes(int N, int C, int S) {
+    return N > 0 && C > 0 && S > 0 ? ((size_t)N * C * cdiv(S, GNB_CHUNK) * 2 + (size_t)N * C * 2) * sizeof(float) : 0;
+}
+
+extern "C" int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats,
+                                          const float *gamma, float *dgamma, float *dbeta, float *ab, int N, int C, int S, int G,
+                                          int relu, void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(x && dy && stats && gamma && dgamma && dbeta && ab && (!relu || y), "groupnorm_bwd_reduce: null pointer");
     MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd_reduce: bad dims");
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, s12, C, C / G, S,
-                       relu);
+    const size_t need = mphip_groupnorm_bwd_workspace_bytes(N, C, S);
+    if (!workspace || workspace_bytes < need) {
+        set_error("groupnorm_bwd_reduce: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    const int chunks = cdiv(S, GNB_CHUNK);
+    float *partial = (float *)workspace, *s12 = partial + (size_t)N * C * chunks * 2;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C * chunks), dim3(256), 0, s, x, y, dy, stats, partial, C, C / G, S, relu,
+                       chunks);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(1), dim3(1024), 0, s, (const float *)partial, gamma, s12, dgamma, dbeta, ab, N, C,
+                       C / G, S, chunks);
     return check_launch("groupnorm_bwd_reduce");
 }
 

@@ -5,14 +5,15 @@ set -euo pipefail
 here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 out="${1:-$here/../libmphip.so}"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=default -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -fvisibility=default -Wall -Wno-unused-function ${MPHIP_EXTRA_FLAGS:-}"
 objs=()
 pids=()
-mkdir -p "$here/build"
-for f in api warp norm conv3d conv3d_f16x3 backward; do
-  "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$here/build/$f.o" &
+bdir="${MPHIP_BUILD_DIR:-$here/build}"
+mkdir -p "$bdir"
+for f in api warp norm conv3d conv3d_f16x3 backward conv3d_bwd_f16x3; do
+  "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$bdir/$f.o" &
   pids+=($!)
-  objs+=("$here/build/$f.o")
+  objs+=("$bdir/$f.o")
 done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}"

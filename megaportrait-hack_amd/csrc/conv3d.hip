@@ -521,7 +521,7 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
     }
 }
 
-static int conv3d_run(const float *x, const float *in_affine, int in_relu, const void *w_packed, const float *bias, float *y,
+static int conv3d_run(const float *x, const float *in_affine, int in_relu, const float *x_scale, const void *w_packed, const float *bias, float *y,
                       float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                       size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
@@ -563,7 +563,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
     if (precision == 1) {
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, s);
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_scale, s);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -593,7 +593,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
 extern "C" int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
                                 int Co, int D, int H, int W, int k, int precision, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-    return conv3d_run(x, nullptr, 0, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, nullptr, 0, nullptr, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }
 
@@ -604,7 +604,7 @@ extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, i
 
 extern "C" int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bias, float *out, int N, int Ci,
                                       int Co, int D, int H, int W, int k, int precision, void *stream) {
-    return conv3d_run(x, nullptr, 0, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, nullptr, 0, stream);
+    return conv3d_run(x, nullptr, 0, nullptr, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, nullptr, 0, stream);
 }
 
 extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
@@ -619,7 +619,7 @@ extern "C" int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const f
     MPHIP_REQUIRE(gn_stats, "conv3d_gn_fwd: null stats pointer");
     MPHIP_REQUIRE(gn_groups > 0 && Co > 0 && Co % gn_groups == 0, "conv3d_gn_fwd: Co=%d not divisible into %d groups", Co,
                   gn_groups);
-    return conv3d_run(x, nullptr, 0, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, nullptr, 0, nullptr, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }
 
@@ -627,6 +627,17 @@ extern "C" int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, int
                                      const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
                                      int precision, void *workspace, size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(in_affine, "conv3d_gnin_fwd: null affine table");
-    return conv3d_run(x, in_affine, in_relu, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision,
+    return conv3d_run(x, in_affine, in_relu, nullptr, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision,
                       workspace, workspace_bytes, stream);
+}
+
+// bwd-data of a conv = the forward conv of dy with the flipped / transposed weight (packed by the caller from
+// Wt[ci][co][a][b][c] = W[co][ci][k-1-a][k-1-b][k-1-c]); dy_scale (from mphip_grad_prep) gives the f16x3 kernel the
+// gradient's own power-of-two scale instead of the activations' fixed one.  Ci/Co here are dy's / dx's channels.
+extern "C" int mphip_conv3d_bwd_data(const float *dy, const void *wt_packed, float *dx, const float *dy_scale, int N, int Ci,
+                                     int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                     size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(precision == 0 || dy_scale, "conv3d_bwd_data: the f16x3 kernel needs the gradient scale of mphip_grad_prep");
+    return conv3d_run(dy, nullptr, 0, precision == 1 ? dy_scale : nullptr, wt_packed, nullptr, dx, nullptr, 0, 0.0f, false, N, Ci,
+                      Co, D, H, W, k, precision, workspace, workspace_bytes, stream);
 }

@@ -20,6 +20,8 @@
 //   C/D: col j = lane&31 (voxel), row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (co)
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "mphip_common.h"
 #include "mphip_conv.h"
 
@@ -51,7 +53,12 @@ __global__ void f16x3_absmax_kernel(const float *__restrict__ w, size_t n, unsig
         m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
-    if ((threadIdx.x & 63) == 0) atomicMax(hdr + 2, __float_as_uint(m));  // non-negative floats order like uints
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    // one atomic per workgroup (same-address atomics serialise in L2: they, not the read, set this kernel's time)
+    if (threadIdx.x == 0)
+        atomicMax(hdr + 2, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));  // non-negative floats order like uints
 }
 
 __device__ __forceinline__ float weight_scale(unsigned maxbits) {
@@ -98,8 +105,12 @@ template <int TD, int TH, int TW, int NWAVES, int GS>
 __global__ void __launch_bounds__(NWAVES * 64)
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
-                       int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu) {
+                       int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
+                       const float *__restrict__ x_scale_p) {
     constexpr int MT = 3, KC = F16X3_KC;
+    // activation scale: the fixed X_SCALE for forward activations; a per-tensor power of two from mphip_grad_prep
+    // when the input is a gradient (bwd-data), whose magnitude is arbitrary
+    const float x_scale = x_scale_p ? x_scale_p[0] : X_SCALE;
     constexpr int TVOX = TD * TH * TW;
     constexpr int NTHR = NWAVES * 64;
     constexpr int NT = TVOX / (32 * NWAVES);          // 32-voxel column tiles per wave
@@ -197,8 +208,8 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
                     }                                                                             \
                 }                                                                                 \
                 _Float16 h0_, l0_, h1_, l1_;                                                      \
-                split_f16(v0_ * X_SCALE, h0_, l0_);                                               \
-                split_f16(v1_ * X_SCALE, h1_, l1_);                                               \
+                split_f16(v0_ * x_scale, h0_, l0_);                                               \
+                split_f16(v1_ * x_scale, h1_, l1_);                                               \
                 half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                        \
                 *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                     \
                 *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                            \
@@ -331,7 +342,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 
     const bool direct = gridDim.z == 1;
     float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
-    const float unscale = whdr[0] * (1.0f / X_SCALE);
+    const float unscale = whdr[0] * (x_scale_p ? x_scale_p[1] : 1.0f / X_SCALE);
     const int co0 = cot * F16X3_COT;
     float bv[MT][16];
 #pragma unroll
@@ -395,14 +406,14 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, hipStream_t s) {
         return MPHIP_ELAUNCH;
     }
     const size_t n = (size_t)Co * Ci * 27;
-    hipLaunchKernelGGL(f16x3_absmax_kernel, dim3(512), dim3(256), 0, s, w, n, hdr);
+    hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(256, (n + 8191) / 8192)), dim3(256), 0, s, w, n, hdr);
     hipLaunchKernelGGL(f16x3_pack_kernel, dim3(2048), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), (const unsigned *)hdr,
                        (float *)out, Co, Ci);
     return check_launch("pack_conv_weight(f16x3)");
 }
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, const float *in_affine, int in_relu, hipStream_t s) {
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s) {
     if (in_affine && Ci > 768) {
         set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
         return MPHIP_EINVAL;
@@ -412,13 +423,13 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
     if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
     else if (p.td == 4)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
     else
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
     return check_launch("conv3d_fwd(f16x3)");
 }
 

@@ -498,23 +498,60 @@ def add_matmul(a: torch.Tensor, a2: Optional[torch.Tensor], m: torch.Tensor, bia
 
 
 # ------------------------------------------------------------------ K9  backward (scope row f2)
-def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, want_bias: bool = True):
-    """(dW [Co,Ci,k,k,k], dbias [Co] or None) of y = conv3d(x, W, b, padding=k//2) given dy."""
+def grad_prep(dy: torch.Tensor, want_bias: bool = True):
+    """One pass over a conv's output gradient: (dbias [C] or None, scale) — `scale` is the device-side power-of-two
+    operand scale the f16x3 backward kernels use for this tensor."""
+    dy = _req(dy, "dy")
+    n, c = dy.shape[0], dy.shape[1]
+    s = dy.numel() // (n * c)
+    scale = torch.empty(4, dtype=torch.float32, device=dy.device)
+    db = torch.empty(c, dtype=torch.float32, device=dy.device) if want_bias else None
+    lib = _lib.load()
+    ws = torch.empty(lib.mphip_grad_prep_workspace_bytes(n, c, s) // 4, dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mphip_grad_prep(_ptr(dy), _ptr(db), _ptr(scale), n, c, s, _ptr(ws), ws.numel() * 4, _stream()),
+               "mphip_grad_prep")
+    return db, scale
+
+
+def conv3d_bwd_data(dy: torch.Tensor, pc_t: "PackedConv", dy_scale: torch.Tensor, precision: Optional[int] = None) -> torch.Tensor:
+    """dx of y = conv3d(x, W): the forward kernels on the flipped/transposed weight `pc_t` (conv_bwd_data_weight)."""
+    dy = _req(dy, "dy")
+    n, ci, d, h, w = dy.shape
+    if ci != pc_t.ci:
+        raise RuntimeError(f"conv3d_bwd_data: dy {tuple(dy.shape)} does not match Co={pc_t.ci}")
+    lib = _lib.load()
+    prec = _default_precision if precision is None else precision
+    if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc_t.co, d, h, w, pc_t.k, prec):
+        prec = 0
+    wp = pc_t.packed(prec)
+    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc_t.co, d, h, w, pc_t.k, prec)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=dy.device) if ws_bytes else None
+    dx = torch.empty((n, pc_t.co, d, h, w), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.mphip_conv3d_bwd_data(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(dy_scale), n, ci, pc_t.co, d, h, w, pc_t.k, prec,
+                                         _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_bwd_data")
+    return dx
+
+
+def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, dy_scale: Optional[torch.Tensor] = None,
+                      precision: Optional[int] = None) -> torch.Tensor:
+    """dW [Co,Ci,k,k,k] of y = conv3d(x, W, b, padding=k//2) given dy.  precision 1 (f16x3) needs dy_scale (grad_prep)."""
     x, dy = _req(x, "x"), _req(dy, "dy")
     n, ci, d, h, w = x.shape
     co = dy.shape[1]
     if tuple(dy.shape) != (n, co, d, h, w):
         raise RuntimeError(f"conv3d_bwd_weight: dy {tuple(dy.shape)} does not match x {tuple(x.shape)}")
     lib = _lib.load()
-    ws_bytes = lib.mphip_conv3d_bwd_weight_workspace_bytes(n, ci, co, d, h, w, k)
+    prec = _default_precision if precision is None else precision
+    if prec != 0 and (dy_scale is None or not lib.mphip_conv3d_bwd_weight_supported(n, ci, co, d, h, w, k, prec)):
+        prec = 0  # the exact fp32 kernel covers every shape
+    ws_bytes = lib.mphip_conv3d_bwd_weight_workspace_bytes(n, ci, co, d, h, w, k, prec)
     if ws_bytes == 0:
         raise RuntimeError(f"conv3d_bwd_weight: unsupported shape {tuple(x.shape)} k={k}")
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.device)
-    db = torch.empty((co,), dtype=torch.float32, device=x.device) if want_bias else None
-    _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dw), _ptr(db), n, ci, co, d, h, w, k, _ptr(ws), ws_bytes,
-                                           _stream()), "mphip_conv3d_bwd_weight")
-    return dw, db
+    _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dy_scale), _ptr(dw), n, ci, co, d, h, w, k, prec, _ptr(ws),
+                                           ws_bytes, _stream()), "mphip_conv3d_bwd_weight")
+    return dw
 
 
 def conv_bwd_data_weight(weight: torch.Tensor) -> torch.Tensor:
@@ -531,12 +568,14 @@ def groupnorm_bwd(x, y, dy, stats, gamma, groups: int, relu: bool, want_res: boo
     cpg = c // groups
     lib = _lib.load()
     gamma = _req(gamma.detach(), "gamma")
-    s12 = torch.empty((n, c, 2), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(s12), n, c, s, groups, int(relu),
-                                              _stream()), "mphip_groupnorm_bwd_reduce")
-    dbeta = s12[:, :, 0].sum(0)
-    dgamma = s12[:, :, 1].sum(0)
-    ab = ((s12 * gamma.view(1, c, 1)).view(n, groups, cpg, 2).sum(2) / float(cpg * s)).contiguous()
+    ws_bytes = lib.mphip_groupnorm_bwd_workspace_bytes(n, c, s)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
+    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
+    ab = torch.empty((n * groups, 2), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
+                                              _ptr(ab), n, c, s, groups, int(relu), _ptr(ws), ws_bytes, _stream()),
+               "mphip_groupnorm_bwd_reduce")
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_res else None
     _lib.check(lib.mphip_groupnorm_bwd_apply(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(ab), _ptr(dx), _ptr(dres),

@@ -46,31 +46,42 @@ def rel_err(got, want):
     (1, 192, 96, 4, 8, 8, 1),      # 1x1x1 shortcut
     (3, 768, 384, 2, 4, 4, 3),     # deepest level of the 256px configuration (4x4 maps)
 ])
-def test_conv3d_bwd_weight(dev, ops, shape):
+@pytest.mark.parametrize("dy_mag", [1.0, 3e-8, 5e4])
+def test_conv3d_bwd_weight(dev, ops, shape, dy_mag):
+    """Both arithmetic paths (exact fp32 MFMA; f16x3 where its tiling applies) for gradients of any magnitude:
+    the f16x3 kernels scale dy by its own power of two (grad_prep), so 1e-8-sized gradients keep fp32-class accuracy."""
     n, ci, co, d, h, w, k = shape
-    x = R.seeded_tensor((n, ci, d, h, w), 11)
-    dy = R.seeded_tensor((n, co, d, h, w), 12)
+    x = R.seeded_tensor((n, ci, d, h, w), 11, scale=1.5)
+    dy = R.seeded_tensor((n, co, d, h, w), 12) * dy_mag
     wt = R.seeded_tensor((co, ci, k, k, k), 13, scale=0.05).requires_grad_(True)
     b = torch.zeros(co, requires_grad=True)
     F.conv3d(x, wt, b, padding=k // 2).backward(dy)
-    dw, db = ops.conv3d_bwd_weight(x.to(dev), dy.to(dev), k)
+    db, scale = ops.grad_prep(dy.to(dev))
+    assert rel_err(db, b.grad) < 2e-5
+    s = scale[0].item()
+    assert 2.0 ** 13 <= dy.abs().max().item() * s < 2.0 ** 14 and s == 2.0 ** round(__import__("math").log2(s))
+    dw = ops.conv3d_bwd_weight(x.to(dev), dy.to(dev), k, precision=0)
     assert dw.shape == wt.shape
     assert rel_err(dw, wt.grad) < 2e-5     # exact fp32 products, fp32 accumulation in a different order
-    assert rel_err(db, b.grad) < 2e-5
+    dw = ops.conv3d_bwd_weight(x.to(dev), dy.to(dev), k, scale, precision=1)
+    assert rel_err(dw, wt.grad) < 2e-5     # f16x3 (falls back to the fp32 kernel where unsupported)
 
 
 @pytest.mark.parametrize("shape", [(2, 96, 96, 4, 16, 16, 3), (1, 192, 96, 2, 8, 8, 3), (1, 96, 192, 4, 8, 8, 1),
                                    (1, 40, 24, 3, 5, 7, 3)])
-def test_conv3d_bwd_data(dev, ops, shape):
-    """bwd-data = the forward conv on the flipped / transposed weight."""
+@pytest.mark.parametrize("dy_mag", [1.0, 3e-8, 5e4])
+def test_conv3d_bwd_data(dev, ops, shape, dy_mag):
+    """bwd-data = the forward conv on the flipped / transposed weight, with the gradient's own operand scale."""
     n, ci, co, d, h, w, k = shape
     x = R.seeded_tensor((n, ci, d, h, w), 21).requires_grad_(True)
-    dy = R.seeded_tensor((n, co, d, h, w), 22)
+    dy = R.seeded_tensor((n, co, d, h, w), 22) * dy_mag
     wt = R.seeded_tensor((co, ci, k, k, k), 23, scale=0.05)
     F.conv3d(x, wt, None, padding=k // 2).backward(dy)
     pc = ops.PackedConv(ops.conv_bwd_data_weight(wt.to(dev)), None)
-    dx = ops.conv3d(dy.to(dev), pc)
-    assert rel_err(dx, x.grad) < 1e-4
+    _, scale = ops.grad_prep(dy.to(dev), want_bias=False)
+    for prec in (0, 1):
+        dx = ops.conv3d_bwd_data(dy.to(dev), pc, scale, precision=prec)
+        assert rel_err(dx, x.grad) < 2e-5
 
 
 @pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, False)])
