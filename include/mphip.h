@@ -198,7 +198,12 @@ int mphip_add_matmul(const float *a, const float *a2, const float *m, const floa
  *                    s1[n][c] = sum du, s2[n][c] = sum du*xhat (du = dy*(y>0) when relu) and folds them into
  *                    dbeta[c] = sum_n s1, dgamma[c] = sum_n s2, ab[n][g] = (sum_c gamma*s1, sum_c gamma*s2)/count;
  *                    apply writes dx = rstd*(gamma*du - a - xhat*b) and dres = du (dres may be NULL).
- *                    y = the forward output (ReLU mask), stats = the forward (mean, rstd).
+ *                    y = the forward output (activation mask), stats = the forward (mean, rstd).
+ *                    act: 0 none, 1 ReLU, 2 tanh(ReLU(.)) (model.py:462-465).  w2 (may be NULL) = AdaptiveGroupNorm's
+ *                    second affine (model.py:314-316): gamma_eff = gamma*w2, and dw2/db2 are produced.
+ * upsample_nearest_bwd: adjoint of mphip_upsample_nearest (D,H,W = dims of dx).
+ * small_gemm:        out[m][n] = sum_k (a[m*sam+k*sak] (+a2)) * b[k*sbk+n*sbn] (+bias[n]) — the generators' dense heads
+ *                    ((z+e)@Gamma, the 1x1 conv on a 1x1 map) and their gradients; strides in elements.
  * avgpool2_bwd, upsample_trilinear2_bwd: adjoints of K7 (D,H,W = dims of dx).                      */
 size_t mphip_grad_prep_workspace_bytes(int N, int C, int S);
 int mphip_grad_prep(const float *dy, float *dbias, float *scale, int N, int C, int S, void *workspace,
@@ -213,13 +218,41 @@ int mphip_conv3d_bwd_weight(const float *x, const float *dy, const float *dy_sca
                             void *stream);
 size_t mphip_groupnorm_bwd_workspace_bytes(int N, int C, int S);
 int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats,
-                               const float *gamma, float *dgamma, float *dbeta, float *ab, int N, int C, int S, int G,
-                               int relu, void *workspace, size_t workspace_bytes, void *stream);
+                               const float *gamma, const float *beta, const float *w2, float *dgamma, float *dbeta,
+                               float *dw2, float *db2, float *ab, int N, int C, int S, int G, int act,
+                               void *workspace, size_t workspace_bytes, void *stream);
 int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, const float *stats,
-                              const float *gamma, const float *ab, float *dx, float *dres, int N, int C, int S,
-                              int G, int relu, void *stream);
+                              const float *gamma, const float *w2, const float *ab, float *dx, float *dres, int N,
+                              int C, int S, int G, int act, void *stream);
 int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
 int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
+int mphip_upsample_nearest_bwd(const float *dout, float *dx, int NC, int D, int H, int W, int sD, int sH, int sW,
+                               void *stream);
+int mphip_small_gemm(const float *a, const float *a2, const float *b, const float *bias, float *out, int M, int N,
+                     int K, long sam, long sak, long sbk, long sbn, void *stream);
+
+/* ------------------------------------------------------------------ K10  backward of K0-K3 (training, row f2)
+ * warp_coords:            the coordinate pass of K2/K3 alone: coords[B,D,H,W,3] (clipped x,y,z sample positions).
+ * warp_volume_bwd:        backward of mphip_warp_volume (dsum=0) / mphip_warp_volume_dsum (dsum=1; dout is [B,C,H,W]):
+ *                         dv [B,C,D,H,W] (scatter with hardware fp32 atomics, like the reference's grid_sample
+ *                         backward) and dfield [B,3,fD,fH,fW] (ATen rule: clipped coordinates pass no gradient;
+ *                         then the adjoint of the align_corners=True resize, model.py:1036).  Either may be NULL.
+ * warp_field_compose_bwd: dtheta [B,3,4] (F.affine_grid backward) and dem [B,3,eD,eH,eW] (adjoint of the
+ *                         align_corners=False resize, model.py:971-973) from dw [B,3,G,G,G].  Either may be NULL.
+ * rt_theta_bwd:           (drot [B,3] in degrees, dtr [B,3]) from dtheta through the rotation composition and,
+ *                         if invert, the matrix inverse (model.py:790-801, 811-856).                        */
+int mphip_warp_coords(const float *field, const float *lin_d, const float *lin_h, const float *lin_w, float *coords,
+                      int B, int D, int H, int W, int fD, int fH, int fW, void *stream);
+size_t mphip_warp_volume_bwd_workspace_bytes(int B, int C, int D, int H, int W);
+int mphip_warp_volume_bwd(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                          const float *lin_w, const float *dout, float *dv, float *dfield, int B, int C, int D, int H,
+                          int W, int fD, int fH, int fW, int dsum, void *workspace, size_t workspace_bytes,
+                          void *stream);
+size_t mphip_warp_field_compose_bwd_workspace_bytes(int B, int G);
+int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *dtheta, float *dem, int B, int eD,
+                                 int eH, int eW, int G, void *workspace, size_t workspace_bytes, void *stream);
+int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
+                       int invert, void *stream);
 
 #ifdef __cplusplus
 }

@@ -56,8 +56,16 @@ SIGNATURES = {
     "mphip_conv3d_bwd_weight_workspace_bytes": (_sz, [_i] * 8),
     "mphip_conv3d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
     "mphip_groupnorm_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
-    "mphip_groupnorm_bwd_reduce": (_i, [_p] * 8 + [_i] * 5 + [_p, _sz, _p]),
-    "mphip_groupnorm_bwd_apply": (_i, [_p] * 8 + [_i] * 5 + [_p]),
+    "mphip_groupnorm_bwd_reduce": (_i, [_p] * 12 + [_i] * 5 + [_p, _sz, _p]),
+    "mphip_groupnorm_bwd_apply": (_i, [_p] * 9 + [_i] * 5 + [_p]),
+    "mphip_upsample_nearest_bwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
+    "mphip_small_gemm": (_i, [_p] * 5 + [_i] * 3 + [ctypes.c_long] * 4 + [_p]),
+    "mphip_warp_coords": (_i, [_p] * 5 + [_i] * 7 + [_p]),
+    "mphip_warp_volume_bwd_workspace_bytes": (_sz, [_i] * 5),
+    "mphip_warp_volume_bwd": (_i, [_p] * 8 + [_i] * 9 + [_p, _sz, _p]),
+    "mphip_warp_field_compose_bwd_workspace_bytes": (_sz, [_i, _i]),
+    "mphip_warp_field_compose_bwd": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p]),
+    "mphip_rt_theta_bwd": (_i, [_p] * 5 + [_i, _i, _p]),
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
 }

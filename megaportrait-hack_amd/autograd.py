@@ -51,23 +51,33 @@ class Conv3dFn(torch.autograd.Function):
 
 
 class GroupNormFn(torch.autograd.Function):
-    """y = act(GroupNorm(x) * gamma + beta (+ residual)), act = ReLU or identity."""
+    """y = act(GroupNorm(x) * gamma + beta [then * w2 + b2] (+ residual)); act: 0 none, 1 ReLU, 2 tanh(ReLU(.)).
+    w2/b2 = AdaptiveGroupNorm's second affine ([1,C,1,1,1], model.py:304-316) or None."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, residual, groups, eps, relu):
+    def forward(ctx, x, gamma, beta, w2, b2, residual, groups, eps, act):
         x = x.contiguous()
         stats = ops.groupnorm_stats(x, groups, eps)
-        y = ops.groupnorm_apply(x, stats, gamma, beta, groups, residual=residual, relu=relu)
-        ctx.groups, ctx.relu, ctx.has_res = groups, relu, residual is not None
-        ctx.save_for_backward(x, y, stats, gamma)
+        y = ops.groupnorm_apply(x, stats, gamma, beta, groups, w2=w2, b2=b2, residual=residual, relu=act >= 1, tanh=act == 2)
+        ctx.groups, ctx.act, ctx.has_res, ctx.has_w2 = groups, act, residual is not None, w2 is not None
+        ctx.w2_shape = None if w2 is None else tuple(w2.shape)
+        if w2 is None:
+            ctx.save_for_backward(x, y, stats, gamma)
+        else:
+            ctx.save_for_backward(x, y, stats, gamma, beta, w2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
+        want_res = ctx.has_res and ctx.needs_input_grad[5]
+        if ctx.has_w2:
+            x, y, stats, gamma, beta, w2 = ctx.saved_tensors
+            dx, dgamma, dbeta, dres, dw2, db2 = ops.groupnorm_bwd(x, y, dy.contiguous(), stats, gamma, ctx.groups, ctx.act,
+                                                                  want_res, beta=beta, w2=w2)
+            return dx, dgamma, dbeta, dw2.view(ctx.w2_shape), db2.view(ctx.w2_shape), dres, None, None, None
         x, y, stats, gamma = ctx.saved_tensors
-        want_res = ctx.has_res and ctx.needs_input_grad[3]
-        dx, dgamma, dbeta, dres = ops.groupnorm_bwd(x, y, dy.contiguous(), stats, gamma, ctx.groups, ctx.relu, want_res)
-        return dx, dgamma, dbeta, dres, None, None, None
+        dx, dgamma, dbeta, dres = ops.groupnorm_bwd(x, y, dy.contiguous(), stats, gamma, ctx.groups, ctx.act, want_res)
+        return dx, dgamma, dbeta, None, None, dres, None, None, None
 
 
 class AvgPool2Fn(torch.autograd.Function):
@@ -94,10 +104,114 @@ def conv3d(x, conv, fwd_pack):
     return Conv3dFn.apply(x, conv.weight, conv.bias, conv, fwd_pack)
 
 
-def groupnorm(x, gn, residual=None, relu=False):
-    return GroupNormFn.apply(x, gn.weight, gn.bias, residual, gn.num_groups, gn.eps, relu)
+def groupnorm(x, gn, residual=None, relu=False, tanh=False):
+    return GroupNormFn.apply(x, gn.weight, gn.bias, None, None, residual, gn.num_groups, gn.eps, 2 if tanh else int(relu))
+
+
+def adaptive_groupnorm(x, agn, residual=None, relu=False):
+    """AdaptiveGroupNorm (model.py:304-316) (+ residual + ReLU of ResBlock3D_Adaptive, model.py:390-403)."""
+    gn = agn.group_norm
+    return GroupNormFn.apply(x, gn.weight, gn.bias, agn.weight, agn.bias, residual, gn.num_groups, gn.eps, int(relu))
 
 
 def needs_grad(module, *tensors) -> bool:
     return torch.is_grad_enabled() and (any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors)
                                         or any(p.requires_grad for p in module.parameters()))
+
+
+class WarpVolumeFn(torch.autograd.Function):
+    """apply_warping_field (model.py:1028-1065); dsum=True fuses the torch.sum(dim=2) of model.py:1171."""
+
+    @staticmethod
+    def forward(ctx, v, field, dsum):
+        ctx.dsum = dsum
+        ctx.save_for_backward(v, field)
+        return ops.warp_volume_dsum(v, field) if dsum else ops.warp_volume(v, field)
+
+    @staticmethod
+    def backward(ctx, dout):
+        v, field = ctx.saved_tensors
+        dv, dfield = ops.warp_volume_bwd(v, field, dout.contiguous(), ctx.dsum, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dv, dfield, None
+
+
+class WarpFieldComposeFn(torch.autograd.Function):
+    """rt + em64 of the warp generators: F.affine_grid(theta) + trilinear(em -> G^3) (model.py:804-806, 971-973)."""
+
+    @staticmethod
+    def forward(ctx, theta, em, grid_size):
+        ctx.em_shape = tuple(em.shape)
+        return ops.warp_field_compose(theta, em, grid_size)
+
+    @staticmethod
+    def backward(ctx, dw):
+        dtheta, dem = ops.warp_field_compose_bwd(dw.contiguous(), ctx.em_shape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return dtheta, dem, None
+
+
+class RtThetaFn(torch.autograd.Function):
+    """theta = rows 0..2 of [R(rotation)|t; 0 0 0 1] (inverted for S2C): model.py:790-801, 811-856."""
+
+    @staticmethod
+    def forward(ctx, rotation, translation, invert):
+        ctx.invert = invert
+        ctx.save_for_backward(rotation, translation)
+        return ops.rt_theta(rotation, translation, invert)
+
+    @staticmethod
+    def backward(ctx, dtheta):
+        rotation, translation = ctx.saved_tensors
+        drot, dtr = ops.rt_theta_bwd(rotation, translation, dtheta.contiguous(), ctx.invert)
+        return drot, dtr, None
+
+
+class UpsampleNearestFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=(sD,sH,sW)), default nearest (model.py:427-433)."""
+
+    @staticmethod
+    def forward(ctx, x, scale):
+        ctx.scale = tuple(int(v) for v in scale)
+        return ops.upsample_nearest(x.contiguous(), ctx.scale)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.upsample_nearest_bwd(dout.contiguous(), ctx.scale), None
+
+
+class AddMatmulFn(torch.autograd.Function):
+    """s = (z + e) @ Gamma (model.py:945-957: right-multiply, no transpose)."""
+
+    @staticmethod
+    def forward(ctx, z, e, gamma):
+        ctx.save_for_backward(z, e, gamma)
+        return ops.add_matmul(z, e, gamma)
+
+    @staticmethod
+    def backward(ctx, ds):
+        z, e, gamma = ctx.saved_tensors
+        ds = ds.contiguous()
+        dz = ops.small_gemm(ds, gamma.detach(), trans_b=True) if (ctx.needs_input_grad[0] or ctx.needs_input_grad[1]) else None
+        dgamma = ops.small_gemm(z, ds, trans_a=True, a2=e) if ctx.needs_input_grad[2] else None
+        return dz, dz, dgamma
+
+
+class Conv1x1OnVectorFn(torch.autograd.Function):
+    """The 1x1 Conv2d applied to a 1x1 map (model.py:446): x = s @ W^T + b with W [N,K,1,1]."""
+
+    @staticmethod
+    def forward(ctx, s, weight, bias, w_kn):
+        ctx.save_for_backward(s, weight)
+        return ops.add_matmul(s, None, w_kn, bias)
+
+    @staticmethod
+    def backward(ctx, dx):
+        s, weight = ctx.saved_tensors
+        dx = dx.contiguous()
+        w2d = weight.detach().reshape(weight.shape[0], weight.shape[1])
+        ds = ops.small_gemm(dx, w2d) if ctx.needs_input_grad[0] else None
+        dw = ops.small_gemm(dx, s, trans_a=True).view(weight.shape) if ctx.needs_input_grad[1] else None
+        db = None
+        if ctx.needs_input_grad[2]:
+            ones = torch.ones((1, dx.shape[0]), dtype=torch.float32, device=dx.device)
+            db = ops.small_gemm(ones, dx).view(-1)
+        return ds, dw, db, None

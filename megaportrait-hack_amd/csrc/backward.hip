@@ -136,6 +136,14 @@ slab_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ out, siz
 //         s1[n,c] = sum du, s2[n,c] = sum du*xh.
 // (host, tiny [N,C] tensors: dbeta = sum_n s1, dgamma = sum_n s2, A[n,g] = sum_c gamma_c*s1/cnt, B[n,g] = sum_c gamma_c*s2/cnt)
 // Pass 2: dx = rstd * (gamma_c*du - A - xh*B);  dres = du.
+// gradient through the activation that follows the norm: act 0 = none, 1 = ReLU, 2 = tanh(ReLU(.)) (FlowField's head,
+// model.py:462-465); y is the forward output (y > 0 <=> pre-activation > 0; d tanh = 1 - y^2)
+__device__ __forceinline__ float act_grad(float dy, float y, int act) {
+    if (act == 0) return dy;
+    if (!(y > 0.0f)) return 0.0f;
+    return act == 2 ? dy * (1.0f - y * y) : dy;
+}
+
 constexpr int GNB_CHUNK = 8192;  // floats per workgroup of the reduce pass
 __global__ void __launch_bounds__(256)
 gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
@@ -154,10 +162,10 @@ gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, c
             float du[4] = {g.x, g.y, g.z, g.w};
             if (relu) {
                 const float4 yv = *reinterpret_cast<const float4 *>(y + base + i);
-                if (!(yv.x > 0.0f)) du[0] = 0.0f;
-                if (!(yv.y > 0.0f)) du[1] = 0.0f;
-                if (!(yv.z > 0.0f)) du[2] = 0.0f;
-                if (!(yv.w > 0.0f)) du[3] = 0.0f;
+                du[0] = act_grad(du[0], yv.x, relu);
+                du[1] = act_grad(du[1], yv.y, relu);
+                du[2] = act_grad(du[2], yv.z, relu);
+                du[3] = act_grad(du[3], yv.w, relu);
             }
             const float xh[4] = {(xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd};
             s1 += (du[0] + du[1]) + (du[2] + du[3]);
@@ -165,8 +173,7 @@ gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, c
         }
     } else {
         for (int i = begin + threadIdx.x; i < end; i += 256) {
-            float du = dy[base + i];
-            if (relu && !(y[base + i] > 0.0f)) du = 0.0f;
+            const float du = relu ? act_grad(dy[base + i], y[base + i], relu) : dy[base + i];
             s1 += du;
             s2 += du * ((x[base + i] - mean) * rstd);
         }
@@ -189,11 +196,13 @@ gn_bwd_reduce_kernel(const float *__restrict__ x, const float *__restrict__ y, c
     }
 }
 
-// folds the partial sums (one workgroup): s12[n][c] = sum over chunks; dgamma[c] = sum_n s2, dbeta[c] = sum_n s1;
-// ab[n][g] = (sum_{c in g} gamma_c*s1, sum_{c in g} gamma_c*s2) / (cpg*S)
+// folds the partial sums (one workgroup): s12[n][c] = sum over chunks; with S1 = sum_n s1, S2 = sum_n s2 and the
+// AdaptiveGroupNorm second affine w2 (model.py:314-316; 1 if absent): dgamma = w2*S2, dbeta = w2*S1,
+// dw2 = gamma*S2 + beta*S1, db2 = S1;  ab[n][g] = (sum_{c in g} gamma_c*w2_c*s1, sum ... *s2) / (cpg*S)
 __global__ void __launch_bounds__(1024)
-gn_bwd_fold_kernel(const float *__restrict__ partial, const float *__restrict__ gamma, float *__restrict__ s12,
-                   float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ ab, int N, int C, int cpg, int S,
+gn_bwd_fold_kernel(const float *__restrict__ partial, const float *__restrict__ gamma, const float *__restrict__ beta,
+                   const float *__restrict__ w2, float *__restrict__ s12, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                   float *__restrict__ dw2, float *__restrict__ db2, float *__restrict__ ab, int N, int C, int cpg, int S,
                    int chunks) {
     for (int p = threadIdx.x; p < N * C; p += 1024) {
         double a = 0.0, b = 0.0;
@@ -211,8 +220,13 @@ gn_bwd_fold_kernel(const float *__restrict__ partial, const float *__restrict__ 
             a += (double)s12[(n * C + c) * 2];
             b += (double)s12[(n * C + c) * 2 + 1];
         }
-        dbeta[c] = (float)a;
-        dgamma[c] = (float)b;
+        const double w = w2 ? (double)w2[c] : 1.0;
+        dbeta[c] = (float)(w * a);
+        dgamma[c] = (float)(w * b);
+        if (w2) {
+            dw2[c] = (float)((double)gamma[c] * b + (double)beta[c] * a);
+            db2[c] = (float)a;
+        }
     }
     const int G = C / cpg;
     const double inv = 1.0 / ((double)cpg * (double)S);
@@ -221,8 +235,9 @@ gn_bwd_fold_kernel(const float *__restrict__ partial, const float *__restrict__ 
         double a = 0.0, b = 0.0;
         for (int k = 0; k < cpg; ++k) {
             const int c = g * cpg + k;
-            a += (double)gamma[c] * (double)s12[(n * C + c) * 2];
-            b += (double)gamma[c] * (double)s12[(n * C + c) * 2 + 1];
+            const double ge = (double)gamma[c] * (w2 ? (double)w2[c] : 1.0);
+            a += ge * (double)s12[(n * C + c) * 2];
+            b += ge * (double)s12[(n * C + c) * 2 + 1];
         }
         ab[q * 2] = (float)(a * inv);
         ab[q * 2 + 1] = (float)(b * inv);
@@ -231,18 +246,19 @@ gn_bwd_fold_kernel(const float *__restrict__ partial, const float *__restrict__ 
 
 __global__ void __launch_bounds__(256)
 gn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
-                    const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ ab,
-                    float *__restrict__ dx, float *__restrict__ dres, int C, int cpg, int S, int relu, size_t total) {
+                    const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ w2,
+                    const float *__restrict__ ab, float *__restrict__ dx, float *__restrict__ dres, int C, int cpg, int S,
+                    int relu, size_t total) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
     const size_t plane = i / S;
     const int c = (int)(plane % C), n = (int)(plane / C);
     const int grp = n * (C / cpg) + c / cpg;
     const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
-    float du = dy[i];
-    if (relu && !(y[i] > 0.0f)) du = 0.0f;
+    const float du = relu ? act_grad(dy[i], y[i], relu) : dy[i];
     const float xh = (x[i] - mean) * rstd;
-    dx[i] = rstd * (gamma[c] * du - ab[grp * 2] - xh * ab[grp * 2 + 1]);
+    const float ge = w2 ? gamma[c] * w2[c] : gamma[c];
+    dx[i] = rstd * (ge * du - ab[grp * 2] - xh * ab[grp * 2 + 1]);
     if (dres) dres[i] = du;
 }
 
@@ -323,6 +339,46 @@ upsample_trilinear2_bwd_kernel(const float *__restrict__ dout, float *__restrict
     dx[t] = acc;
 }
 
+// nn.Upsample(scale_factor=(sD,sH,sW)) nearest backward: dx[i] = sum of the sD*sH*sW replicated outputs (model.py:427-433)
+__global__ void __launch_bounds__(256)
+upsample_nearest_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, int sD, int sH, int sW,
+                            size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // over dx elements
+    if (t >= total) return;
+    const int w = (int)(t % W);
+    size_t r = t / W;
+    const int h = (int)(r % H);
+    r /= H;
+    const int d = (int)(r % D);
+    const size_t plane = r / D;
+    const int oH = H * sH, oW = W * sW;
+    const float *p = dout + ((plane * (size_t)(D * sD) + (size_t)d * sD) * oH + (size_t)h * sH) * oW + (size_t)w * sW;
+    float acc = 0.0f;
+    for (int a = 0; a < sD; ++a)
+        for (int b = 0; b < sH; ++b)
+            for (int c = 0; c < sW; ++c) acc += p[((size_t)a * oH + b) * oW + c];
+    dx[t] = acc;
+}
+
+// out[m][n] = sum_k (A[m*sam + k*sak] (+ A2[...])) * B[k*sbk + n*sbn]  (+ bias[n]): the tiny dense products of the
+// warp generators' heads and their gradients ((z+e) @ Gamma, the 1x1 Conv2d on a 1x1 map; model.py:945-957, 446).
+// One thread per output, double accumulation; M*N <= a few 10^6, K <= 2048.
+__global__ void __launch_bounds__(256)
+small_gemm_kernel(const float *__restrict__ A, const float *__restrict__ A2, const float *__restrict__ Bm,
+                  const float *__restrict__ bias, float *__restrict__ out, int M, int N, int K, long sam, long sak, long sbk,
+                  long sbn) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)M * N) return;
+    const int n = (int)(t % N), m = (int)(t / N);
+    double acc = bias ? (double)bias[n] : 0.0;
+    for (int k = 0; k < K; ++k) {
+        float a = A[m * sam + k * sak];
+        if (A2) a += A2[m * sam + k * sak];
+        acc += (double)a * (double)Bm[k * sbk + n * sbn];
+    }
+    out[t] = (float)acc;
+}
+
 }  // namespace mphip
 
 using namespace mphip;
@@ -385,9 +441,13 @@ extern "C" size_t mphip_groupnorm_bwd_workspace_bytes(int N, int C, int S) {
 }
 
 extern "C" int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats,
-                                          const float *gamma, float *dgamma, float *dbeta, float *ab, int N, int C, int S, int G,
-                                          int relu, void *workspace, size_t workspace_bytes, void *stream) {
-    MPHIP_REQUIRE(x && dy && stats && gamma && dgamma && dbeta && ab && (!relu || y), "groupnorm_bwd_reduce: null pointer");
+                                          const float *gamma, const float *beta, const float *w2, float *dgamma, float *dbeta,
+                                          float *dw2, float *db2, float *ab, int N, int C, int S, int G, int act,
+                                          void *workspace, size_t workspace_bytes, void *stream) {
+    const int relu = act;
+    MPHIP_REQUIRE(x && dy && stats && gamma && dgamma && dbeta && ab && (!act || y), "groupnorm_bwd_reduce: null pointer");
+    MPHIP_REQUIRE(!w2 || (beta && dw2 && db2), "groupnorm_bwd_reduce: the second affine needs beta, dw2 and db2");
+    MPHIP_REQUIRE(act >= 0 && act <= 2, "groupnorm_bwd_reduce: act must be 0 (none), 1 (ReLU) or 2 (tanh(ReLU))");
     MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd_reduce: bad dims");
     const size_t need = mphip_groupnorm_bwd_workspace_bytes(N, C, S);
     if (!workspace || workspace_bytes < need) {
@@ -399,19 +459,20 @@ extern "C" int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C * chunks), dim3(256), 0, s, x, y, dy, stats, partial, C, C / G, S, relu,
                        chunks);
-    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(1), dim3(1024), 0, s, (const float *)partial, gamma, s12, dgamma, dbeta, ab, N, C,
-                       C / G, S, chunks);
+    hipLaunchKernelGGL(gn_bwd_fold_kernel, dim3(1), dim3(1024), 0, s, (const float *)partial, gamma, beta, w2, s12, dgamma, dbeta,
+                       dw2, db2, ab, N, C, C / G, S, chunks);
     return check_launch("groupnorm_bwd_reduce");
 }
 
 extern "C" int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, const float *stats,
-                                         const float *gamma, const float *ab, float *dx, float *dres, int N, int C, int S,
-                                         int G, int relu, void *stream) {
-    MPHIP_REQUIRE(x && dy && stats && gamma && ab && dx && (!relu || y), "groupnorm_bwd_apply: null pointer");
+                                         const float *gamma, const float *w2, const float *ab, float *dx, float *dres, int N,
+                                         int C, int S, int G, int act, void *stream) {
+    const int relu = act;
+    MPHIP_REQUIRE(x && dy && stats && gamma && ab && dx && (!act || y), "groupnorm_bwd_apply: null pointer");
     MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd_apply: bad dims");
     const size_t total = (size_t)N * C * S;
     hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, gamma,
-                       ab, dx, dres, C, C / G, S, relu, total);
+                       w2, ab, dx, dres, C, C / G, S, relu, total);
     return check_launch("groupnorm_bwd_apply");
 }
 
@@ -433,4 +494,23 @@ extern "C" int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int N
     hipLaunchKernelGGL(upsample_trilinear2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, D, H,
                        W, sD, sH, sW, total);
     return check_launch("upsample_trilinear2_bwd");
+}
+
+extern "C" int mphip_upsample_nearest_bwd(const float *dout, float *dx, int NC, int D, int H, int W, int sD, int sH, int sW,
+                                          void *stream) {
+    MPHIP_REQUIRE(dout && dx, "upsample_nearest_bwd: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && sD > 0 && sH > 0 && sW > 0, "upsample_nearest_bwd: bad dims");
+    const size_t total = (size_t)NC * D * H * W;
+    hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, D, H, W, sD,
+                       sH, sW, total);
+    return check_launch("upsample_nearest_bwd");
+}
+
+extern "C" int mphip_small_gemm(const float *a, const float *a2, const float *b, const float *bias, float *out, int M, int N,
+                                int K, long sam, long sak, long sbk, long sbn, void *stream) {
+    MPHIP_REQUIRE(a && b && out, "small_gemm: null pointer");
+    MPHIP_REQUIRE(M > 0 && N > 0 && K > 0, "small_gemm: bad dims");
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv((size_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, a, a2, b, bias, out, M,
+                       N, K, sam, sak, sbk, sbn);
+    return check_launch("small_gemm");
 }

@@ -553,3 +553,362 @@ extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const 
                        coords, out, B, C, D, H, W);
     return check_launch("warp_volume_dsum");
 }
+
+// =====================================================================================================
+// K10 — backward of K1/K2/K3 (scope row f2).  Gradients as torch.autograd gives them for the reference's ops:
+// F.grid_sample(bilinear, border, align_corners=True) wrt input and grid (ATen GridSampler backward: clipped
+// coordinates pass no gradient), the align_corners=True resize of the field, torch.sum(dim=2), F.affine_grid and
+// the align_corners=False resize of the flow field.
+namespace mphip {
+
+// One thread per output voxel and channel slice: scatters dout into dv (hardware fp32 atomics; the reference's
+// own CUDA backward is an atomicAdd scatter too) and accumulates the coordinate gradient of its slice.
+template <bool DSUM>
+__global__ void __launch_bounds__(256)
+warp_bwd_kernel(const float *__restrict__ v, const float *__restrict__ coords, const float *__restrict__ dout,
+                float *__restrict__ dv, float *__restrict__ dcoords, int B, int C, int D, int H, int W, int cpb) {
+    const size_t vol = (size_t)D * H * W;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * vol) return;
+    const int b = (int)(t / vol);
+    const size_t r = t - (size_t)b * vol;
+    const int HW = H * W;
+    const int hw = (int)(r % HW);
+    const float cx = coords[t * 3], cy = coords[t * 3 + 1], cz = coords[t * 3 + 2];
+    const int x0 = (int)floorf(cx), y0 = (int)floorf(cy), z0 = (int)floorf(cz);
+    float wx1 = cx - (float)x0, wx0 = (float)(x0 + 1) - cx;
+    float wy1 = cy - (float)y0, wy0 = (float)(y0 + 1) - cy;
+    float wz1 = cz - (float)z0, wz0 = (float)(z0 + 1) - cz;
+    const bool vx = x0 + 1 < W, vy = y0 + 1 < H, vz = z0 + 1 < D;
+    if (!vx) wx1 = 0.0f;  // the +1 corner is outside: ATen skips it (value and scatter)
+    if (!vy) wy1 = 0.0f;
+    if (!vz) wz1 = 0.0f;
+    const int base = (z0 * H + y0) * W + x0;
+    const int dx = vx ? 1 : 0, dy = vy ? W : 0, dz = vz ? HW : 0;
+    const float w000 = wx0 * wy0 * wz0, w100 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w110 = wx1 * wy1 * wz0;
+    const float w001 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w011 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
+    const int c_begin = blockIdx.y * cpb, c_end = min(C, c_begin + cpb);
+    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
+    for (int ch = c_begin; ch < c_end; ++ch) {
+        const size_t plane = (size_t)b * C + ch;
+        const float g = DSUM ? dout[plane * HW + hw] : dout[plane * vol + r];
+        if (dcoords) {
+            const float *p = v + plane * vol + base;
+            const float v000 = p[0], v100 = vx ? p[dx] : 0.0f, v010 = vy ? p[dy] : 0.0f, v110 = (vx && vy) ? p[dy + dx] : 0.0f;
+            const float v001 = vz ? p[dz] : 0.0f, v101 = (vz && vx) ? p[dz + dx] : 0.0f;
+            const float v011 = (vz && vy) ? p[dz + dy] : 0.0f, v111 = (vz && vy && vx) ? p[dz + dy + dx] : 0.0f;
+            gx += g * (((v100 - v000) * wy0 + (v110 - v010) * wy1) * wz0 + ((v101 - v001) * wy0 + (v111 - v011) * wy1) * wz1);
+            gy += g * (((v010 - v000) * wx0 + (v110 - v100) * wx1) * wz0 + ((v011 - v001) * wx0 + (v111 - v101) * wx1) * wz1);
+            gz += g * (((v001 - v000) * wx0 + (v101 - v100) * wx1) * wy0 + ((v011 - v010) * wx0 + (v111 - v110) * wx1) * wy1);
+        }
+        if (dv) {
+            float *q = dv + plane * vol + base;
+            unsafeAtomicAdd(q, w000 * g);
+            if (w100 != 0.0f) unsafeAtomicAdd(q + dx, w100 * g);
+            if (w010 != 0.0f) unsafeAtomicAdd(q + dy, w010 * g);
+            if (w110 != 0.0f) unsafeAtomicAdd(q + dy + dx, w110 * g);
+            if (w001 != 0.0f) unsafeAtomicAdd(q + dz, w001 * g);
+            if (w101 != 0.0f) unsafeAtomicAdd(q + dz + dx, w101 * g);
+            if (w011 != 0.0f) unsafeAtomicAdd(q + dz + dy, w011 * g);
+            if (w111 != 0.0f) unsafeAtomicAdd(q + dz + dy + dx, w111 * g);
+        }
+    }
+    if (dcoords) {
+        // clip_coordinates_set_grad: a clipped coordinate (<= 0 or >= size-1) passes no gradient; the remaining chain
+        // (unnormalise (S-1)/2, then 2/(S-1) of model.py:1058, then d(grid+field)/dfield = 1) multiplies to 1
+        float *o = dcoords + ((size_t)blockIdx.y * B * vol + t) * 3;
+        o[0] = (cx > 0.0f && cx < (float)(W - 1)) ? gx : 0.0f;
+        o[1] = (cy > 0.0f && cy < (float)(H - 1)) ? gy : 0.0f;
+        o[2] = (cz > 0.0f && cz < (float)(D - 1)) ? gz : 0.0f;
+    }
+}
+
+template <bool ALIGN>
+__device__ __forceinline__ void adj_bounds(int i, int in, int out, int &lo, int &hi) {
+    // outputs whose source interval [i0, i1] can contain input index i (padded by one for rounding; weights decide)
+    float a, b2;
+    if (ALIGN) {
+        const float scale = out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.0f;
+        if (!(scale > 0.0f)) { lo = 0; hi = out - 1; return; }
+        a = ((float)i - 1.0f) / scale;
+        b2 = ((float)i + 1.0f) / scale;
+    } else {
+        const float scale = (float)in / (float)out;
+        a = ((float)i - 0.5f) / scale - 0.5f;
+        b2 = ((float)i + 1.5f) / scale - 0.5f;
+    }
+    lo = max(0, (int)floorf(a) - 1);
+    hi = min(out - 1, (int)ceilf(b2) + 1);
+    if (!ALIGN && i == 0) lo = 0;  // src is clamped at 0: every o below the first source lands on i0 = 0
+}
+template <bool ALIGN>
+__device__ __forceinline__ float adj_w(int o, int i, int in, int out) {
+    const SrcIdx s = src_index<ALIGN>(o, in, out);
+    float w = 0.0f;
+    if (s.i0 == i) w += s.l0;
+    if (s.i1 == i) w += s.l1;
+    return w;
+}
+
+// adjoint of a trilinear resize [B,C,iD,iH,iW] -> [B,C,oD,oH,oW]: gin[i] = sum_o w(o -> i) * sum_slabs gout[o]
+// (gather form, deterministic).  interleaved: gout is [slab][B][oVol][C] (the coordinate-gradient layout of
+// warp_bwd_kernel) instead of [slab][B][C][oVol].
+template <bool ALIGN>
+__global__ void __launch_bounds__(256)
+resize_trilinear_adjoint_kernel(const float *__restrict__ gout, float *__restrict__ gin, int B, int C, int iD, int iH, int iW,
+                                int oD, int oH, int oW, int slabs, int interleaved) {
+    const size_t ivol = (size_t)iD * iH * iW, ovol = (size_t)oD * oH * oW;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)B * C * ivol) return;
+    const int iw = (int)(t % iW);
+    size_t r = t / iW;
+    const int ih = (int)(r % iH);
+    r /= iH;
+    const int id = (int)(r % iD);
+    r /= iD;
+    const int ch = (int)(r % C), b = (int)(r / C);
+    int dlo, dhi, hlo, hhi, wlo, whi;
+    adj_bounds<ALIGN>(id, iD, oD, dlo, dhi);
+    adj_bounds<ALIGN>(ih, iH, oH, hlo, hhi);
+    adj_bounds<ALIGN>(iw, iW, oW, wlo, whi);
+    const size_t slab_stride = (size_t)B * C * ovol;
+    float acc = 0.0f;
+    for (int od = dlo; od <= dhi; ++od) {
+        const float wd = adj_w<ALIGN>(od, id, iD, oD);
+        if (wd == 0.0f) continue;
+        float pl = 0.0f;
+        for (int oh = hlo; oh <= hhi; ++oh) {
+            const float wh = adj_w<ALIGN>(oh, ih, iH, oH);
+            if (wh == 0.0f) continue;
+            float rs = 0.0f;
+            for (int ow = wlo; ow <= whi; ++ow) {
+                const float ww = adj_w<ALIGN>(ow, iw, iW, oW);
+                if (ww == 0.0f) continue;
+                const size_t o = ((size_t)od * oH + oh) * oW + ow;
+                const size_t idx = interleaved ? ((size_t)b * ovol + o) * C + ch : ((size_t)b * C + ch) * ovol + o;
+                float g = gout[idx];
+                for (int s = 1; s < slabs; ++s) g += gout[(size_t)s * slab_stride + idx];
+                rs += ww * g;
+            }
+            pl += wh * rs;
+        }
+        acc += wd * pl;
+    }
+    gin[t] = acc;
+}
+
+// dtheta[b][j][k] = sum_p dw[b][j][p] * (x_p, y_p, z_p, 1)[k]   (F.affine_grid backward); partial sums per chunk
+constexpr int TG_CHUNK = 8192;
+__global__ void __launch_bounds__(256)
+theta_grad_partial_kernel(const float *__restrict__ dw, const float *__restrict__ base, double *__restrict__ partial, int G,
+                          int chunks) {
+    const int bj = blockIdx.x / chunks, chunk = blockIdx.x % chunks;
+    const size_t vol = (size_t)G * G * G;
+    const float *p = dw + (size_t)bj * vol;
+    const size_t begin = (size_t)chunk * TG_CHUNK, end = min(vol, begin + TG_CHUNK);
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+    for (size_t i = begin + threadIdx.x; i < end; i += 256) {
+        const float g = p[i];
+        const int w = (int)(i % G), h = (int)((i / G) % G), d = (int)(i / ((size_t)G * G));
+        s[0] += (double)(g * base[w]);
+        s[1] += (double)(g * base[h]);
+        s[2] += (double)(g * base[d]);
+        s[3] += (double)g;
+    }
+    __shared__ double red[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) s[k] += __shfl_xor(s[k], sft, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = s[k];
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ void theta_grad_finalize_kernel(const double *__restrict__ partial, float *__restrict__ dtheta, int n, int chunks) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over B*3*4
+    if (i >= n) return;
+    const int bj = i / 4, k = i % 4;
+    double a = 0.0;
+    for (int c = 0; c < chunks; ++c) a += partial[((size_t)bj * chunks + c) * 4 + k];
+    dtheta[i] = (float)a;
+}
+
+// backward of rt_theta_kernel: theta = rows 0..2 of A (or of inv(A)), A = [Rx*Ry*Rz | t; 0 0 0 1], angles in degrees.
+// d(inv A) -> dA = -M^T dM M^T with M = inv(A); then the product rule through the three axis rotations.
+__global__ void rt_theta_bwd_kernel(const float *__restrict__ rot, const float *__restrict__ tr, const float *__restrict__ dtheta,
+                                    float *__restrict__ drot, float *__restrict__ dtr, int B, int invert) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const double k = 0.017453292519943295;
+    const double ra = (double)(rot[b * 3] * 0.017453292519943295f), rb = (double)(rot[b * 3 + 1] * 0.017453292519943295f),
+                 rg = (double)(rot[b * 3 + 2] * 0.017453292519943295f);
+    const double ca = cos(ra), sa = sin(ra), cb = cos(rb), sb = sin(rb), cg = cos(rg), sg = sin(rg);
+    const double Rx[3][3] = {{1, 0, 0}, {0, ca, -sa}, {0, sa, ca}};
+    const double Ry[3][3] = {{cb, 0, sb}, {0, 1, 0}, {-sb, 0, cb}};
+    const double Rz[3][3] = {{cg, -sg, 0}, {sg, cg, 0}, {0, 0, 1}};
+    double YZ[3][3], XY[3][3], R[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0, u = 0.0;
+            for (int q = 0; q < 3; ++q) { s += Ry[i][q] * Rz[q][j]; u += Rx[i][q] * Ry[q][j]; }
+            YZ[i][j] = s;
+            XY[i][j] = u;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < 3; ++q) s += Rx[i][q] * YZ[q][j];
+            R[i][j] = s;
+        }
+    double dA[3][4];  // gradient wrt the top three rows of A
+    if (invert) {
+        // A rigid: inv(A) = [R^T | -R^T t]; written through the general identity dA = -M^T dM M^T (dM's last row is 0)
+        double M[4][4];
+        for (int i = 0; i < 3; ++i) {
+            for (int j = 0; j < 3; ++j) M[i][j] = R[j][i];
+            double s = 0.0;
+            for (int q = 0; q < 3; ++q) s += R[q][i] * (double)tr[b * 3 + q];
+            M[i][3] = -s;
+        }
+        M[3][0] = M[3][1] = M[3][2] = 0.0;
+        M[3][3] = 1.0;
+        double T[4][4];  // T = M^T dM  (dM rows 0..2 = dtheta, row 3 = 0)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.0;
+                for (int q = 0; q < 3; ++q) s += M[q][i] * (double)dtheta[(b * 3 + q) * 4 + j];
+                T[i][j] = s;
+            }
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) {
+                double s = 0.0;
+                for (int q = 0; q < 4; ++q) s += T[i][q] * M[j][q];
+                dA[i][j] = -s;
+            }
+    } else {
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 4; ++j) dA[i][j] = (double)dtheta[(b * 3 + i) * 4 + j];
+    }
+    for (int i = 0; i < 3; ++i) dtr[b * 3 + i] = (float)dA[i][3];
+    // R = Rx * (Ry * Rz):  dRx = dR (YZ)^T,  dRy = Rx^T dR Rz^T,  dRz = (XY)^T dR
+    double dRx[3][3], dRy[3][3], dRz[3][3], tmp[3][3];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0, u = 0.0, w = 0.0;
+            for (int q = 0; q < 3; ++q) {
+                s += dA[i][q] * YZ[j][q];
+                u += Rx[q][i] * dA[q][j];
+                w += XY[q][i] * dA[q][j];
+            }
+            dRx[i][j] = s;
+            tmp[i][j] = u;
+            dRz[i][j] = w;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < 3; ++q) s += tmp[i][q] * Rz[j][q];
+            dRy[i][j] = s;
+        }
+    const double da = dRx[1][1] * -sa + dRx[1][2] * -ca + dRx[2][1] * ca + dRx[2][2] * -sa;
+    const double db = dRy[0][0] * -sb + dRy[0][2] * cb + dRy[2][0] * -cb + dRy[2][2] * -sb;
+    const double dg = dRz[0][0] * -sg + dRz[0][1] * -cg + dRz[1][0] * cg + dRz[1][1] * -sg;
+    drot[b * 3] = (float)(da * k);
+    drot[b * 3 + 1] = (float)(db * k);
+    drot[b * 3 + 2] = (float)(dg * k);
+}
+
+constexpr int WARP_BWD_CPB = 12;  // channels per slice of the scatter pass
+
+}  // namespace mphip
+
+extern "C" int mphip_warp_coords(const float *field, const float *lin_d, const float *lin_h, const float *lin_w, float *coords,
+                                 int B, int D, int H, int W, int fD, int fH, int fW, void *stream) {
+    MPHIP_REQUIRE(field && lin_d && lin_h && lin_w && coords, "warp_coords: null pointer");
+    MPHIP_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && fD > 0 && fH > 0 && fW > 0, "warp_coords: bad dims");
+    return launch_coords(field, lin_d, lin_h, lin_w, coords, nullptr, B, D, H, W, fD, fH, fW, (hipStream_t)stream);
+}
+
+extern "C" size_t mphip_warp_volume_bwd_workspace_bytes(int B, int C, int D, int H, int W) {
+    if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t groups = (size_t)cdiv(C, WARP_BWD_CPB);
+    return (size_t)B * D * H * W * 3 * sizeof(float) * (1 + groups);
+}
+
+extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                                     const float *lin_w, const float *dout, float *dv, float *dfield, int B, int C, int D,
+                                     int H, int W, int fD, int fH, int fW, int dsum, void *workspace, size_t workspace_bytes,
+                                     void *stream) {
+    int rc = check_warp_args("warp_volume_bwd", v, field, lin_d, lin_h, lin_w, dout, B, C, D, H, W, fD, fH, fW);
+    if (rc) return rc;
+    MPHIP_REQUIRE(dv || dfield, "warp_volume_bwd: nothing to compute (dv and dfield are both NULL)");
+    const size_t need = mphip_warp_volume_bwd_workspace_bytes(B, C, D, H, W);
+    if (!workspace || workspace_bytes < need) {
+        set_error("warp_volume_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nvox = (size_t)B * D * H * W;
+    float *coords = (float *)workspace, *dcoords = coords + nvox * 3;
+    rc = launch_coords(field, lin_d, lin_h, lin_w, coords, nullptr, B, D, H, W, fD, fH, fW, s);
+    if (rc) return rc;
+    if (dv && hipMemsetAsync(dv, 0, (size_t)B * C * D * H * W * sizeof(float), s) != hipSuccess) {
+        set_error("warp_volume_bwd: memset failed");
+        return MPHIP_ELAUNCH;
+    }
+    const int groups = cdiv(C, WARP_BWD_CPB);
+    dim3 grid(cdiv(nvox, 256), groups);
+    if (dsum)
+        hipLaunchKernelGGL(warp_bwd_kernel<true>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
+                           dfield ? dcoords : nullptr, B, C, D, H, W, WARP_BWD_CPB);
+    else
+        hipLaunchKernelGGL(warp_bwd_kernel<false>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
+                           dfield ? dcoords : nullptr, B, C, D, H, W, WARP_BWD_CPB);
+    if (dfield) {
+        const size_t nf = (size_t)B * 3 * fD * fH * fW;
+        hipLaunchKernelGGL(resize_trilinear_adjoint_kernel<true>, dim3(cdiv(nf, 256)), dim3(256), 0, s, (const float *)dcoords,
+                           dfield, B, 3, fD, fH, fW, D, H, W, groups, 1);
+    }
+    return check_launch("warp_volume_bwd");
+}
+
+extern "C" size_t mphip_warp_field_compose_bwd_workspace_bytes(int B, int G) {
+    if (B <= 0 || G <= 0) return 0;
+    return (size_t)B * 3 * cdiv((size_t)G * G * G, TG_CHUNK) * 4 * sizeof(double);
+}
+
+extern "C" int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *dtheta, float *dem, int B, int eD,
+                                            int eH, int eW, int G, void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(dw && base_tbl && (dtheta || dem), "warp_field_compose_bwd: null pointer");
+    MPHIP_REQUIRE(B > 0 && eD > 0 && eH > 0 && eW > 0 && G > 0, "warp_field_compose_bwd: bad dims");
+    hipStream_t s = (hipStream_t)stream;
+    if (dtheta) {
+        const size_t need = mphip_warp_field_compose_bwd_workspace_bytes(B, G);
+        if (!workspace || workspace_bytes < need) {
+            set_error("warp_field_compose_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+            return MPHIP_EWORKSPACE;
+        }
+        const int chunks = cdiv((size_t)G * G * G, TG_CHUNK);
+        hipLaunchKernelGGL(theta_grad_partial_kernel, dim3(B * 3 * chunks), dim3(256), 0, s, dw, base_tbl, (double *)workspace, G,
+                           chunks);
+        hipLaunchKernelGGL(theta_grad_finalize_kernel, dim3(cdiv(B * 12, 64)), dim3(64), 0, s, (const double *)workspace, dtheta,
+                           B * 12, chunks);
+    }
+    if (dem) {
+        const size_t ne = (size_t)B * 3 * eD * eH * eW;
+        hipLaunchKernelGGL(resize_trilinear_adjoint_kernel<false>, dim3(cdiv(ne, 256)), dim3(256), 0, s, dw, dem, B, 3, eD, eH, eW,
+                           G, G, G, 1, 0);
+    }
+    return check_launch("warp_field_compose_bwd");
+}
+
+extern "C" int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
+                                  int invert, void *stream) {
+    MPHIP_REQUIRE(rot && tr && dtheta && drot && dtr, "rt_theta_bwd: null pointer");
+    MPHIP_REQUIRE(B > 0, "rt_theta_bwd: bad batch");
+    hipLaunchKernelGGL(rt_theta_bwd_kernel, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, rot, tr, dtheta, drot, dtr, B,
+                       invert);
+    return check_launch("rt_theta_bwd");
+}

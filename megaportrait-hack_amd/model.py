@@ -7,9 +7,9 @@ arithmetic runs in libmphip.so (hand-written HIP for gfx950) through the C ABI. 
 nn.GroupNorm objects are kept purely as parameter containers (names, shapes, default init,
 .to()/.state_dict()); their own forward is never called.
 
-Training: ResBlock3D and G3d are differentiable — under autograd they run the same HIP ops as
-torch.autograd Functions (autograd.py) whose backward kernels live in csrc/backward.hip.  The warp generators and
-the two warps are still forward-only: under autograd they raise instead of silently detaching.
+Training: every module here is differentiable — under autograd the same HIP ops run as
+torch.autograd Functions (autograd.py) whose backward kernels live in csrc/backward.hip, csrc/conv3d_bwd_f16x3.hip
+and csrc/warp.hip (K9/K10); under torch.no_grad() the fused inference path runs.
 """
 from __future__ import annotations
 
@@ -22,14 +22,6 @@ from . import autograd as ag
 from . import ops
 
 COMPRESS_DIM = 512  # model.py:48
-
-
-def _no_autograd(*tensors, module: nn.Module):
-    if torch.is_grad_enabled() and (any(t.requires_grad for t in tensors if isinstance(t, torch.Tensor))
-                                    or any(p.requires_grad for p in module.parameters())):
-        raise NotImplementedError(
-            f"{type(module).__name__}: the HIP hot path is forward-only in this release; call it under "
-            "torch.no_grad() (training backward is the next scope row, see DESIGN.md)")
 
 
 class _PackCache:
@@ -60,7 +52,9 @@ def compute_rt_warp(rotation, translation, invert=False, grid_size=64):
 
 
 def apply_warping_field(v, warp_field):
-    """model.py:1028-1065 — same signature and result; one fused HIP kernel (K2)."""
+    """model.py:1028-1065 — same signature and result; one fused HIP kernel (K2); differentiable (autograd.WarpVolumeFn)."""
+    if torch.is_grad_enabled() and (v.requires_grad or warp_field.requires_grad):
+        return ag.WarpVolumeFn.apply(v, warp_field, False)
     return ops.warp_volume(v, warp_field)
 
 
@@ -76,7 +70,8 @@ class AdaptiveGroupNorm(nn.Module):
         self.group_norm = nn.GroupNorm(num_groups, num_channels)
 
     def forward(self, x):
-        _no_autograd(x, module=self)
+        if ag.needs_grad(self, x):
+            return ag.adaptive_groupnorm(x, self)
         st = ops.groupnorm_stats(x, self.num_groups, self.group_norm.eps)
         return ops.groupnorm_apply(x, st, self.group_norm.weight, self.group_norm.bias, self.num_groups,
                                    w2=self.weight, b2=self.bias)
@@ -102,7 +97,13 @@ class ResBlock3D_Adaptive(nn.Module):
 
     def forward(self, x, _up=(1, 1, 1)):
         """`_up`: nearest-upsample factors fused into the block's last elementwise pass (FlowField's nn.Upsample)."""
-        _no_autograd(x, module=self)
+        if ag.needs_grad(self, x):  # differentiable path: the same ops, unfused, as autograd Functions (autograd.py)
+            y = ag.conv3d(x, self.conv1, _packs.get(self.conv1))
+            y = ag.adaptive_groupnorm(y, self.norm1, relu=True)
+            y = ag.conv3d(y, self.conv2, _packs.get(self.conv2))
+            res = x if isinstance(self.residual_conv, nn.Identity) else ag.conv3d(x, self.residual_conv, _packs.get(self.residual_conv))
+            y = ag.adaptive_groupnorm(y, self.norm2, residual=res, relu=True)
+            return y if tuple(_up) == (1, 1, 1) else ag.UpsampleNearestFn.apply(y, tuple(_up))
         n1, n2 = self.norm1, self.norm2
         y = ops.conv3d_split(x, _packs.get(self.conv1))  # split-K slabs are summed by the GN kernels below
         tiny = ops.groupnorm_fused_ok(y, n1.num_groups)  # FlowField: statistics + apply in one launch
@@ -161,13 +162,21 @@ class FlowField(nn.Module):
         return hit[1]
 
     def forward(self, zs, adaptive_gamma=0, adaptive_beta=0):  # last two ignored, as in the reference
-        _no_autograd(zs, module=self)
+        train = ag.needs_grad(self, zs)
         b = zs.shape[0]
         s = zs.reshape(b, 512)
-        x = ops.add_matmul(s, None, self._conv1x1_kn(), self.conv1x1.bias)  # 1x1 conv on a 1x1 map == s @ W^T + b
+        if train:
+            x = ag.Conv1x1OnVectorFn.apply(s, self.conv1x1.weight, self.conv1x1.bias, self._conv1x1_kn())
+        else:
+            x = ops.add_matmul(s, None, self._conv1x1_kn(), self.conv1x1.bias)  # 1x1 conv on a 1x1 map == s @ W^T + b
         x = x.view(b, 512, 4, 1, 1)  # model.py:425: channel c*4+d -> (c,d)
         for blk, up in zip((self.resblock1, self.resblock2, self.resblock3, self.resblock4), self._UPS):
             x = blk(x, _up=up)  # nn.Upsample (nearest, model.py:450-457) fused into the block's last pass
+        if train:
+            x = ag.conv3d(x, self.conv3x3x3, _packs.get(self.conv3x3x3))
+            x = ag.groupnorm(x, self.gn, relu=True, tanh=True)
+            assert x.shape[1] == 3, f"Expected 3 channels after conv3x3x3, got {x.shape[1]}"
+            return x
         x = ops.conv3d_split(x, _packs.get(self.conv3x3x3))
         if ops.groupnorm_fused_ok(x, 1):
             x = ops.groupnorm_small(x, self.gn.weight, self.gn.bias, 1, self.gn.eps, relu=True, tanh=True)
@@ -194,7 +203,11 @@ class _WarpGenerator(nn.Module):
         assert R.shape == (z.shape[0], 3), f"Expected R shape (batch_size, 3), got {R.shape}"
         assert t.shape == (z.shape[0], 3), f"Expected t shape (batch_size, 3), got {t.shape}"
         assert z.shape == e.shape, f"Expected z and e to have the same shape, got {z.shape} and {e.shape}"
-        _no_autograd(R, t, z, e, module=self)
+        if ag.needs_grad(self, R, t, z, e):
+            s = ag.AddMatmulFn.apply(z, e, self.adaptive_matrix_gamma)
+            em = self.flowfield(s.unsqueeze(-1).unsqueeze(-1), 0, 0)
+            theta = ag.RtThetaFn.apply(R, t, self._INVERT)
+            return ag.WarpFieldComposeFn.apply(theta, em, 64)
         s = ops.add_matmul(z, e, self.adaptive_matrix_gamma)  # (z+e) @ Gamma, model.py:945-957
         em = self.flowfield(s.unsqueeze(-1).unsqueeze(-1), 0, 0)
         theta = ops.rt_theta(R, t, self._INVERT)
@@ -339,7 +352,9 @@ class GbaseHotSlice(nn.Module):
 
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         main = torch.cuda.current_stream(vs.device)
-        side = self._side_stream(main) if self.overlap_generators else None
+        train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
+        # training: one stream (autograd replays each op's backward on its forward stream; the overlap is an inference trick)
+        side = self._side_stream(main) if (self.overlap_generators and not train) else None
         if side is not None:
             side.wait_stream(main)  # inputs produced on the main stream are visible
         # critical path first: the host issues S2C's launches before it spends time on the side stream's
@@ -357,6 +372,8 @@ class GbaseHotSlice(nn.Module):
         else:
             w_c2d = self.warp_generator_c2d(Rd, td, zd, es)
         # apply_warping_field + torch.sum(dim=2) (model.py:1167-1171) in one kernel (K3)
+        if train:
+            return ag.WarpVolumeFn.apply(vc2d, w_c2d, True)
         return ops.warp_volume_dsum(vc2d, w_c2d)
 
     def forward(self, vs, es, Rs, ts, zs, Rd, td, zd):

@@ -559,27 +559,36 @@ def conv_bwd_data_weight(weight: torch.Tensor) -> torch.Tensor:
     return weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
 
 
-def groupnorm_bwd(x, y, dy, stats, gamma, groups: int, relu: bool, want_res: bool):
-    """Backward of y = relu?(GroupNorm(x)*gamma+beta (+res)) -> (dx, dgamma, dbeta, dres|None).  `y` is the forward
-    output (ReLU mask); stats = the forward (mean, rstd)."""
+def groupnorm_bwd(x, y, dy, stats, gamma, groups: int, relu, want_res: bool, beta=None, w2=None):
+    """Backward of y = act(GroupNorm(x)*gamma+beta [*w2+b2] (+res)) -> (dx, dgamma, dbeta, dres|None[, dw2, db2]).
+    `y` is the forward output (activation mask); stats = the forward (mean, rstd); relu: False/True or act code 0/1/2
+    (2 = tanh(ReLU(.)))."""
     x, dy = _req(x, "x"), _req(dy, "dy")
     n, c = x.shape[0], x.shape[1]
     s = x.numel() // (n * c)
-    cpg = c // groups
+    act = int(relu)
     lib = _lib.load()
     gamma = _req(gamma.detach(), "gamma")
+    dev = x.device
+    if w2 is not None:
+        w2 = _req(w2.detach(), "w2").reshape(-1)
+        beta = _req(beta.detach(), "beta")
     ws_bytes = lib.mphip_groupnorm_bwd_workspace_bytes(n, c, s)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-    dgamma = torch.empty(c, dtype=torch.float32, device=x.device)
-    dbeta = torch.empty(c, dtype=torch.float32, device=x.device)
-    ab = torch.empty((n * groups, 2), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
-                                              _ptr(ab), n, c, s, groups, int(relu), _ptr(ws), ws_bytes, _stream()),
-               "mphip_groupnorm_bwd_reduce")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+    dgamma = torch.empty(c, dtype=torch.float32, device=dev)
+    dbeta = torch.empty(c, dtype=torch.float32, device=dev)
+    dw2 = torch.empty(c, dtype=torch.float32, device=dev) if w2 is not None else None
+    db2 = torch.empty(c, dtype=torch.float32, device=dev) if w2 is not None else None
+    ab = torch.empty((n * groups, 2), dtype=torch.float32, device=dev)
+    _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2),
+                                              _ptr(dgamma), _ptr(dbeta), _ptr(dw2), _ptr(db2), _ptr(ab), n, c, s, groups, act,
+                                              _ptr(ws), ws_bytes, _stream()), "mphip_groupnorm_bwd_reduce")
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_res else None
-    _lib.check(lib.mphip_groupnorm_bwd_apply(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(ab), _ptr(dx), _ptr(dres),
-                                             n, c, s, groups, int(relu), _stream()), "mphip_groupnorm_bwd_apply")
+    _lib.check(lib.mphip_groupnorm_bwd_apply(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(w2), _ptr(ab), _ptr(dx),
+                                             _ptr(dres), n, c, s, groups, act, _stream()), "mphip_groupnorm_bwd_apply")
+    if w2 is not None:
+        return dx, dgamma, dbeta, dres, dw2, db2
     return dx, dgamma, dbeta, dres
 
 
@@ -600,3 +609,79 @@ def upsample_trilinear2_bwd(dout: torch.Tensor) -> torch.Tensor:
     _lib.check(_lib.load().mphip_upsample_trilinear2_bwd(_ptr(dout), _ptr(dx), n * c, d // 2, h // 2, w // 2, _stream()),
                "mphip_upsample_trilinear2_bwd")
     return dx
+
+
+# ------------------------------------------------------------------ K10  backward of the warps / field composition
+def warp_volume_bwd(v: torch.Tensor, field: torch.Tensor, dout: torch.Tensor, dsum: bool, want_v: bool = True,
+                    want_field: bool = True):
+    """(dv, dfield) of warp_volume (dsum=False) / warp_volume_dsum (dsum=True, dout [B,C,H,W])."""
+    v, field, dout = _req(v, "v"), _req(field, "warp_field"), _req(dout, "dout")
+    b, c, d, h, w = v.shape
+    want = (b, c, h, w) if dsum else (b, c, d, h, w)
+    if tuple(dout.shape) != want:
+        raise RuntimeError(f"warp_volume_bwd: dout {tuple(dout.shape)} != {want}")
+    dev = v.device
+    lib = _lib.load()
+    dv = torch.empty_like(v) if want_v else None
+    dfield = torch.empty_like(field) if want_field else None
+    ws_bytes = lib.mphip_warp_volume_bwd_workspace_bytes(b, c, d, h, w)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+    _lib.check(lib.mphip_warp_volume_bwd(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
+                                         _ptr(linspace_table(w, dev)), _ptr(dout), _ptr(dv), _ptr(dfield), b, c, d, h, w,
+                                         field.shape[2], field.shape[3], field.shape[4], int(dsum), _ptr(ws), ws_bytes,
+                                         _stream()), "mphip_warp_volume_bwd")
+    return dv, dfield
+
+
+def warp_field_compose_bwd(dw: torch.Tensor, em_shape, want_theta: bool = True, want_em: bool = True):
+    """(dtheta [B,3,4], dem [B,3,eD,eH,eW]) of warp_field_compose given dw [B,3,G,G,G]."""
+    dw = _req(dw, "dw")
+    b, _, g = dw.shape[0], dw.shape[1], dw.shape[2]
+    lib = _lib.load()
+    dtheta = torch.empty((b, 3, 4), dtype=torch.float32, device=dw.device) if want_theta else None
+    dem = torch.empty((b, 3) + tuple(em_shape[2:]), dtype=torch.float32, device=dw.device) if want_em else None
+    ws_bytes = lib.mphip_warp_field_compose_bwd_workspace_bytes(b, g)
+    ws = torch.empty(ws_bytes // 8, dtype=torch.float64, device=dw.device)
+    _lib.check(lib.mphip_warp_field_compose_bwd(_ptr(dw), _ptr(affine_base_table(g, dw.device)), _ptr(dtheta), _ptr(dem), b,
+                                                em_shape[2], em_shape[3], em_shape[4], g, _ptr(ws), ws_bytes, _stream()),
+               "mphip_warp_field_compose_bwd")
+    return dtheta, dem
+
+
+def rt_theta_bwd(rotation_deg: torch.Tensor, translation: torch.Tensor, dtheta: torch.Tensor, invert: bool):
+    rotation_deg, translation, dtheta = _req(rotation_deg, "rotation"), _req(translation, "translation"), _req(dtheta, "dtheta")
+    b = rotation_deg.shape[0]
+    drot, dtr = torch.empty_like(rotation_deg), torch.empty_like(translation)
+    _lib.check(_lib.load().mphip_rt_theta_bwd(_ptr(rotation_deg), _ptr(translation), _ptr(dtheta), _ptr(drot), _ptr(dtr), b,
+                                              int(bool(invert)), _stream()), "mphip_rt_theta_bwd")
+    return drot, dtr
+
+
+def upsample_nearest_bwd(dout: torch.Tensor, scale: Tuple[int, int, int]) -> torch.Tensor:
+    dout = _req(dout, "dout")
+    n, c, d, h, w = dout.shape
+    sd, sh, sw = (int(v) for v in scale)
+    if d % sd or h % sh or w % sw:
+        raise RuntimeError("upsample_nearest_bwd: gradient dims are not multiples of the scale factors")
+    dx = torch.empty((n, c, d // sd, h // sh, w // sw), dtype=torch.float32, device=dout.device)
+    _lib.check(_lib.load().mphip_upsample_nearest_bwd(_ptr(dout), _ptr(dx), n * c, d // sd, h // sh, w // sw, sd, sh, sw, _stream()),
+               "mphip_upsample_nearest_bwd")
+    return dx
+
+
+def small_gemm(a: torch.Tensor, b: torch.Tensor, trans_a: bool = False, trans_b: bool = False, a2: Optional[torch.Tensor] = None,
+               bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """op(a (+a2)) @ op(b) (+bias) for the generators' tiny dense heads and their gradients (2-D contiguous fp32)."""
+    a, b = _req(a, "a"), _req(b, "b")
+    if a2 is not None:
+        a2 = _req(a2, "a2")
+    m, k = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    k2, n = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    if k != k2:
+        raise RuntimeError(f"small_gemm: inner dims differ ({k} vs {k2})")
+    sam, sak = (1, a.shape[1]) if trans_a else (a.shape[1], 1)
+    sbk, sbn = (1, b.shape[1]) if trans_b else (b.shape[1], 1)
+    out = torch.empty((m, n), dtype=torch.float32, device=a.device)
+    _lib.check(_lib.load().mphip_small_gemm(_ptr(a), _ptr(a2), _ptr(b), _ptr(bias), _ptr(out), m, n, k, sam, sak, sbk, sbn,
+                                            _stream()), "mphip_small_gemm")
+    return out

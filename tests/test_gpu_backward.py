@@ -194,3 +194,134 @@ def test_g3d_sgd_step_matches_cpu(dev, M):
     for name, p in g.named_parameters():
         want = cpu["G3d." + name].detach() - 1e-3 * cpu["G3d." + name].grad
         assert rel_err(p, want) < 1e-5, name
+
+
+# ------------------------------------------------------------------------------- K10: warps, field composition, theta
+def _ag():
+    from megaportrait_hack_amd import autograd as ag
+
+    return ag
+
+
+@pytest.mark.parametrize("dsum", [False, True])
+@pytest.mark.parametrize("kind", ["faithful", "wide", "small"])
+def test_warp_volume_backward(dev, kind, dsum):
+    """grid_sample backward (input: atomicAdd scatter; grid: ATen's clip rule) + the align_corners=True field resize
+    (+ the depth sum), vs CPU autograd of the oracle's apply_warping_field."""
+    fields = {
+        "faithful": R.seeded_tensor((2, 3, 64, 64, 64), 301, scale=1.3) + 0.4,
+        "wide": (R.seeded_tensor((2, 3, 64, 64, 64), 302) + 1.0) * torch.tensor([20.0, 20.0, 6.0]).view(1, 3, 1, 1, 1) - 2.0,
+        "small": R.seeded_tensor((2, 3, 5, 7, 9), 303, scale=6.0) + 4.0,
+    }
+    C, D, H, W = (12, 8, 16, 24) if kind != "small" else (5, 6, 10, 14)
+    v = R.seeded_tensor((2, C, D, H, W), 310, scale=1.7).requires_grad_(True)
+    f = fields[kind].clone().requires_grad_(True)
+    out = R.apply_warping_field(v, f)
+    if dsum:
+        out = out.sum(dim=2)
+    dout = R.seeded_tensor(tuple(out.shape), 311)
+    out.backward(dout)
+    vg, fg = v.detach().to(dev).requires_grad_(True), f.detach().to(dev).requires_grad_(True)
+    got = _ag().WarpVolumeFn.apply(vg, fg, dsum)
+    assert rel_err(got, out) < 1e-5
+    got.backward(dout.to(dev))
+    assert rel_err(vg.grad, v.grad) < 1e-5
+    assert rel_err(fg.grad, f.grad) < 1e-4
+
+
+def test_warp_field_compose_backward(dev):
+    theta = R.seeded_tensor((3, 3, 4), 201).requires_grad_(True)
+    em = ((R.seeded_tensor((3, 3, 16, 16, 16), 202) + 1.0) * 0.5).requires_grad_(True)
+    w = F.affine_grid(theta, (3, 1, 64, 64, 64), align_corners=False).permute(0, 4, 1, 2, 3) \
+        + F.interpolate(em, size=(64, 64, 64), mode="trilinear", align_corners=False)
+    dw = R.seeded_tensor((3, 3, 64, 64, 64), 203)
+    w.backward(dw)
+    tg, eg = theta.detach().to(dev).requires_grad_(True), em.detach().to(dev).requires_grad_(True)
+    got = _ag().WarpFieldComposeFn.apply(tg, eg, 64)
+    got.backward(dw.to(dev))
+    assert rel_err(tg.grad, theta.grad) < 1e-4   # 262144-term sums: ours in double, the CPU reference in fp32
+    assert rel_err(eg.grad, em.grad) < 1e-5
+
+
+@pytest.mark.parametrize("invert", [False, True])
+def test_rt_theta_backward(dev, invert):
+    rot = R.seeded_tensor((8, 3), 101, scale=30.0).requires_grad_(True)
+    tr = R.seeded_tensor((8, 3), 102, scale=0.17).requires_grad_(True)
+    theta = R.affine_theta(rot, tr, invert)
+    dth = R.seeded_tensor((8, 3, 4), 103)
+    theta.backward(dth)
+    rg, tg = rot.detach().to(dev).requires_grad_(True), tr.detach().to(dev).requires_grad_(True)
+    got = _ag().RtThetaFn.apply(rg, tg, invert)
+    got.backward(dth.to(dev))
+    assert rel_err(rg.grad, rot.grad) < 1e-5
+    assert rel_err(tg.grad, tr.grad) < 1e-5
+
+
+def _check_param_grads(named_params, ref_grad, tol):
+    """Every parameter's gradient within `tol` of its own max-abs.  A conv bias feeding a GroupNorm whose groups hold
+    one channel each (FlowField's 32-channel block, model.py:374-383) has an exactly zero true gradient — the norm
+    removes a per-channel shift — so both sides are rounding noise of sum(dy); a bias is therefore measured on the
+    scale of max(own gradient, 1 % of its layer's weight gradient), which that noise is proportional to."""
+    items = [(n, p, ref_grad(n)) for n, p in named_params]
+    items = [(n, p, g) for n, p, g in items if g is not None]
+    by_name = {n: g for n, _, g in items}
+    bad = []
+    for n, p, g in items:
+        assert p.grad is not None, n
+        scale = g.abs().max().item()
+        sib = by_name.get(n[:-len("bias")] + "weight") if n.endswith(".bias") else None
+        if sib is not None:
+            scale = max(scale, 1e-2 * sib.abs().max().item())
+        err = (p.grad.detach().cpu().double() - g.double()).abs().max().item() / scale
+        if err >= tol:
+            bad.append((err, n, g.abs().max().item()))
+    assert not bad, sorted(bad, reverse=True)[:6]
+
+
+def test_flowfield_generator_backward(dev, M):
+    """WarpGeneratorS2C end to end (model.py:927-975): (z+e)@Gamma -> FlowField (1x1 conv, four ResBlock3D_Adaptive with
+    AdaptiveGroupNorm + nearest upsampling, conv -> GroupNorm(1) -> ReLU -> tanh) -> rt + resized field; gradients of
+    every parameter and of R, t, z, e vs CPU autograd."""
+    sd_all = R.seeded_gbase_hot_state_dict(7)
+    pre = "warp_generator_s2c."
+    sd = {k: v for k, v in sd_all.items() if k.startswith(pre)}
+    gen = M.WarpGeneratorS2C(num_channels=512)
+    M.load_hot_state_dict(gen, {k[len(pre):]: v for k, v in sd.items()})
+    gen = gen.to(dev).train()
+    inp = R.seeded_hot_inputs(2, 5)
+    names = ("Rs", "ts", "zs", "es")
+    cpu_in = [inp[k].clone().requires_grad_(True) for k in names]
+    cpu_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    w_ref = R.warp_generator(*cpu_in, cpu_sd, pre, invert=True)
+    dw = R.seeded_tensor(tuple(w_ref.shape), 91)
+    w_ref.backward(dw)
+    gpu_in = [inp[k].to(dev).requires_grad_(True) for k in names]
+    w = gen(*gpu_in)
+    assert rel_err(w, w_ref) < 1e-5
+    w.backward(dw.to(dev))
+    for k, a, b in zip(names, gpu_in, cpu_in):
+        assert rel_err(a.grad, b.grad) < 1e-3, k
+    _check_param_grads(gen.named_parameters(), lambda n: cpu_sd[pre + n].grad, 1e-3)
+    assert gen.adaptive_matrix_beta.grad is None   # unused in the reference's forward too (model.py:958-963)
+
+
+def test_hot_slice_backward(dev, M):
+    """The whole Gbase hot slice (model.py:1151-1171) under autograd at the 256px configuration's volume size
+    (96x16x32x32): loss gradient wrt all inputs and every parameter vs CPU autograd of the oracle."""
+    sd = R.seeded_gbase_hot_state_dict(7)
+    hot = M.GbaseHotSlice()
+    M.load_hot_state_dict(hot, sd)
+    hot = hot.to(dev).train()
+    inp = R.seeded_hot_inputs(1, 43, D=16, H=32, W=32)
+    cpu_in = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    cpu_sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    out_ref = R.hot_slice(sd=cpu_sd, **cpu_in)
+    dout = R.seeded_tensor(tuple(out_ref.shape), 92)
+    out_ref.backward(dout)
+    gpu_in = {k: v.to(dev).requires_grad_(True) for k, v in inp.items()}
+    out = hot.forward_any_size(**gpu_in)
+    assert rel_err(out, out_ref) < 1e-4
+    out.backward(dout.to(dev))
+    for k in inp:
+        assert rel_err(gpu_in[k].grad, cpu_in[k].grad) < 2e-3, k
+    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3)

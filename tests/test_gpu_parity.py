@@ -452,10 +452,6 @@ def test_errors_are_loud(ops, M, dev):
         ops.warp_volume(torch.zeros(1, 2, 4, 4, 4), torch.zeros(1, 3, 4, 4, 4))       # CPU tensors: no fallback
     with pytest.raises(RuntimeError):
         ops.conv3d(torch.zeros(1, 5, 4, 4, 4, device=dev), ops.PackedConv(torch.zeros(4, 6, 3, 3, 3, device=dev), None))
-    s2c = M.WarpGeneratorS2C(num_channels=512).to(dev)
-    with pytest.raises(NotImplementedError):               # still forward-only: refuses instead of silently detaching
-        s2c(torch.zeros(1, 3, device=dev), torch.zeros(1, 3, device=dev), torch.zeros(1, 512, device=dev),
-            torch.zeros(1, 512, device=dev))
     hot = M.GbaseHotSlice().to(dev)
     bad = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 1, D=8, H=8, W=8).items()}
     with torch.no_grad(), pytest.raises(AssertionError):
