@@ -17,10 +17,10 @@ def _bwd_pack(conv) -> ops.PackedConv:
     """PackedConv of the flipped/transposed weight (bwd-data as a forward conv), cached on the module like the
     forward pack and rebuilt when the parameter changes."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device))
+    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device), ops.weight_epoch())
     hit = conv.__dict__.get("_mphip_bwd_pack")
-    if hit is None or hit[0] != key:
-        hit = (key, ops.PackedConv(ops.conv_bwd_data_weight(w), None))
+    if hit is None or hit[0] != key or ops.repacking():
+        hit = (key, ops.PackedConv(w, None, transposed=True))
         conv.__dict__["_mphip_bwd_pack"] = hit
     return hit[1]
 

@@ -379,9 +379,59 @@ small_gemm_kernel(const float *__restrict__ A, const float *__restrict__ A2, con
     out[t] = (float)acc;
 }
 
+// same product, one wavefront per output: the K loop is spread over the 64 lanes (few outputs, long K: ds = dx @ W)
+__global__ void __launch_bounds__(256)
+small_gemm_wave_kernel(const float *__restrict__ A, const float *__restrict__ A2, const float *__restrict__ Bm,
+                       const float *__restrict__ bias, float *__restrict__ out, int M, int N, int K, long sam, long sak, long sbk,
+                       long sbn) {
+    const size_t t = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= (size_t)M * N) return;
+    const int n = (int)(t % N), m = (int)(t / N), lane = threadIdx.x & 63;
+    double acc = 0.0;
+    for (int k = lane; k < K; k += 64) {
+        float a = A[m * sam + k * sak];
+        if (A2) a += A2[m * sam + k * sak];
+        acc += (double)a * (double)Bm[k * sbk + n * sbn];
+    }
+#pragma unroll
+    for (int sft = 32; sft >= 1; sft >>= 1) acc += __shfl_xor(acc, sft, 64);
+    if (lane == 0) out[t] = (float)(acc + (bias ? (double)bias[n] : 0.0));
+}
+
+// conv3d backward-weight for tiny volumes (FlowField's first blocks: 4..256 voxels per sample, up to 512x256x27
+// outputs): one thread per dW element, looping over the voxels — the MFMA kernels above would spend their time
+// staging mostly-padding tiles.  Exact fp32, fixed order.
+template <int KS>
+__global__ void __launch_bounds__(256)
+conv_bwd_weight_direct_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dw, int N, int Ci,
+                              int Co, int D, int H, int W) {
+    constexpr int TAPS = KS * KS * KS;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (size_t)Co * Ci * TAPS) return;
+    const int tap = (int)(t % TAPS);
+    const int ci = (int)((t / TAPS) % Ci), co = (int)(t / ((size_t)TAPS * Ci));
+    const int kd = KS == 3 ? tap / 9 - 1 : 0, kh = KS == 3 ? (tap / 3) % 3 - 1 : 0, kw = KS == 3 ? tap % 3 - 1 : 0;
+    const int HW = H * W, DHW = D * HW;
+    // output voxels whose shifted input voxel is inside the volume
+    const int d_lo = max(0, -kd), d_hi = min(D, D - kd), h_lo = max(0, -kh), h_hi = min(H, H - kh);
+    const int w_lo = max(0, -kw), w_hi = min(W, W - kw);
+    float acc = 0.0f;
+    for (int n = 0; n < N; ++n) {
+        const float *gy = dy + ((size_t)n * Co + co) * DHW;
+        const float *xx = x + ((size_t)n * Ci + ci) * DHW + kd * HW + kh * W + kw;
+        for (int d = d_lo; d < d_hi; ++d)
+            for (int h = h_lo; h < h_hi; ++h)
+                for (int w = w_lo; w < w_hi; ++w) acc += gy[d * HW + h * W + w] * xx[d * HW + h * W + w];
+    }
+    dw[t] = acc;
+}
+
 }  // namespace mphip
 
 using namespace mphip;
+
+// tiny volumes: one thread per dW element beats tiling (see conv_bwd_weight_direct_kernel)
+static bool bwd_weight_direct(int N, int D, int H, int W) { return (long)N * D * H * W <= 2048; }
 
 static int bw_splits(long ntiles, int blocks_xy) {
     int s = 1;
@@ -397,6 +447,7 @@ extern "C" int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, i
 
 extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    if (bwd_weight_direct(N, D, H, W)) return 16;  // unused
     if (precision == 1) return bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W);
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int bxy = ((Ci + 31) / 32) * ((Co + 95) / 96) * (k == 3 ? 3 : 1);
@@ -419,6 +470,14 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, const fl
         return MPHIP_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (bwd_weight_direct(N, D, H, W)) {
+        const size_t nw = (size_t)Co * Ci * k * k * k;
+        if (k == 3)
+            hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<3>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
+        else
+            hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<1>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
+        return check_launch("conv3d_bwd_weight(direct)");
+    }
     if (precision == 1) return bwd_weight_f16x3_launch(x, dy, dy_scale, dw, N, Ci, Co, D, H, W, workspace, s);
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;
@@ -510,7 +569,11 @@ extern "C" int mphip_small_gemm(const float *a, const float *a2, const float *b,
                                 int K, long sam, long sak, long sbk, long sbn, void *stream) {
     MPHIP_REQUIRE(a && b && out, "small_gemm: null pointer");
     MPHIP_REQUIRE(M > 0 && N > 0 && K > 0, "small_gemm: bad dims");
-    hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv((size_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, a, a2, b, bias, out, M,
-                       N, K, sam, sak, sbk, sbn);
+    if ((size_t)M * N <= 65536 && K >= 128)
+        hipLaunchKernelGGL(small_gemm_wave_kernel, dim3(cdiv((size_t)M * N, 4)), dim3(256), 0, (hipStream_t)stream, a, a2, b, bias,
+                           out, M, N, K, sam, sak, sbk, sbn);
+    else
+        hipLaunchKernelGGL(small_gemm_kernel, dim3(cdiv((size_t)M * N, 256)), dim3(256), 0, (hipStream_t)stream, a, a2, b, bias, out,
+                           M, N, K, sam, sak, sbk, sbn);
     return check_launch("small_gemm");
 }

@@ -23,14 +23,17 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 }
 
 // OIDHW [Co,Ci,k,k,k] -> [k^3][CiP][CoP], zero padded.
+// transposed: `w` is the ORIGINAL conv's weight [Ci][Co][taps] and the packed conv is its bwd-data conv:
+// Wt[co][ci][tap] = w[ci][co][taps-1-tap] (flipping all three axes reverses the linear tap index).
 __global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int CoP,
-                                   int CiP, int taps) {
+                                   int CiP, int taps, int transposed) {
     size_t n = (size_t)taps * CiP * CoP;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         int co = (int)(i % CoP);
         int ci = (int)((i / CoP) % CiP);
         int tap = (int)(i / ((size_t)CoP * CiP));
-        wp[i] = (co < Co && ci < Ci) ? w[((size_t)co * Ci + ci) * taps + tap] : 0.0f;
+        const size_t src = transposed ? ((size_t)ci * Co + co) * taps + (taps - 1 - tap) : ((size_t)co * Ci + ci) * taps + tap;
+        wp[i] = (co < Co && ci < Ci) ? w[src] : 0.0f;
     }
 }
 
@@ -459,17 +462,29 @@ extern "C" size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision
     return 0;
 }
 
+static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, int transposed, void *stream);
+
 extern "C" int mphip_pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, void *stream) {
+    return pack_conv_weight(w, wp, Co, Ci, k, precision, 0, stream);
+}
+
+// packs the bwd-data conv of the conv whose OIDHW weight is `w` [Ci][Co][k^3] (Co/Ci are the bwd-data conv's own
+// output/input channels = the original conv's input/output channels): no flipped/transposed copy is materialised
+extern "C" int mphip_pack_conv_weight_bwd_data(const float *w, void *wp, int Co, int Ci, int k, int precision, void *stream) {
+    return pack_conv_weight(w, wp, Co, Ci, k, precision, 1, stream);
+}
+
+static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, int transposed, void *stream) {
     MPHIP_REQUIRE(w && wp, "pack_conv_weight: null pointer");
     MPHIP_REQUIRE(Co > 0 && Ci > 0 && (k == 1 || k == 3), "pack_conv_weight: bad dims");
     MPHIP_REQUIRE(mphip_packed_weight_bytes(Co, Ci, k, precision) > 0,
                   "pack_conv_weight: precision %d not available for Co=%d Ci=%d k=%d", precision, Co, Ci, k);
-    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, (hipStream_t)stream);
+    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, transposed, (hipStream_t)stream);
     size_t n = packed_elems_f32(Co, Ci, k);
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float *)wp, Co, Ci,
-                       (Co + 31) / 32 * 32, (Ci + 1) / 2 * 2, k * k * k);
+                       (Co + 31) / 32 * 32, (Ci + 1) / 2 * 2, k * k * k, transposed);
     return check_launch("pack_conv_weight");
 }
 

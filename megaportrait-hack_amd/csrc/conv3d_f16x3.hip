@@ -71,7 +71,7 @@ __device__ __forceinline__ float weight_scale(unsigned maxbits) {
 
 // OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*NG + g][part][tap][kg][co][8] f16 (after the header)
 __global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in,
-                                  float *__restrict__ hdr_out, int Co, int Ci) {
+                                  float *__restrict__ hdr_out, int Co, int Ci, int transposed) {
     const float scale = weight_scale(hdr_in[2]);
     const int nchunks = Ci / F16X3_KC;
     const size_t n = (size_t)(Co / F16X3_COT) * nchunks * F16X3_NG * (SLAB_HALFS / 2);  // one thread per (hi,lo) pair
@@ -86,7 +86,9 @@ __global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restr
         const int cot = (int)(r / nchunks);
         const int ci = chunk * F16X3_KC + kg * 8 + e, tap = g * F16X3_TG + tg, cog = cot * F16X3_COT + co;
         _Float16 hi, lo;
-        split_f16(w[((size_t)cog * Ci + ci) * 27 + tap] * scale, hi, lo);
+        // transposed: w is the original conv's [Ci][Co][27] weight, this pack its bwd-data conv (taps reversed)
+        const size_t src = transposed ? ((size_t)ci * Co + cog) * 27 + (26 - tap) : ((size_t)cog * Ci + ci) * 27 + tap;
+        split_f16(w[src] * scale, hi, lo);
         const size_t slab = ((size_t)cot * nchunks + chunk) * F16X3_NG + g;
         const size_t inner = (((size_t)tg * 2 + kg) * F16X3_COT + co) * 8 + e;
         out[slab * SLAB_HALFS + inner] = hi;
@@ -398,7 +400,7 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     return p;
 }
 
-int f16x3_pack(const float *w, void *out, int Co, int Ci, hipStream_t s) {
+int f16x3_pack(const float *w, void *out, int Co, int Ci, int transposed, hipStream_t s) {
     unsigned *hdr = (unsigned *)out;
     hipError_t e = hipMemsetAsync(out, 0, 16, s);
     if (e != hipSuccess) {
@@ -408,7 +410,7 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, hipStream_t s) {
     const size_t n = (size_t)Co * Ci * 27;
     hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(256, (n + 8191) / 8192)), dim3(256), 0, s, w, n, hdr);
     hipLaunchKernelGGL(f16x3_pack_kernel, dim3(2048), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), (const unsigned *)hdr,
-                       (float *)out, Co, Ci);
+                       (float *)out, Co, Ci, transposed);
     return check_launch("pack_conv_weight(f16x3)");
 }
 

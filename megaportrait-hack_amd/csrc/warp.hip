@@ -561,65 +561,133 @@ extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const 
 // the align_corners=False resize of the flow field.
 namespace mphip {
 
-// One thread per output voxel and channel slice: scatters dout into dv (hardware fp32 atomics; the reference's
-// own CUDA backward is an atomicAdd scatter too) and accumulates the coordinate gradient of its slice.
+// Scatter pass (dv via hardware fp32 atomics — the reference's own CUDA backward is an atomicAdd scatter too — and the
+// coordinate gradient of each channel slice): a workgroup owns a 4x16x16 tile of output voxels (4 per thread) and WB_CH
+// channels.  With a smooth field the source voxels of the tile form a small box (as in K2): dv contributions are
+// accumulated in an LDS image of that box (ds_add_f32) and flushed with ONE global atomic per box element, in
+// coalesced rows — ~1.7 global atomics per output value instead of 8 scattered ones.  A box that does not fit
+// (wild field) falls back to direct global atomics for that tile.
+constexpr int WB_CH = 8;
+constexpr int WB_LDS = 16384;  // floats: 64 KB of accumulation image
 template <bool DSUM>
 __global__ void __launch_bounds__(256)
-warp_bwd_kernel(const float *__restrict__ v, const float *__restrict__ coords, const float *__restrict__ dout,
-                float *__restrict__ dv, float *__restrict__ dcoords, int B, int C, int D, int H, int W, int cpb) {
-    const size_t vol = (size_t)D * H * W;
-    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (size_t)B * vol) return;
-    const int b = (int)(t / vol);
-    const size_t r = t - (size_t)b * vol;
+warp_bwd_tiled_kernel(const float *__restrict__ v, const float *__restrict__ coords, const float *__restrict__ dout,
+                      float *__restrict__ dv, float *__restrict__ dcoords, int B, int C, int D, int H, int W) {
+    __shared__ float img[WB_LDS];
+    __shared__ int red[24];
     const int HW = H * W;
-    const int hw = (int)(r % HW);
-    const float cx = coords[t * 3], cy = coords[t * 3 + 1], cz = coords[t * 3 + 2];
-    const int x0 = (int)floorf(cx), y0 = (int)floorf(cy), z0 = (int)floorf(cz);
-    float wx1 = cx - (float)x0, wx0 = (float)(x0 + 1) - cx;
-    float wy1 = cy - (float)y0, wy0 = (float)(y0 + 1) - cy;
-    float wz1 = cz - (float)z0, wz0 = (float)(z0 + 1) - cz;
-    const bool vx = x0 + 1 < W, vy = y0 + 1 < H, vz = z0 + 1 < D;
-    if (!vx) wx1 = 0.0f;  // the +1 corner is outside: ATen skips it (value and scatter)
-    if (!vy) wy1 = 0.0f;
-    if (!vz) wz1 = 0.0f;
-    const int base = (z0 * H + y0) * W + x0;
-    const int dx = vx ? 1 : 0, dy = vy ? W : 0, dz = vz ? HW : 0;
-    const float w000 = wx0 * wy0 * wz0, w100 = wx1 * wy0 * wz0, w010 = wx0 * wy1 * wz0, w110 = wx1 * wy1 * wz0;
-    const float w001 = wx0 * wy0 * wz1, w101 = wx1 * wy0 * wz1, w011 = wx0 * wy1 * wz1, w111 = wx1 * wy1 * wz1;
-    const int c_begin = blockIdx.y * cpb, c_end = min(C, c_begin + cpb);
-    float gx = 0.0f, gy = 0.0f, gz = 0.0f;
-    for (int ch = c_begin; ch < c_end; ++ch) {
-        const size_t plane = (size_t)b * C + ch;
-        const float g = DSUM ? dout[plane * HW + hw] : dout[plane * vol + r];
-        if (dcoords) {
-            const float *p = v + plane * vol + base;
-            const float v000 = p[0], v100 = vx ? p[dx] : 0.0f, v010 = vy ? p[dy] : 0.0f, v110 = (vx && vy) ? p[dy + dx] : 0.0f;
-            const float v001 = vz ? p[dz] : 0.0f, v101 = (vz && vx) ? p[dz + dx] : 0.0f;
-            const float v011 = (vz && vy) ? p[dz + dy] : 0.0f, v111 = (vz && vy && vx) ? p[dz + dy + dx] : 0.0f;
-            gx += g * (((v100 - v000) * wy0 + (v110 - v010) * wy1) * wz0 + ((v101 - v001) * wy0 + (v111 - v011) * wy1) * wz1);
-            gy += g * (((v010 - v000) * wx0 + (v110 - v100) * wx1) * wz0 + ((v011 - v001) * wx0 + (v111 - v101) * wx1) * wz1);
-            gz += g * (((v001 - v000) * wx0 + (v101 - v100) * wx1) * wy0 + ((v011 - v010) * wx0 + (v111 - v110) * wx1) * wy1);
+    const size_t vol = (size_t)D * HW;
+    const int tiles_w = (W + 15) / 16, tiles_h = (H + 15) / 16, tiles_d = (D + 3) / 4;
+    int bid = blockIdx.x;
+    const int tw = bid % tiles_w; bid /= tiles_w;
+    const int th = bid % tiles_h; bid /= tiles_h;
+    const int td = bid % tiles_d;
+    const int b = bid / tiles_d;
+    const int ox = tw * 16 + (threadIdx.x & 15), oy = th * 16 + (threadIdx.x >> 4);
+    const int c0 = blockIdx.y * WB_CH, cs = min(WB_CH, C - c0);
+
+    bool ok[4];
+    int base[4], dxyz[4];
+    float wx1[4], wy1[4], wz1[4], cxs[4], cys[4], czs[4];
+    int x0s[4], y0s[4], z0s[4];
+    int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int oz = td * 4 + k;
+        ok[k] = ox < W && oy < H && oz < D;
+        const size_t t = (size_t)b * vol + (size_t)(ok[k] ? oz : 0) * HW + (ok[k] ? oy * W + ox : 0);
+        const float cx = coords[t * 3], cy = coords[t * 3 + 1], cz = coords[t * 3 + 2];
+        const int x0 = (int)floorf(cx), y0 = (int)floorf(cy), z0 = (int)floorf(cz);
+        cxs[k] = cx; cys[k] = cy; czs[k] = cz;
+        x0s[k] = x0; y0s[k] = y0; z0s[k] = z0;
+        const bool vx = x0 + 1 < W, vy = y0 + 1 < H, vz = z0 + 1 < D;
+        wx1[k] = vx ? cx - (float)x0 : 0.0f;  // the +1 corner outside: ATen skips it
+        wy1[k] = vy ? cy - (float)y0 : 0.0f;
+        wz1[k] = vz ? cz - (float)z0 : 0.0f;
+        dxyz[k] = (vx ? 1 : 0) | (vy ? 2 : 0) | (vz ? 4 : 0);
+        base[k] = (z0 * H + y0) * W + x0;
+        if (ok[k]) {
+            lx = min(lx, x0); ly = min(ly, y0); lz = min(lz, z0);
+            hx = max(hx, x0); hy = max(hy, y0); hz = max(hz, z0);
         }
-        if (dv) {
-            float *q = dv + plane * vol + base;
-            unsafeAtomicAdd(q, w000 * g);
-            if (w100 != 0.0f) unsafeAtomicAdd(q + dx, w100 * g);
-            if (w010 != 0.0f) unsafeAtomicAdd(q + dy, w010 * g);
-            if (w110 != 0.0f) unsafeAtomicAdd(q + dy + dx, w110 * g);
-            if (w001 != 0.0f) unsafeAtomicAdd(q + dz, w001 * g);
-            if (w101 != 0.0f) unsafeAtomicAdd(q + dz + dx, w101 * g);
-            if (w011 != 0.0f) unsafeAtomicAdd(q + dz + dy, w011 * g);
-            if (w111 != 0.0f) unsafeAtomicAdd(q + dz + dy + dx, w111 * g);
+    }
+    const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
+    const int bvol = bx.ex * bx.ey * bx.ez;
+    const bool staged = dv != nullptr && bvol * WB_CH <= WB_LDS && bvol > 0;  // block-uniform
+    if (staged) {
+        for (int i = threadIdx.x; i < bvol * cs; i += 256) img[i] = 0.0f;
+        __syncthreads();
+    }
+    float gx[4] = {0.f, 0.f, 0.f, 0.f}, gy[4] = {0.f, 0.f, 0.f, 0.f}, gz[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < cs; ++c) {
+        const size_t plane = (size_t)b * C + c0 + c;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const int oz = td * 4 + k;
+            const float g = DSUM ? dout[plane * HW + oy * W + ox] : dout[plane * vol + (size_t)oz * HW + oy * W + ox];
+            const bool vx = dxyz[k] & 1, vy = dxyz[k] & 2, vz = dxyz[k] & 4;
+            const int dx = vx ? 1 : 0, dy = vy ? W : 0, dz = vz ? HW : 0;
+            const float ax = (float)(x0s[k] + 1) - cxs[k], ay = (float)(y0s[k] + 1) - cys[k], az = (float)(z0s[k] + 1) - czs[k];
+            const float bx1 = wx1[k], by1 = wy1[k], bz1 = wz1[k];
+            if (dcoords) {
+                const float *p = v + plane * vol + base[k];
+                const float v000 = p[0], v100 = vx ? p[dx] : 0.0f, v010 = vy ? p[dy] : 0.0f, v110 = (vx && vy) ? p[dy + dx] : 0.0f;
+                const float v001 = vz ? p[dz] : 0.0f, v101 = (vz && vx) ? p[dz + dx] : 0.0f;
+                const float v011 = (vz && vy) ? p[dz + dy] : 0.0f, v111 = (vz && vy && vx) ? p[dz + dy + dx] : 0.0f;
+                gx[k] += g * (((v100 - v000) * ay + (v110 - v010) * by1) * az + ((v101 - v001) * ay + (v111 - v011) * by1) * bz1);
+                gy[k] += g * (((v010 - v000) * ax + (v110 - v100) * bx1) * az + ((v011 - v001) * ax + (v111 - v101) * bx1) * bz1);
+                gz[k] += g * (((v001 - v000) * ax + (v101 - v100) * bx1) * ay + ((v011 - v010) * ax + (v111 - v110) * bx1) * by1);
+            }
+            if (dv) {
+                float *q;
+                int sx, sy, sz;
+                if (staged) {
+                    q = img + c * bvol + ((z0s[k] - bx.oz) * bx.ey + (y0s[k] - bx.oy)) * bx.ex + (x0s[k] - bx.ox);
+                    sx = dx; sy = vy ? bx.ex : 0; sz = vz ? bx.ex * bx.ey : 0;
+                } else {
+                    q = dv + plane * vol + base[k];
+                    sx = dx; sy = dy; sz = dz;
+                }
+                const float w00 = ay * az * g, w10 = by1 * az * g, w01 = ay * bz1 * g, w11 = by1 * bz1 * g;
+                unsafeAtomicAdd(q, ax * w00);
+                if (bx1 != 0.0f) unsafeAtomicAdd(q + sx, bx1 * w00);
+                if (by1 != 0.0f) {
+                    unsafeAtomicAdd(q + sy, ax * w10);
+                    if (bx1 != 0.0f) unsafeAtomicAdd(q + sy + sx, bx1 * w10);
+                }
+                if (bz1 != 0.0f) {
+                    unsafeAtomicAdd(q + sz, ax * w01);
+                    if (bx1 != 0.0f) unsafeAtomicAdd(q + sz + sx, bx1 * w01);
+                    if (by1 != 0.0f) {
+                        unsafeAtomicAdd(q + sz + sy, ax * w11);
+                        if (bx1 != 0.0f) unsafeAtomicAdd(q + sz + sy + sx, bx1 * w11);
+                    }
+                }
+            }
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        const int exy = bx.ex * bx.ey;
+        for (int i = threadIdx.x; i < bvol * cs; i += 256) {
+            const float a = img[i];
+            if (a == 0.0f) continue;
+            const int c = i / bvol, e = i - c * bvol;
+            const int z = e / exy, r2 = e - z * exy, y = r2 / bx.ex, x = r2 - y * bx.ex;
+            unsafeAtomicAdd(dv + ((size_t)b * C + c0 + c) * vol + (size_t)(bx.oz + z) * HW + (bx.oy + y) * W + bx.ox + x, a);
         }
     }
     if (dcoords) {
-        // clip_coordinates_set_grad: a clipped coordinate (<= 0 or >= size-1) passes no gradient; the remaining chain
-        // (unnormalise (S-1)/2, then 2/(S-1) of model.py:1058, then d(grid+field)/dfield = 1) multiplies to 1
-        float *o = dcoords + ((size_t)blockIdx.y * B * vol + t) * 3;
-        o[0] = (cx > 0.0f && cx < (float)(W - 1)) ? gx : 0.0f;
-        o[1] = (cy > 0.0f && cy < (float)(H - 1)) ? gy : 0.0f;
-        o[2] = (cz > 0.0f && cz < (float)(D - 1)) ? gz : 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (!ok[k]) continue;
+            const size_t t = (size_t)b * vol + (size_t)(td * 4 + k) * HW + oy * W + ox;
+            float *o = dcoords + ((size_t)blockIdx.y * B * vol + t) * 3;
+            o[0] = (cxs[k] > 0.0f && cxs[k] < (float)(W - 1)) ? gx[k] : 0.0f;
+            o[1] = (cys[k] > 0.0f && cys[k] < (float)(H - 1)) ? gy[k] : 0.0f;
+            o[2] = (czs[k] > 0.0f && czs[k] < (float)(D - 1)) ? gz[k] : 0.0f;
+        }
     }
 }
 
@@ -820,7 +888,7 @@ __global__ void rt_theta_bwd_kernel(const float *__restrict__ rot, const float *
     drot[b * 3 + 2] = (float)(dg * k);
 }
 
-constexpr int WARP_BWD_CPB = 12;  // channels per slice of the scatter pass
+constexpr int WARP_BWD_CPB = WB_CH;  // channels per slice of the scatter pass
 
 }  // namespace mphip
 
@@ -859,13 +927,13 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
         return MPHIP_ELAUNCH;
     }
     const int groups = cdiv(C, WARP_BWD_CPB);
-    dim3 grid(cdiv(nvox, 256), groups);
+    dim3 grid((unsigned)((size_t)B * cdiv(D, 4) * cdiv(H, 16) * cdiv(W, 16)), groups);
     if (dsum)
-        hipLaunchKernelGGL(warp_bwd_kernel<true>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
-                           dfield ? dcoords : nullptr, B, C, D, H, W, WARP_BWD_CPB);
+        hipLaunchKernelGGL(warp_bwd_tiled_kernel<true>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
+                           dfield ? dcoords : nullptr, B, C, D, H, W);
     else
-        hipLaunchKernelGGL(warp_bwd_kernel<false>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
-                           dfield ? dcoords : nullptr, B, C, D, H, W, WARP_BWD_CPB);
+        hipLaunchKernelGGL(warp_bwd_tiled_kernel<false>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
+                           dfield ? dcoords : nullptr, B, C, D, H, W);
     if (dfield) {
         const size_t nf = (size_t)B * 3 * fD * fH * fW;
         hipLaunchKernelGGL(resize_trilinear_adjoint_kernel<true>, dim3(cdiv(nf, 256)), dim3(256), 0, s, (const float *)dcoords,

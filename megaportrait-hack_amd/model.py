@@ -32,9 +32,10 @@ class _PackCache:
     @staticmethod
     def get(conv: nn.Module) -> ops.PackedConv:
         w, b = conv.weight, conv.bias
-        key = (w.data_ptr(), w._version, tuple(w.shape), None if b is None else (b.data_ptr(), b._version), str(w.device))
+        key = (w.data_ptr(), w._version, tuple(w.shape), None if b is None else (b.data_ptr(), b._version), str(w.device),
+               ops.weight_epoch())
         hit = conv.__dict__.get("_mphip_pack")
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] != key or ops.repacking():
             hit = (key, ops.PackedConv(w, b))
             conv.__dict__["_mphip_pack"] = hit
         return hit[1]
@@ -154,9 +155,9 @@ class FlowField(nn.Module):
         """conv1x1.weight [2048,512,1,1] re-laid as [K=512][N=2048] (N contiguous) for the coalesced matmul kernel;
         rebuilt when the parameter changes."""
         w = self.conv1x1.weight
-        key = (w.data_ptr(), w._version, str(w.device))
+        key = (w.data_ptr(), w._version, str(w.device), ops.weight_epoch())
         hit = self.__dict__.get("_w_kn")
-        if hit is None or hit[0] != key:
+        if hit is None or hit[0] != key or ops.repacking():
             hit = (key, w.detach().reshape(2048, 512).t().contiguous())
             self.__dict__["_w_kn"] = hit
         return hit[1]
@@ -410,7 +411,9 @@ class GraphedHotSlice:
         for k, v in inputs.items():
             if v.data_ptr() != self.static_in[k].data_ptr():
                 self.static_in[k].copy_(v)
+        torch.cuda.current_stream().synchronize()  # replay bracketed by syncs: see training.GraphedTrainStep
         self.graph.replay()
+        torch.cuda.synchronize()
         return self.static_out
 
 

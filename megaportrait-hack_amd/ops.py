@@ -175,11 +175,14 @@ class PackedConv:
     """One Conv3d / 1x1 Conv2d: OIDHW fp32 weight + bias, packed lazily per precision into the
     kernel layouts described in include/mphip.h."""
 
-    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed")
+    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed", "transposed")
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor]):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool = False):
+        """transposed: this object is the bwd-data conv of the conv whose weight is `weight` (Co/Ci swapped, taps
+        flipped); the packing kernels read the original layout directly."""
         weight = _req(weight.detach(), "conv weight")
-        co, ci = weight.shape[0], weight.shape[1]
+        self.transposed = bool(transposed)
+        co, ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         k = weight.shape[2]
         if weight.dim() == 4:  # Conv2d 1x1 (model.py:425)
             if tuple(weight.shape[2:]) != (1, 1):
@@ -187,7 +190,7 @@ class PackedConv:
         elif weight.dim() != 5 or tuple(weight.shape[2:]) != (k, k, k) or k not in (1, 3):
             raise RuntimeError(f"PackedConv: unsupported weight shape {tuple(weight.shape)}")
         self.weight = weight
-        self.bias = None if bias is None else _req(bias.detach(), "conv bias").clone()
+        self.bias = None if bias is None else _req(bias.detach(), "conv bias")  # a view: the owner re-creates the pack when it changes
         self.co, self.ci, self.k = co, ci, k
         self._packed = {}
 
@@ -199,8 +202,8 @@ class PackedConv:
             if nbytes == 0:
                 raise RuntimeError(f"PackedConv: precision {precision} not available for Co={self.co} Ci={self.ci} k={self.k}")
             wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.weight.device)
-            _lib.check(lib.mphip_pack_conv_weight(_ptr(self.weight), _ptr(wp), self.co, self.ci, self.k, precision, _stream()),
-                       "mphip_pack_conv_weight")
+            fn = lib.mphip_pack_conv_weight_bwd_data if self.transposed else lib.mphip_pack_conv_weight
+            _lib.check(fn(_ptr(self.weight), _ptr(wp), self.co, self.ci, self.k, precision, _stream()), "mphip_pack_conv_weight")
             self._packed[precision] = wp
         return wp
 
@@ -210,6 +213,38 @@ class PackedConv:
 
 
 _conv_hook = None
+_repack_always = False
+
+
+class repack_always:
+    """Context: packed-weight caches are bypassed (training.GraphedTrainStep captures the re-packing of the updated
+    weights into its graph; a cache hit at capture time would freeze stale packs into every replay)."""
+
+    def __enter__(self):
+        global _repack_always
+        self._old, _repack_always = _repack_always, True
+
+    def __exit__(self, *exc):
+        global _repack_always
+        _repack_always = self._old
+
+
+def repacking() -> bool:
+    return _repack_always
+
+
+_weight_epoch = 0
+
+
+def invalidate_packs() -> None:
+    """Bumps the epoch that is part of every packed-weight cache key.  For writers that change parameter memory without
+    bumping the tensors' autograd version counters — a hipGraph replay of an optimizer step (training.GraphedTrainStep)."""
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+def weight_epoch() -> int:
+    return _weight_epoch
 
 
 def set_conv_hook(hook) -> None:
@@ -552,11 +587,6 @@ def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, dy_scale: Optio
     _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dy_scale), _ptr(dw), n, ci, co, d, h, w, k, prec, _ptr(ws),
                                            ws_bytes, _stream()), "mphip_conv3d_bwd_weight")
     return dw
-
-
-def conv_bwd_data_weight(weight: torch.Tensor) -> torch.Tensor:
-    """The conv whose forward is the bwd-data of `weight`'s conv: Wt[ci][co][a][b][c] = W[co][ci][k-1-a][k-1-b][k-1-c]."""
-    return weight.detach().flip(2, 3, 4).transpose(0, 1).contiguous()
 
 
 def groupnorm_bwd(x, y, dy, stats, gamma, groups: int, relu, want_res: bool, beta=None, w2=None):

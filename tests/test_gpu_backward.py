@@ -71,13 +71,14 @@ def test_conv3d_bwd_weight(dev, ops, shape, dy_mag):
                                    (1, 40, 24, 3, 5, 7, 3)])
 @pytest.mark.parametrize("dy_mag", [1.0, 3e-8, 5e4])
 def test_conv3d_bwd_data(dev, ops, shape, dy_mag):
-    """bwd-data = the forward conv on the flipped / transposed weight, with the gradient's own operand scale."""
+    """bwd-data = the forward conv kernels on the flipped / transposed weight (packed straight from the original OIDHW
+    layout), with the gradient's own operand scale."""
     n, ci, co, d, h, w, k = shape
     x = R.seeded_tensor((n, ci, d, h, w), 21).requires_grad_(True)
     dy = R.seeded_tensor((n, co, d, h, w), 22) * dy_mag
     wt = R.seeded_tensor((co, ci, k, k, k), 23, scale=0.05)
     F.conv3d(x, wt, None, padding=k // 2).backward(dy)
-    pc = ops.PackedConv(ops.conv_bwd_data_weight(wt.to(dev)), None)
+    pc = ops.PackedConv(wt.to(dev), None, transposed=True)
     _, scale = ops.grad_prep(dy.to(dev), want_bias=False)
     for prec in (0, 1):
         dx = ops.conv3d_bwd_data(dy.to(dev), pc, scale, precision=prec)
@@ -325,3 +326,41 @@ def test_hot_slice_backward(dev, M):
     for k in inp:
         assert rel_err(gpu_in[k].grad, cpu_in[k].grad) < 2e-3, k
     _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3)
+
+
+def test_graphed_train_step_matches_eager(dev, M):
+    """training.GraphedTrainStep (forward + backward + SGD replayed as one hipGraph, weights re-packed inside the
+    graph) walks the parameters exactly like the eager step."""
+    from megaportrait_hack_amd import training
+
+    def make():
+        g = M.G3d(96)
+        sd = R.seeded_state_dict(R.g3d_shapes(96), 81, prefix="G3d.")
+        g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+        return g.to(dev).train()
+
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 82).to(dev)
+    tgt = R.seeded_tensor((1, 96, 8, 16, 16), 83).to(dev)
+    loss_fn = lambda m, x: F.mse_loss(m(x), tgt)
+    eager, graphed = make(), make()
+    opt_e = torch.optim.SGD(eager.parameters(), lr=1e-2, momentum=0.9)
+    opt_g = torch.optim.SGD(graphed.parameters(), lr=1e-2, momentum=0.9)
+    step = training.GraphedTrainStep(graphed, loss_fn, opt_g, {"x": x}, warmup=2)   # 2 warm-up + 1 capture-free = 2 updates
+    for _ in range(2):
+        training.train_step(eager, loss_fn, opt_e, {"x": x})
+    losses = []
+    for _ in range(3):
+        le = training.train_step(eager, loss_fn, opt_e, {"x": x})
+        lg = step(x=x)
+        losses.append((le.item(), lg.item()))
+    for le, lg in losses:
+        assert abs(le - lg) <= 1e-5 * abs(le), losses
+    for (n, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert rel_err(pg, pe.detach().cpu()) < 1e-5, n
+    # the replays rewrote the weights behind autograd's version counters: eager paths must still see the new values
+    for _ in range(4):
+        lg = step(x=x)                 # replay first, eager kernels of the other model right behind it
+        le = training.train_step(eager, loss_fn, opt_e, {"x": x})
+        assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item())
+    with torch.no_grad():
+        assert rel_err(graphed(x), eager(x).cpu()) < 1e-5

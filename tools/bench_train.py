@@ -1,70 +1,103 @@
-"""G3d training step (forward + backward, SGD) through the HIP path vs the same nn graph in PyTorch-ROCm eager
-on the same GPU.  Dev tool — not the graded bench (bench.py).   usage: bench_train.py [B] [--torch] [--iters n]"""
-import argparse, os, sys
+"""Training step (forward + backward + SGD) through the HIP path vs the same graph in PyTorch-ROCm eager on the
+same GPU.  Dev tool — not the graded bench (bench.py).
+usage: bench_train.py [B] [--what g3d|slice] [--torch] [--only hip|torch] [--iters n]"""
+import argparse, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, torch.nn as nn, torch.nn.functional as F
 
 ap = argparse.ArgumentParser()
 ap.add_argument("B", nargs="?", type=int, default=4)
+ap.add_argument("--what", choices=["g3d", "slice"], default="g3d")
 ap.add_argument("--torch", action="store_true", help="also time the PyTorch-ROCm eager graph")
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--only", choices=["hip", "torch"], default=None)
+ap.add_argument("--graph", action="store_true", help="also time the HIP step replayed as one hipGraph (training.GraphedTrainStep)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
+from oracle import hotpath_ref as R
 
 
-class TorchResBlock3D(nn.Module):  # the reference's graph (model.py:500-528) as plain nn modules
-    def __init__(s, ci, co):
-        super().__init__()
-        s.conv1, s.gn1 = nn.Conv3d(ci, co, 3, padding=1), nn.GroupNorm(32, co)
-        s.conv2, s.gn2 = nn.Conv3d(co, co, 3, padding=1), nn.GroupNorm(32, co)
-        s.shortcut = nn.Conv3d(ci, co, 1) if ci != co else nn.Identity()
-
-    def forward(s, x):
-        i = s.shortcut(x)
-        o = F.relu(s.gn1(s.conv1(x)))
-        return F.relu(s.gn2(s.conv2(o)) + i)
-
-
-class TorchG3d(nn.Module):
-    def __init__(s):
-        super().__init__()
-        R, P = TorchResBlock3D, lambda: nn.AvgPool3d(2, 2)
-        U = lambda: nn.Upsample(scale_factor=2, mode="trilinear", align_corners=True)
-        s.downsampling = nn.Sequential(R(96, 96), P(), R(96, 192), P(), R(192, 384), P(), R(384, 768))
-        s.upsampling = nn.Sequential(R(768, 384), U(), R(384, 192), U(), R(192, 96), U())
-        s.final_conv = nn.Conv3d(96, 96, 3, padding=1)
-
-    def forward(s, x):
-        return s.final_conv(s.upsampling(s.downsampling(x)))
-
-
-def step_time(model, x, tgt, iters):
-    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = F.mse_loss(model(x), tgt)
-        loss.backward()
-        opt.step()
-        return loss
+def timed(step, iters):
     for _ in range(2): step()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters): loss = step()
     e1.record(); torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / iters, loss.item()
+    return e0.elapsed_time(e1) / iters, float(loss)
 
 
-x = torch.randn(a.B, 96, 16, 64, 64, device=dev)
-tgt = torch.randn(a.B, 96, 16, 64, 64, device=dev)
-tg = TorchG3d().to(dev)
-if a.only != "torch":
-    from megaportrait_hack_amd import model as M
-    g = M.G3d(96).to(dev).train()
-    g.load_state_dict(tg.state_dict())
-    ms, loss = step_time(g, x, tgt, a.iters)
-    print(f"HIP   G3d train step B={a.B}: {ms:8.2f} ms  ({a.B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
-if a.torch or a.only == "torch":
-    ms, loss = step_time(tg, x, tgt, a.iters)
-    print(f"torch G3d train step B={a.B}: {ms:8.2f} ms  ({a.B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
+def module_step(model, fwd, tgt):
+    opt = torch.optim.SGD(model.parameters(), lr=1e-4)
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = F.mse_loss(fwd(), tgt)
+        loss.backward()
+        opt.step()
+        return loss
+    return step
+
+
+def functional_step(sd, fwd, tgt):
+    """The oracle's functional graph on GPU tensors: parameters are leaf tensors, manual SGD."""
+    params = [v for v in sd.values()]
+    def step():
+        for p in params: p.grad = None
+        loss = F.mse_loss(fwd(sd), tgt)
+        loss.backward()
+        with torch.no_grad():
+            for p in params:
+                if p.grad is not None: p.add_(p.grad, alpha=-1e-4)
+        return loss
+    return step
+
+
+class _GpuConsts:  # the restatement builds a few tiny constants on the default (CPU) device: route them to the GPU
+    def __enter__(self):
+        self.o = (torch.eye, torch.linspace, torch.tensor)
+        torch.eye = lambda *x, **k: self.o[0](*x, **{**k, "device": k.get("device", dev)})
+        torch.linspace = lambda *x, **k: self.o[1](*x, **{**k, "device": k.get("device", dev)})
+        torch.tensor = lambda *x, **k: self.o[2](*x, **{**k, "device": k.get("device", dev)})
+    def __exit__(self, *exc):
+        torch.eye, torch.linspace, torch.tensor = self.o
+
+
+B = a.B
+if a.what == "g3d":
+    sd = R.seeded_state_dict(R.g3d_shapes(96), 61, prefix="G3d.")
+    x = torch.randn(B, 96, 16, 64, 64, device=dev)
+    tgt = torch.randn(B, 96, 16, 64, 64, device=dev)
+    if a.only != "torch":
+        from megaportrait_hack_amd import model as M
+        g = M.G3d(96)
+        g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+        g = g.to(dev).train()
+        ms, loss = timed(module_step(g, lambda: g(x), tgt), a.iters)
+        print(f"HIP   G3d train step B={B}: {ms:8.2f} ms  ({B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
+    if a.torch or a.only == "torch":
+        gsd = {k: v.to(dev).requires_grad_(True) for k, v in sd.items()}
+        ms, loss = timed(functional_step(gsd, lambda s: R.g3d(x, s), tgt), a.iters)
+        print(f"torch G3d train step B={B}: {ms:8.2f} ms  ({B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
+else:
+    sd = R.seeded_gbase_hot_state_dict(7)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(B, 3).items()}
+    inp["vs"].requires_grad_(True)   # vs comes from Eapp in the reference's training step: its gradient is part of the work
+    tgt = torch.randn(B, 96, 64, 64, device=dev)
+    if a.only != "torch":
+        from megaportrait_hack_amd import model as M
+        hot = M.GbaseHotSlice()
+        M.load_hot_state_dict(hot, sd)
+        hot = hot.to(dev).train()
+        ms, loss = timed(module_step(hot, lambda: hot(**inp), tgt), a.iters)
+        print(f"HIP   hot-slice train step B={B}: {ms:8.2f} ms  ({B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
+        if a.graph:
+            from megaportrait_hack_amd import training
+            opt = torch.optim.SGD(hot.parameters(), lr=1e-4)
+            gs = training.GraphedTrainStep(hot, lambda m, **kw: F.mse_loss(m(**kw), tgt), opt, inp)
+            ms, loss = timed(lambda: gs(**inp), a.iters)
+            print(f"HIP   hot-slice train step B={B} (hipGraph replay): {ms:8.2f} ms  ({B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
+    if a.torch or a.only == "torch":
+        gsd = {k: v.to(dev).requires_grad_(True) for k, v in sd.items()}
+        with _GpuConsts():
+            ms, loss = timed(functional_step(gsd, lambda s: R.hot_slice(sd=s, **inp), tgt), a.iters)
+        print(f"torch hot-slice train step B={B}: {ms:8.2f} ms  ({B / ms * 1e3:.1f} frames/s)  loss {loss:.6f}")
