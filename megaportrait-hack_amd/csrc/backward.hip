@@ -426,12 +426,59 @@ conv_bwd_weight_direct_kernel(const float *__restrict__ x, const float *__restri
     dw[t] = acc;
 }
 
+// small volumes (<= 4096 voxels over the batch: FlowField's middle blocks, 4x4 and 8x8 maps): one wavefront per
+// (co, ci) pair, lanes over the voxels, all k^3 taps accumulated per lane and wave-reduced.  Exact fp32.
+template <int KS>
+__global__ void __launch_bounds__(256)
+conv_bwd_weight_wave_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dw, int N, int Ci,
+                            int Co, int D, int H, int W) {
+    constexpr int TAPS = KS * KS * KS;
+    const int pair = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pair >= Co * Ci) return;
+    const int ci = pair % Ci, co = pair / Ci, lane = threadIdx.x & 63;
+    const int HW = H * W, DHW = D * HW;
+    float acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) acc[t] = 0.0f;
+    for (int v = lane; v < N * DHW; v += 64) {
+        const int n = v / DHW, r = v - n * DHW;
+        const int d = r / HW, h = (r / W) % H, w = r % W;
+        const float g = dy[((size_t)n * Co + co) * DHW + r];
+        const float *xc = x + ((size_t)n * Ci + ci) * DHW + r;
+        if (KS == 1) {
+            acc[0] += g * xc[0];
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                if ((unsigned)(d + a - 1) >= (unsigned)D) continue;
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    if ((unsigned)(h + b - 1) >= (unsigned)H) continue;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        if ((unsigned)(w + c - 1) < (unsigned)W) acc[(a * 3 + b) * 3 + c] += g * xc[(a - 1) * HW + (b - 1) * W + (c - 1)];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t) {
+        float a = acc[t];
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) a += __shfl_xor(a, sft, 64);
+        if (lane == 0) dw[(size_t)pair * TAPS + t] = a;
+    }
+}
+
 }  // namespace mphip
 
 using namespace mphip;
 
 // tiny volumes: one thread per dW element beats tiling (see conv_bwd_weight_direct_kernel)
-static bool bwd_weight_direct(int N, int D, int H, int W) { return (long)N * D * H * W <= 2048; }
+static bool bwd_weight_direct(int N, int D, int H, int W) {
+    const long vox = (long)N * D * H * W;
+    return vox <= 64 || (W % 8 != 0 && vox <= 4096);  // maps narrower than the MFMA kernels' 8-wide voxel rows
+}
 
 static int bw_splits(long ntiles, int blocks_xy) {
     int s = 1;
@@ -472,10 +519,17 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, const fl
     hipStream_t s = (hipStream_t)stream;
     if (bwd_weight_direct(N, D, H, W)) {
         const size_t nw = (size_t)Co * Ci * k * k * k;
-        if (k == 3)
+        const bool per_thread = (long)N * D * H * W <= 64;  // a handful of voxels: one thread per dW element
+        if (per_thread && k == 3)
             hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<3>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
-        else
+        else if (per_thread)
             hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<1>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
+        else if (k == 3)
+            hipLaunchKernelGGL(conv_bwd_weight_wave_kernel<3>, dim3(cdiv((size_t)Co * Ci, 4)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D,
+                               H, W);
+        else
+            hipLaunchKernelGGL(conv_bwd_weight_wave_kernel<1>, dim3(cdiv((size_t)Co * Ci, 4)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D,
+                               H, W);
         return check_launch("conv3d_bwd_weight(direct)");
     }
     if (precision == 1) return bwd_weight_f16x3_launch(x, dy, dy_scale, dw, N, Ci, Co, D, H, W, workspace, s);

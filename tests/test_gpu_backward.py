@@ -356,7 +356,7 @@ def test_graphed_train_step_matches_eager(dev, M):
     for le, lg in losses:
         assert abs(le - lg) <= 1e-5 * abs(le), losses
     for (n, pe), (_, pg) in zip(eager.named_parameters(), graphed.named_parameters()):
-        assert rel_err(pg, pe.detach().cpu()) < 1e-5, n
+        assert rel_err(pg, pe.detach().cpu()) < 1e-4, n   # (a stale-pack bug shows up at the 1e-2 level)
     # the replays rewrote the weights behind autograd's version counters: eager paths must still see the new values
     for _ in range(4):
         lg = step(x=x)                 # replay first, eager kernels of the other model right behind it
