@@ -12,6 +12,11 @@ import torch
 
 from . import ops
 
+# train.py:188 runs the generator under torch.cuda.amp.autocast(): the HIP path computes in fp32, so
+# every Function casts floating-point inputs back to fp32 and runs with autocast disabled
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 def _bwd_pack(conv) -> ops.PackedConv:
     """PackedConv of the flipped/transposed weight (bwd-data as a forward conv), cached on the module like the
@@ -29,6 +34,7 @@ class Conv3dFn(torch.autograd.Function):
     """y = conv3d(x, W, b, padding=k//2).  `conv` is the nn.Conv3d holding W, b (for the pack caches)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, weight, bias, conv, fwd_pack):
         ctx.conv = conv
         ctx.has_bias = bias is not None
@@ -36,6 +42,7 @@ class Conv3dFn(torch.autograd.Function):
         return ops.conv3d(x, fwd_pack)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         conv = ctx.conv
@@ -55,6 +62,7 @@ class GroupNormFn(torch.autograd.Function):
     w2/b2 = AdaptiveGroupNorm's second affine ([1,C,1,1,1], model.py:304-316) or None."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, gamma, beta, w2, b2, residual, groups, eps, act):
         x = x.contiguous()
         stats = ops.groupnorm_stats(x, groups, eps)
@@ -68,6 +76,7 @@ class GroupNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @_bwd
     def backward(ctx, dy):
         want_res = ctx.has_res and ctx.needs_input_grad[5]
         if ctx.has_w2:
@@ -82,20 +91,24 @@ class GroupNormFn(torch.autograd.Function):
 
 class AvgPool2Fn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, x):
         return ops.avgpool2(x.contiguous())
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         return ops.avgpool2_bwd(dout.contiguous())
 
 
 class UpsampleTrilinear2Fn(torch.autograd.Function):
     @staticmethod
+    @_fwd
     def forward(ctx, x):
         return ops.upsample_trilinear2(x.contiguous())
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         return ops.upsample_trilinear2_bwd(dout.contiguous())
 
@@ -123,12 +136,14 @@ class WarpVolumeFn(torch.autograd.Function):
     """apply_warping_field (model.py:1028-1065); dsum=True fuses the torch.sum(dim=2) of model.py:1171."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, v, field, dsum):
         ctx.dsum = dsum
         ctx.save_for_backward(v, field)
         return ops.warp_volume_dsum(v, field) if dsum else ops.warp_volume(v, field)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         v, field = ctx.saved_tensors
         dv, dfield = ops.warp_volume_bwd(v, field, dout.contiguous(), ctx.dsum, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
@@ -139,11 +154,13 @@ class WarpFieldComposeFn(torch.autograd.Function):
     """rt + em64 of the warp generators: F.affine_grid(theta) + trilinear(em -> G^3) (model.py:804-806, 971-973)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, theta, em, grid_size):
         ctx.em_shape = tuple(em.shape)
         return ops.warp_field_compose(theta, em, grid_size)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dw):
         dtheta, dem = ops.warp_field_compose_bwd(dw.contiguous(), ctx.em_shape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         return dtheta, dem, None
@@ -153,12 +170,14 @@ class RtThetaFn(torch.autograd.Function):
     """theta = rows 0..2 of [R(rotation)|t; 0 0 0 1] (inverted for S2C): model.py:790-801, 811-856."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, rotation, translation, invert):
         ctx.invert = invert
         ctx.save_for_backward(rotation, translation)
         return ops.rt_theta(rotation, translation, invert)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dtheta):
         rotation, translation = ctx.saved_tensors
         drot, dtr = ops.rt_theta_bwd(rotation, translation, dtheta.contiguous(), ctx.invert)
@@ -169,11 +188,13 @@ class UpsampleNearestFn(torch.autograd.Function):
     """nn.Upsample(scale_factor=(sD,sH,sW)), default nearest (model.py:427-433)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, x, scale):
         ctx.scale = tuple(int(v) for v in scale)
         return ops.upsample_nearest(x.contiguous(), ctx.scale)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dout):
         return ops.upsample_nearest_bwd(dout.contiguous(), ctx.scale), None
 
@@ -182,11 +203,13 @@ class AddMatmulFn(torch.autograd.Function):
     """s = (z + e) @ Gamma (model.py:945-957: right-multiply, no transpose)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, z, e, gamma):
         ctx.save_for_backward(z, e, gamma)
         return ops.add_matmul(z, e, gamma)
 
     @staticmethod
+    @_bwd
     def backward(ctx, ds):
         z, e, gamma = ctx.saved_tensors
         ds = ds.contiguous()
@@ -199,11 +222,13 @@ class Conv1x1OnVectorFn(torch.autograd.Function):
     """The 1x1 Conv2d applied to a 1x1 map (model.py:446): x = s @ W^T + b with W [N,K,1,1]."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, s, weight, bias, w_kn):
         ctx.save_for_backward(s, weight)
         return ops.add_matmul(s, None, w_kn, bias)
 
     @staticmethod
+    @_bwd
     def backward(ctx, dx):
         s, weight = ctx.saved_tensors
         dx = dx.contiguous()

@@ -14,3 +14,10 @@ void set_error(const char *fmt, ...) {
 
 extern "C" int mphip_version(void) { return 1; }
 extern "C" const char *mphip_last_error(void) { return mphip::g_err; }
+
+namespace mphip {
+__global__ void __launch_bounds__(256) zero_fill_kernel(float4 *__restrict__ p, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256)
+        p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+}  // namespace mphip

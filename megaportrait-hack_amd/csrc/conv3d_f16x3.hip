@@ -402,11 +402,7 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
 
 int f16x3_pack(const float *w, void *out, int Co, int Ci, int transposed, hipStream_t s) {
     unsigned *hdr = (unsigned *)out;
-    hipError_t e = hipMemsetAsync(out, 0, 16, s);
-    if (e != hipSuccess) {
-        set_error("pack_conv_weight(f16x3): memset: %s", hipGetErrorString(e));
-        return MPHIP_ELAUNCH;
-    }
+    zero_fill(out, 16, s);  // header: the absmax kernel accumulates with atomicMax
     const size_t n = (size_t)Co * Ci * 27;
     hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(256, (n + 8191) / 8192)), dim3(256), 0, s, w, n, hdr);
     hipLaunchKernelGGL(f16x3_pack_kernel, dim3(2048), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), (const unsigned *)hdr,

@@ -41,6 +41,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 
+// zero fill as a KERNEL (float4 stores; n_bytes % 16 == 0, 16-B aligned).  Used instead of hipMemsetAsync: the memset
+// nodes of a captured hipGraph were not reliably ordered with the kernels around them on ROCm 7.2 (a replayed
+// training step went wrong in ~40 % of runs until the two memsets on this path became kernels).
+__global__ void __launch_bounds__(256) zero_fill_kernel(float4 *__restrict__ p, size_t n16);
+inline void zero_fill(void *p, size_t n_bytes, hipStream_t s) {
+    const size_t n16 = n_bytes / 16;
+    const unsigned blocks = (unsigned)((n16 + 255) / 256 < 65536 * 16 ? (n16 + 255) / 256 : 65536 * 16);
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, (float4 *)p, n16);
+}
+
 // value of a split-K tensor element: slab[0][o] + slab[1][o] + ... (z ascending, the reduce kernel's order).
 // The loads of 8 slabs are issued together (independent addresses) and only the adds are sequential, so a
 // 32-way split costs 4 memory round trips instead of 32.

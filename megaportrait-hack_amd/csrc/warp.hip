@@ -922,9 +922,10 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
     float *coords = (float *)workspace, *dcoords = coords + nvox * 3;
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, nullptr, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
-    if (dv && hipMemsetAsync(dv, 0, (size_t)B * C * D * H * W * sizeof(float), s) != hipSuccess) {
-        set_error("warp_volume_bwd: memset failed");
-        return MPHIP_ELAUNCH;
+    if (dv) {
+        const size_t bytes = (size_t)B * C * D * H * W * sizeof(float);
+        MPHIP_REQUIRE(bytes % 16 == 0 && ((uintptr_t)dv & 15) == 0, "warp_volume_bwd: dv must be 16-byte aligned / sized");
+        zero_fill(dv, bytes, s);  // the scatter pass accumulates with atomics
     }
     const int groups = cdiv(C, WARP_BWD_CPB);
     dim3 grid((unsigned)((size_t)B * cdiv(D, 4) * cdiv(H, 16) * cdiv(W, 16)), groups);

@@ -24,6 +24,14 @@ from . import ops
 COMPRESS_DIM = 512  # model.py:48
 
 
+def _f32(*tensors):
+    """Inputs arrive in fp16/bf16 when an upstream PyTorch module ran under autocast (train.py:188): the HIP path
+    computes in fp32, like the reference's fp32 parameters do outside autocast."""
+    out = tuple(t.float() if isinstance(t, torch.Tensor) and t.is_floating_point() and t.dtype != torch.float32 else t
+                for t in tensors)
+    return out[0] if len(out) == 1 else out
+
+
 class _PackCache:
     """Packed conv weights, rebuilt when the parameter changes (in-place update, load_state_dict or .to()).
     The pack lives ON the conv module (not in a global table keyed by id()), so it dies with the module and
@@ -46,6 +54,7 @@ _packs = _PackCache()
 
 def compute_rt_warp(rotation, translation, invert=False, grid_size=64):
     """model.py:777-809 — rigid warp grid [B,3,G,G,G] (x,y,z channels)."""
+    rotation, translation = _f32(rotation, translation)
     theta = ops.rt_theta(rotation, translation, invert)
     zero_em = torch.zeros((rotation.shape[0], 3, 1, 1, 1), dtype=torch.float32, device=rotation.device)
     _, rt, _ = ops.warp_field_compose(theta, zero_em, grid_size, parts=True)
@@ -54,6 +63,7 @@ def compute_rt_warp(rotation, translation, invert=False, grid_size=64):
 
 def apply_warping_field(v, warp_field):
     """model.py:1028-1065 — same signature and result; one fused HIP kernel (K2); differentiable (autograd.WarpVolumeFn)."""
+    v, warp_field = _f32(v, warp_field)
     if torch.is_grad_enabled() and (v.requires_grad or warp_field.requires_grad):
         return ag.WarpVolumeFn.apply(v, warp_field, False)
     return ops.warp_volume(v, warp_field)
@@ -71,6 +81,7 @@ class AdaptiveGroupNorm(nn.Module):
         self.group_norm = nn.GroupNorm(num_groups, num_channels)
 
     def forward(self, x):
+        x = _f32(x)
         if ag.needs_grad(self, x):
             return ag.adaptive_groupnorm(x, self)
         st = ops.groupnorm_stats(x, self.num_groups, self.group_norm.eps)
@@ -98,6 +109,7 @@ class ResBlock3D_Adaptive(nn.Module):
 
     def forward(self, x, _up=(1, 1, 1)):
         """`_up`: nearest-upsample factors fused into the block's last elementwise pass (FlowField's nn.Upsample)."""
+        x = _f32(x)
         if ag.needs_grad(self, x):  # differentiable path: the same ops, unfused, as autograd Functions (autograd.py)
             y = ag.conv3d(x, self.conv1, _packs.get(self.conv1))
             y = ag.adaptive_groupnorm(y, self.norm1, relu=True)
@@ -163,6 +175,7 @@ class FlowField(nn.Module):
         return hit[1]
 
     def forward(self, zs, adaptive_gamma=0, adaptive_beta=0):  # last two ignored, as in the reference
+        zs = _f32(zs)
         train = ag.needs_grad(self, zs)
         b = zs.shape[0]
         s = zs.reshape(b, 512)
@@ -204,6 +217,7 @@ class _WarpGenerator(nn.Module):
         assert R.shape == (z.shape[0], 3), f"Expected R shape (batch_size, 3), got {R.shape}"
         assert t.shape == (z.shape[0], 3), f"Expected t shape (batch_size, 3), got {t.shape}"
         assert z.shape == e.shape, f"Expected z and e to have the same shape, got {z.shape} and {e.shape}"
+        R, t, z, e = _f32(R, t, z, e)
         if ag.needs_grad(self, R, t, z, e):
             s = ag.AddMatmulFn.apply(z, e, self.adaptive_matrix_gamma)
             em = self.flowfield(s.unsqueeze(-1).unsqueeze(-1), 0, 0)
@@ -250,6 +264,7 @@ class ResBlock3D(nn.Module):
         return ag.groupnorm(y, self.gn2, residual=identity, relu=True)
 
     def forward(self, x, _pool_after: bool = False):
+        x = _f32(x)
         if ag.needs_grad(self, x):
             y = self._forward_train(x)
             return ag.AvgPool2Fn.apply(y) if _pool_after else y
@@ -287,6 +302,7 @@ class G3d(nn.Module):
         self.final_conv = nn.Conv3d(96, 96, kernel_size=3, padding=1)
 
     def forward(self, x):
+        x = _f32(x)
         train = ag.needs_grad(self, x)
         up = ag.UpsampleTrilinear2Fn.apply if train else ops.upsample_trilinear2
         d = self.downsampling
@@ -321,6 +337,7 @@ class Eapp3DTail(nn.Module):
 
     def forward(self, out):
         """out: Eapp's conv_1 output [B,1536,H,W] (model.py:268) or the reshaped volume [B,96,16,H,W]."""
+        out = _f32(out)
         vs = out.view(out.size(0), 96, 16, *out.shape[2:]) if out.dim() == 4 else out  # model.py:271
         for name in self._ORDER:
             vs = getattr(self, name)(vs)
@@ -352,6 +369,7 @@ class GbaseHotSlice(nn.Module):
         return st
 
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
+        vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
         main = torch.cuda.current_stream(vs.device)
         train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
         # training: one stream (autograd replays each op's backward on its forward stream; the overlap is an inference trick)
@@ -411,9 +429,7 @@ class GraphedHotSlice:
         for k, v in inputs.items():
             if v.data_ptr() != self.static_in[k].data_ptr():
                 self.static_in[k].copy_(v)
-        torch.cuda.current_stream().synchronize()  # replay bracketed by syncs: see training.GraphedTrainStep
         self.graph.replay()
-        torch.cuda.synchronize()
         return self.static_out
 
 

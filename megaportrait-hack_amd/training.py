@@ -82,7 +82,9 @@ class GraphedTrainStep:
 
     Inputs are copied into static buffers; `__call__` replays the graph and returns the (static) loss tensor.
     The packed-weight caches are bypassed while capturing (ops.repack_always) so the graph contains the per-step
-    re-packing of the updated weights.  Single-process only: a distributed step keeps the eager `train_step`
+    re-packing of the updated weights.  Everything on the path zero-fills with kernels, not hipMemsetAsync: memset
+    nodes of a captured graph were not reliably ordered with the kernels around them on ROCm 7.2 (a replayed step
+    went wrong in ~40 % of runs — stale f16x3 pack headers — until they were replaced; csrc/mphip_common.h).  Single-process only: a distributed step keeps the eager `train_step`
     (collectives stay outside the graph)."""
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
@@ -117,13 +119,6 @@ class GraphedTrainStep:
             for k, v in inputs.items():
                 if v.data_ptr() != self.static_in[k].data_ptr():
                     self.static_in[k].copy_(v)
-        # The replay is bracketed by synchronisation: on ROCm 7.2 a graph launch did not behave as stream-ordered with
-        # the work around it — back-to-back replays raced (NaN losses), and a loss read through the launch stream right
-        # after a replay returned an older value — while a replay that starts on an idle device and is waited for is
-        # exact (tests/test_gpu_backward.py::test_graphed_train_step_matches_eager).  The step stays one launch; only
-        # host/GPU overlap across steps is given up.
-        torch.cuda.current_stream().synchronize()
         self.graph.replay()
-        torch.cuda.synchronize()
         ops.invalidate_packs()  # the replay rewrote the parameters without touching their version counters
         return self.static_loss

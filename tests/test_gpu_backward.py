@@ -364,3 +364,27 @@ def test_graphed_train_step_matches_eager(dev, M):
         assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item())
     with torch.no_grad():
         assert rel_err(graphed(x), eager(x).cpu()) < 1e-5
+
+
+def test_autocast_inputs_are_computed_in_fp32(dev, M):
+    """train.py:188 calls the generator under autocast: half-precision inputs / an enabled autocast region must not
+    change what the HIP path computes (fp32), forward or backward."""
+    blk = M.ResBlock3D(96, 96)
+    sd = R.seeded_state_dict({k: tuple(v.shape) for k, v in blk.state_dict().items()}, 51)
+    blk.load_state_dict(sd)
+    blk = blk.to(dev).train()
+    x32 = R.seeded_tensor((1, 96, 4, 8, 8), 52).to(dev).half().float()   # exactly representable in fp16
+    ref_in = x32.clone().requires_grad_(True)
+    ref = blk(ref_in)
+    ref.sum().backward()
+    g_ref = blk.conv1.weight.grad.clone()
+    blk.zero_grad(set_to_none=True)
+    x16 = x32.half().requires_grad_(True)
+    with torch.autocast(device_type="cuda", dtype=torch.float16):
+        out = blk(x16)
+    assert out.dtype == torch.float32 and torch.equal(out, ref)
+    out.sum().backward()
+    assert torch.equal(blk.conv1.weight.grad, g_ref)
+    assert x16.grad is not None and x16.grad.dtype == torch.float16
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16):
+        assert torch.equal(blk(x16), blk(x32))
