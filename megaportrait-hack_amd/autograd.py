@@ -53,7 +53,7 @@ class Conv3dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv3d_bwd_weight(x, dy, k, scale)
+            dw = ops.conv3d_bwd_weight(x, dy, k, scale).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
         return dx, dw, db, None, None
 
 

@@ -195,6 +195,17 @@ def g3d(x, sd: SD, prefix: str = "G3d.") -> torch.Tensor:
     return F.conv3d(x, sd[prefix + "final_conv.weight"], sd[prefix + "final_conv.bias"], padding=1)
 
 
+# --------------------------------------------------------------------------- f3 (next row)
+def g2d_head(p: torch.Tensor, sd: SD, prefix: str = "G2d.") -> torch.Tensor:
+    """model.py:718-719, 756-757: `reshape` Conv2d(96,1536,1) then `conv1x1` Conv2d(1536,512,1), no nonlinearity between."""
+    x = F.conv2d(p, sd[prefix + "reshape.weight"], sd[prefix + "reshape.bias"])
+    return F.conv2d(x, sd[prefix + "conv1x1.weight"], sd[prefix + "conv1x1.bias"])
+
+
+def g2d_head_shapes() -> Dict[str, tuple]:
+    return {"reshape.weight": (1536, 96, 1, 1), "reshape.bias": (1536,), "conv1x1.weight": (512, 1536, 1, 1), "conv1x1.bias": (512,)}
+
+
 # --------------------------------------------------------------------------- f1 (next row)
 _EAPP_TAIL_ORDER = ("resblock3D_96", "resblock3D_96_2", "resblock3D_96_1", "resblock3D_96_1_2", "resblock3D_96_2",
                     "resblock3D_96_2_2")   # model.py:276-290 — `resblock3D_96_2` is assigned twice (218,225) and applied twice

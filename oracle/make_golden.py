@@ -54,7 +54,29 @@ def capture_tables():
     return path
 
 
+def make_g2d_head():
+    """(10) next-row f3: the entry of G2d (model.py:718-719, 756-757) — the reference's own `reshape` and `conv1x1`
+    Conv2d modules applied to a projected feature map [2,96,16,16]."""
+    m = load_reference_model()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    g2d = m.G2d(96)
+    sd = R.seeded_state_dict(R.g2d_head_shapes(), WEIGHT_SEED + 20, "G2d.")
+    g2d.reshape.load_state_dict({"weight": sd["G2d.reshape.weight"], "bias": sd["G2d.reshape.bias"]})
+    g2d.conv1x1.load_state_dict({"weight": sd["G2d.conv1x1.weight"], "bias": sd["G2d.conv1x1.bias"]})
+    x = R.seeded_tensor((2, 96, 16, 16), 120, scale=2.0)
+    with torch.no_grad():
+        out = g2d.conv1x1(g2d.reshape(x))
+        assert torch.equal(out, R.g2d_head(x, sd))
+    np.savez(os.path.join(OUT, "g2d_head.npz"), out=out.numpy())
+    print("g2d_head.npz", os.path.getsize(os.path.join(OUT, "g2d_head.npz")))
+
+
 def main():
+    import sys
+
+    if "--only-g2d-head" in sys.argv:
+        return make_g2d_head()
     capture_tables()
     m = load_reference_model()
     os.makedirs(OUT, exist_ok=True)
@@ -158,6 +180,7 @@ def main():
     }
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
+    make_g2d_head()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

@@ -392,6 +392,36 @@ def test_eapp_tail_golden_and_full_size(M, dev):
         assert err < 1e-3
 
 
+def test_g2d_head_fused_golden(M, dev):
+    """Row f3: G2d's two stacked 1x1 convs (model.py:756-757) as one 96->512 product vs the reference's own modules
+    (golden), vs the oracle at the full 64x64 map, and vs the unfused differentiable path."""
+    sd = R.seeded_state_dict(R.g2d_head_shapes(), WEIGHT_SEED + 20, "G2d.")
+    head = M.G2dHead()
+    head.load_state_dict({k[len("G2d."):]: v for k, v in sd.items()})
+    head = head.to(dev).eval()
+    x = R.seeded_tensor((2, 96, 16, 16), 120, scale=2.0)
+    with torch.no_grad():
+        got = head(x.to(dev))
+    assert got.shape == (2, 512, 16, 16)
+    assert maxabs(got, gold("g2d_head")["out"]) < 1e-4       # reassociated (W2 W1) x: not bitwise, far inside 1e-3
+    xf = R.seeded_tensor((2, 96, 64, 64), 121, scale=2.0)
+    with torch.no_grad():
+        fused = head(xf.to(dev))
+    assert maxabs(fused, R.g2d_head(xf, sd)) < 1e-4
+    xg = xf.to(dev).requires_grad_(True)
+    unfused = head(xg)                                        # autograd on: the two convs run separately
+    assert maxabs(unfused, fused.cpu()) < 1e-4
+    cpu = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xc = xf.clone().requires_grad_(True)
+    dy = R.seeded_tensor((2, 512, 64, 64), 122)
+    R.g2d_head(xc, cpu).backward(dy)
+    unfused.backward(dy.to(dev))
+    rel = lambda a, b: (a.detach().cpu().double() - b.double()).abs().max().item() / b.abs().max().item()
+    assert rel(xg.grad, xc.grad) < 1e-4
+    for n, p in head.named_parameters():
+        assert rel(p.grad, cpu["G2d." + n].grad) < 1e-4, n
+
+
 def test_hot_slice_small_golden(dev, hot):
     inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, INPUT_SEED + 1, D=16, H=16, W=16).items()}
     with torch.no_grad():
