@@ -120,6 +120,10 @@ int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const f
 int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
                           const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
                           int precision, void *workspace, size_t workspace_bytes, void *stream);
+int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+                             const float *bias, float *y, float *gn_stats, int N, int Ci, int Co, int D, int H, int W,
+                             int k, int precision, int gn_groups, float gn_eps, void *workspace,
+                             size_t workspace_bytes, void *stream);
 
 /* Split-K aware chain for small volumes (G3d's 4x16x16 / 2x8x8 levels, all of FlowField): the conv leaves
  * its result as `splits` partial slabs out[z][N,Co,D,H,W] (bias NOT added) and the GroupNorm statistics /

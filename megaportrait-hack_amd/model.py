@@ -118,7 +118,8 @@ class ResBlock3D_Adaptive(nn.Module):
             y = ag.adaptive_groupnorm(y, self.norm2, residual=res, relu=True)
             return y if tuple(_up) == (1, 1, 1) else ag.UpsampleNearestFn.apply(y, tuple(_up))
         n1, n2 = self.norm1, self.norm2
-        y = ops.conv3d_split(x, _packs.get(self.conv1))  # split-K slabs are summed by the GN kernels below
+        # split-K slabs are summed by the GN kernels below; a direct launch carries the norm's statistics along
+        y = ops.conv3d_split(x, _packs.get(self.conv1), gn_groups=n1.num_groups, gn_eps=n1.group_norm.eps)
         tiny = ops.groupnorm_fused_ok(y, n1.num_groups)  # FlowField: statistics + apply in one launch
         if tiny:
             a = ops.groupnorm_small(y, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, n1.group_norm.eps,
@@ -128,12 +129,13 @@ class ResBlock3D_Adaptive(nn.Module):
             st = ops.groupnorm_stats(y, n1.num_groups, n1.group_norm.eps)
             pc2 = _packs.get(self.conv2)
             if y.splits == 1 and ops.gn_in_conv_ok(y.shape, pc2):  # Eapp's 3D tail: AGN1 + ReLU inside conv2's staging
-                y = ops.ConvOut(ops.conv3d_gn_in(y.data, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, pc2,
-                                                 w2=n1.weight, b2=n1.bias), 1, None, y.shape)
+                y2, st2 = ops.conv3d_gn_in(y.data, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, pc2,
+                                           w2=n1.weight, b2=n1.bias, out_gn_groups=n2.num_groups, out_gn_eps=n2.group_norm.eps)
+                y = ops.ConvOut(y2, 1, None, y.shape, st2, n2.num_groups)
             else:
                 a = ops.groupnorm_apply(y, st, n1.group_norm.weight, n1.group_norm.bias, n1.num_groups, w2=n1.weight,
                                         b2=n1.bias, relu=True)
-                y = ops.conv3d_split(a, pc2)
+                y = ops.conv3d_split(a, pc2, gn_groups=n2.num_groups, gn_eps=n2.group_norm.eps)
         res = x if isinstance(self.residual_conv, nn.Identity) else ops.conv3d_split(x, _packs.get(self.residual_conv))
         if tiny:
             return ops.groupnorm_small(y, n2.group_norm.weight, n2.group_norm.bias, n2.num_groups, n2.group_norm.eps,
@@ -269,15 +271,17 @@ class ResBlock3D(nn.Module):
             y = self._forward_train(x)
             return ag.AvgPool2Fn.apply(y) if _pool_after else y
         identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d_split(x, _packs.get(self.shortcut))
-        y = ops.conv3d_split(x, _packs.get(self.conv1))
+        y = ops.conv3d_split(x, _packs.get(self.conv1), gn_groups=32, gn_eps=self.gn1.eps)  # + GN1's statistics
         st = ops.groupnorm_stats(y, 32, self.gn1.eps)
         pc2 = _packs.get(self.conv2)
         if y.splits == 1 and ops.gn_in_conv_ok(y.shape, pc2):
             # GN1 + ReLU folded into conv2's input staging: the normalised tensor never touches HBM
-            y = ops.ConvOut(ops.conv3d_gn_in(y.data, st, self.gn1.weight, self.gn1.bias, 32, pc2), 1, None, y.shape)
+            y2, st2 = ops.conv3d_gn_in(y.data, st, self.gn1.weight, self.gn1.bias, 32, pc2, out_gn_groups=32,
+                                       out_gn_eps=self.gn2.eps)
+            y = ops.ConvOut(y2, 1, None, y.shape, st2, 32)
         else:
             a = ops.groupnorm_apply(y, st, self.gn1.weight, self.gn1.bias, 32, relu=True)
-            y = ops.conv3d_split(a, pc2)
+            y = ops.conv3d_split(a, pc2, gn_groups=32, gn_eps=self.gn2.eps)
         st = ops.groupnorm_stats(y, 32, self.gn2.eps)
         return ops.groupnorm_apply(y, st, self.gn2.weight, self.gn2.bias, 32, residual=identity, relu=True,
                                    pool2=_pool_after)

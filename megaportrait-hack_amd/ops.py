@@ -303,8 +303,9 @@ def gn_in_conv_ok(x_shape, pc: "PackedConv") -> bool:
 
 
 def conv3d_gn_in(x: torch.Tensor, stats: torch.Tensor, gamma, beta, groups: int, pc: "PackedConv", w2=None, b2=None,
-                 relu: bool = True) -> torch.Tensor:
-    """conv(relu(GN(x))) with the normalisation applied inside the conv's input staging (mphip_conv3d_gnin_fwd)."""
+                 relu: bool = True, out_gn_groups: Optional[int] = None, out_gn_eps: float = 1e-5):
+    """conv(relu(GN(x))) with the normalisation applied inside the conv's input staging (mphip_conv3d_gnin_fwd).
+    With out_gn_groups, also returns the (mean, rstd) statistics of the result for the next GroupNorm: -> (y, stats)."""
     x = _req(x, "x")
     n, ci, d, h, w = x.shape
     lib = _lib.load()
@@ -315,30 +316,45 @@ def conv3d_gn_in(x: torch.Tensor, stats: torch.Tensor, gamma, beta, groups: int,
     _lib.check(lib.mphip_groupnorm_affine_table(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(table), n, ci,
                                                 groups, _stream()), "mphip_groupnorm_affine_table")
     wp = pc.packed(1)
-    ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, 1)
+    if out_gn_groups:
+        ws_bytes = lib.mphip_conv3d_gn_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, 1, out_gn_groups)
+        out_stats = torch.empty((n * out_gn_groups, 2), dtype=torch.float32, device=x.device)
+    else:
+        ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, 1)
+        out_stats = None
     ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
     y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
 
     def launch():
-        _lib.check(lib.mphip_conv3d_gnin_fwd(_ptr(x), _ptr(table), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h,
-                                             w, pc.k, 1, _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_gnin_fwd")
+        if out_gn_groups:
+            _lib.check(lib.mphip_conv3d_gnin_gn_fwd(_ptr(x), _ptr(table), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(out_stats),
+                                                    n, ci, pc.co, d, h, w, pc.k, 1, out_gn_groups, out_gn_eps, _ptr(ws), ws_bytes,
+                                                    _stream()), "mphip_conv3d_gnin_gn_fwd")
+        else:
+            _lib.check(lib.mphip_conv3d_gnin_fwd(_ptr(x), _ptr(table), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d,
+                                                 h, w, pc.k, 1, _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_gnin_fwd")
         return y
 
-    return _conv_hook(x, pc, launch) if _conv_hook is not None else launch()
+    y = _conv_hook(x, pc, launch) if _conv_hook is not None else launch()
+    return (y, out_stats) if out_gn_groups else y
 
 
 class ConvOut:
     """A conv result that may still be in split-K form: `data` is [splits, N, Co, D, H, W] partial slabs (bias
     not added, passed on in `bias`) when splits > 1, or the finished [N, Co, D, H, W] tensor when splits == 1."""
 
-    __slots__ = ("data", "splits", "bias", "shape")
+    __slots__ = ("data", "splits", "bias", "shape", "stats", "stats_groups")
 
-    def __init__(self, data, splits, bias, shape):
+    def __init__(self, data, splits, bias, shape, stats=None, stats_groups=0):
         self.data, self.splits, self.bias, self.shape = data, splits, bias, shape
+        self.stats, self.stats_groups = stats, stats_groups  # GroupNorm (mean, rstd) of the result, when the conv produced them
 
 
-def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None) -> ConvOut:
-    """Conv whose split-K reduction (small volumes) is left to the GroupNorm kernels that consume it."""
+def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_groups: Optional[int] = None,
+                 gn_eps: float = 1e-5) -> ConvOut:
+    """Conv whose split-K reduction (small volumes) is left to the GroupNorm kernels that consume it.  gn_groups: the
+    result feeds a GroupNorm — a direct (unsplit) launch then carries the statistics along (ConvOut.stats: computed in
+    the f16x3 kernel's epilogue instead of a separate pass over the tensor)."""
     x = _req(x, "x")
     if x.dim() != 5 or x.shape[1] != pc.ci:
         raise RuntimeError(f"conv3d: input {tuple(x.shape)} does not match Ci={pc.ci}")
@@ -352,7 +368,13 @@ def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = Non
     if splits > 1 and n * pc.co * d * h * w > _SPLIT_CHAIN_MAX_ELEMS:
         # mid-sized tensors (G3d's inner levels): the dedicated reduce + vectorised GN kernels are faster than the
         # one-thread-per-element split-aware kernels (measured: -13 % end to end when those were used everywhere)
+        if gn_groups:
+            y, st = conv3d(x, pc, precision=prec, gn_groups=gn_groups, gn_eps=gn_eps)
+            return ConvOut(y, 1, None, shape, st, gn_groups)
         return ConvOut(conv3d(x, pc, precision=prec), 1, None, shape)
+    if gn_groups and splits == 1 and prec == 1:
+        y, st = conv3d(x, pc, precision=prec, gn_groups=gn_groups, gn_eps=gn_eps)
+        return ConvOut(y, 1, None, shape, st, gn_groups)
     out = torch.empty((splits,) + shape if splits > 1 else shape, dtype=torch.float32, device=x.device)
     wp = pc.packed(prec)
 
@@ -383,6 +405,8 @@ def _finish(co: ConvOut) -> torch.Tensor:
 # ------------------------------------------------------------------ K6
 def groupnorm_stats(x, groups: int, eps: float = 1e-5) -> torch.Tensor:
     lib = _lib.load()
+    if isinstance(x, ConvOut) and x.stats is not None and x.stats_groups == groups:
+        return x.stats  # produced by the conv itself
     if isinstance(x, ConvOut):
         n, c, d, h, w = x.shape
         s = d * h * w

@@ -312,6 +312,31 @@ def test_groupnorm_folded_into_conv(ops, dev):
     assert maxabs(got, want) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 96, 8, 16, 32), (1, 96, 192, 4, 16, 16), (1, 192, 384, 4, 8, 16), (2, 384, 768, 4, 8, 8)])
+def test_conv_with_groupnorm_statistics(ops, dev, shape):
+    """conv + the following GroupNorm's (mean, rstd) in one call (mphip_conv3d_gn_fwd / mphip_conv3d_gnin_gn_fwd): same
+    numbers as the separate statistics pass over the stored output, for the plain conv and for the conv with the
+    previous norm folded into its input.  (MPHIP_GN_EPILOGUE=1 moves the statistics into the f16x3 epilogue: an
+    opt-in that measured slower; this test passes in both modes.)"""
+    n, ci, co, d, h, w = shape
+    x = R.seeded_tensor((n, ci, d, h, w), 821, scale=1.7) + 0.3
+    wt = R.seeded_tensor((co, ci, 3, 3, 3), 822, scale=(ci * 27) ** -0.5)
+    bias = R.seeded_tensor((co,), 823, scale=0.5)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    y, st = ops.conv3d(x.to(dev), pc, precision=1, gn_groups=32)
+    want = ops.groupnorm_stats(y, 32)
+    assert torch.equal(y, ops.conv3d(x.to(dev), pc, precision=1))
+    assert maxabs(st[:, 0], want[:, 0].cpu()) < 1e-6 and (st[:, 1] / want[:, 1] - 1).abs().max().item() < 1e-5
+    ref = F.conv3d(x, wt, bias, padding=1).view(n, 32, -1)
+    assert maxabs(st[:, 0], ref.mean(dim=2).reshape(-1)) < 2e-5
+    if ops.gn_in_conv_ok(tuple(x.shape), pc) and ci == co:
+        g, b = R.seeded_tensor((ci,), 824, scale=0.25, shift=1.0), R.seeded_tensor((ci,), 825, scale=0.25)
+        sx = ops.groupnorm_stats(x.to(dev), 32)
+        y2, st2 = ops.conv3d_gn_in(x.to(dev), sx, g.to(dev), b.to(dev), 32, pc, out_gn_groups=32)
+        want2 = ops.groupnorm_stats(y2, 32)
+        assert maxabs(st2[:, 0], want2[:, 0].cpu()) < 1e-6 and (st2[:, 1] / want2[:, 1] - 1).abs().max().item() < 1e-5
+
+
 def test_cross_reenactment_equals_pairwise(M, dev, hot):
     """BASELINE config 5 (1 source x N drivers, dp.cross_reenact): the source-side half is computed once,
     results must equal running the hot slice on every (source, driver) pair."""
