@@ -52,6 +52,10 @@ def parse():
                     help="also time the same graph through PyTorch-ROCm eager ops (ATen/MIOpen) on this GPU — what the "
                          "reference's own model.py would run on an MI355X — and add it as `torch_rocm_baseline` (off by "
                          "default: MIOpen's first-run kernel search can take minutes)")
+    ap.add_argument("--mode", default="infer", choices=["infer", "train"],
+                    help="infer (default) = the graded metric, BASELINE config 2; train = one training step of the hot slice "
+                         "(forward + backward + SGD, BASELINE config 3's per-GPU shard: --batch 4) with the RCCL gradient "
+                         "all-reduce when --gpus > 1 — a side measurement, separate JSON line")
     return ap.parse_args()
 
 
@@ -148,6 +152,66 @@ def cpu_baseline(frames):
                       f"(ATen CPU fp32, {threads} threads), {dt:.1f} s"}
 
 
+def train_mode(args, rank, world, dev, dist):
+    """Side measurement (not the graded metric): training step of the hot slice, frames sharded over ranks, gradients
+    averaged with bucketed RCCL all-reduces (training.train_step); --graph 1 replays the step as one hipGraph (1 GPU)."""
+    import torch.nn.functional as F
+
+    from megaportrait_hack_amd import _lib, model as M, training
+
+    _lib.load()
+    B = args.batch if args.batch != 8 else 4   # config 3: batch 32 over 8 GPUs
+    torch.manual_seed(20240501)                 # identical replicas on every rank
+    hot = M.GbaseHotSlice().to(dev).train()
+    g = torch.Generator(device="cpu").manual_seed(20240501 + rank)
+    inp = dict(vs=torch.randn(B, 96, 16, 64, 64, generator=g), es=torch.randn(B, 512, generator=g),
+               zs=torch.randn(B, 512, generator=g), zd=torch.randn(B, 512, generator=g),
+               Rs=(torch.rand(B, 3, generator=g) * 60 - 30), Rd=(torch.rand(B, 3, generator=g) * 60 - 30),
+               ts=torch.randn(B, 3, generator=g) * 0.1, td=torch.randn(B, 3, generator=g) * 0.1)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    inp["vs"].requires_grad_(True)              # vs comes from Eapp: its gradient is part of the step
+    tgt = torch.randn(B, 96, 64, 64, generator=g).to(dev)
+    loss_fn = lambda m, **kw: F.mse_loss(m(**kw), tgt)
+    opt = torch.optim.SGD(hot.parameters(), lr=1e-5)
+    if args.graph and world == 1:
+        graphed = training.GraphedTrainStep(hot, loss_fn, opt, inp)
+        step = lambda: graphed(**inp)
+    else:
+        step = lambda: training.train_step(hot, loss_fn, opt, inp)
+
+    def sync_all():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    sync_all()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).all()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        n_param = sum(p.numel() for p in hot.parameters())
+        print(json.dumps({
+            "metric": "hot-slice training step frames/sec (fwd + bwd + SGD; BASELINE config 3 shard)", "value": round(world * B * args.steps / dt, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16x3 forward/backward convs, fp32 everything else", "data": "synthetic",
+            "config": {"workload": "GbaseHotSlice train step (model.py:1151-1171 under autograd)", "frames_per_gpu": B,
+                       "global_batch": B * world, "parallelism": f"dp{world} (frame shards, gradient all-reduce: "
+                       f"{n_param * 4 / 1e6:.0f} MB fp32 per step)" if world > 1 else "single GPU",
+                       "hip_graph": bool(args.graph and world == 1), "optimizer": "SGD"}}))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -164,6 +228,8 @@ def main():
         import torch.distributed as dist
 
         dist.init_process_group(backend="nccl", device_id=dev)  # RCCL on ROCm
+    if args.mode == "train":
+        return train_mode(args, rank, world, dev, dist)
 
     from megaportrait_hack_amd import _lib, model as M, ops
 
