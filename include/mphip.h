@@ -197,7 +197,7 @@ int mphip_add_matmul(const float *a, const float *a2, const float *m, const floa
  *                    mphip_conv3d_fwd (Ci/Co = channels of dy/dx).  mphip_pack_conv_weight_bwd_data packs Wt straight
  *                    from the original OIDHW weight W (its Co/Ci = Wt's: the original conv's Ci/Co).
  * conv3d_bwd_weight: dW[co][ci][tap] = sum_{n,v} dY[n][co][v] * X[n][ci][v+tap]  (nn.Conv3d model.py:505-510, 591).
- *                    precision 0: exact fp32 MFMA, any shape, k in {1,3}; precision 1: f16x3 (k=3, W%8==0).
+ *                    precision 0: exact fp32 MFMA, any shape, k in {1,3}; precision 1: f16x3 (k=3: W%8==0; k=1: D*H*W%128==0).
  *                    Split over voxels, deterministic slab reduce.
  * groupnorm_bwd_reduce / _apply: nn.GroupNorm (+ residual + ReLU) backward (model.py:506-523).  reduce computes
  *                    s1[n][c] = sum du, s2[n][c] = sum du*xhat (du = dy*(y>0) when relu) and folds them into

@@ -495,7 +495,7 @@ extern "C" int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, i
 extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
     if (bwd_weight_direct(N, D, H, W)) return 16;  // unused
-    if (precision == 1) return bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W);
+    if (precision == 1) return bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W, k);
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int bxy = ((Ci + 31) / 32) * ((Co + 95) / 96) * (k == 3 ? 3 : 1);
     return (size_t)bw_splits(ntiles, bxy) * Co * Ci * k * k * k * sizeof(float);
@@ -532,7 +532,7 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, const fl
                                H, W);
         return check_launch("conv3d_bwd_weight(direct)");
     }
-    if (precision == 1) return bwd_weight_f16x3_launch(x, dy, dy_scale, dw, N, Ci, Co, D, H, W, workspace, s);
+    if (precision == 1) return bwd_weight_f16x3_launch(x, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, workspace, s);
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;
     const int splits = bw_splits(ntiles, ci_tiles * co_tiles * (k == 3 ? 3 : 1));

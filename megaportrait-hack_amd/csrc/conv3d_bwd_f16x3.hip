@@ -232,6 +232,116 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
     }
 }
 
+// ---- 1x1x1 backward-weight: dW[co][ci] = sum_v dY[co][v] * X[ci][v] — a plain GEMM with K = voxels, HBM-bound (each
+// operand is read once per output-tile column/row).  Workgroup = 8 waves on a 96 co x 96 ci output tile; a staged tile
+// holds 128 voxels = 8 K-steps of 16, one per wave, so every wave keeps all nine 32x32 accumulators and the eight
+// partial sums are combined in LDS before one slab write.  Same split precision as above.
+__global__ void __launch_bounds__(512)
+conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gscale,
+                                float *__restrict__ slabs, int N, int Ci, int Co, int DHW, int tiles_per_split) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[4 * BF_A_PART];
+    _Float16 *const As = smem;                  // dY [part][96][BF_AP]
+    _Float16 *const Bs = smem + 2 * BF_A_PART;  // X  [part][96][BF_AP]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 31, kb = lane >> 5;
+    const int ci_tiles = (Ci + 95) / 96;
+    const int ci0 = (blockIdx.x % ci_tiles) * 96, co0 = (blockIdx.x / ci_tiles) * 96;
+    const int tiles_per_sample = DHW / 128;
+    const int ntiles = N * tiles_per_sample;
+    const int t_begin = blockIdx.z * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
+    const float dscale = gscale[0];
+    f32x16 acc[3][3];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int n = tile / tiles_per_sample, v0 = (tile % tiles_per_sample) * 128;
+        __syncthreads();
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {  // 0: dY -> As, 1: X -> Bs; 96 channels x 16 rows of 8 voxels, 3 rows per thread
+            const float *src = which ? x : dy;
+            const int C = which ? Ci : Co, c0 = which ? ci0 : co0;
+            const float scale = which ? BF_X_SCALE : dscale;
+            _Float16 *dst = which ? Bs : As;
+            float4 va[3][2];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = tid + i * 512, ch = q >> 4, grp = q & 15;
+                const bool ok = c0 + ch < C;
+                const float *p = src + (ok ? ((size_t)n * C + c0 + ch) * DHW + v0 + grp * 8 : 0);
+                va[i][0] = *reinterpret_cast<const float4 *>(p);
+                va[i][1] = *reinterpret_cast<const float4 *>(p + 4);
+                if (!ok) va[i][0] = va[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int q = tid + i * 512, ch = q >> 4, grp = q & 15;
+                const float v[8] = {va[i][0].x, va[i][0].y, va[i][0].z, va[i][0].w, va[i][1].x, va[i][1].y, va[i][1].z, va[i][1].w};
+                half8 hi, lo;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    _Float16 h, l;
+                    bf_split(v[e] * scale, h, l);
+                    hi[e] = h;
+                    lo[e] = l;
+                }
+                *reinterpret_cast<half8 *>(dst + ch * BF_AP + grp * 8) = hi;
+                *reinterpret_cast<half8 *>(dst + BF_A_PART + ch * BF_AP + grp * 8) = lo;
+            }
+        }
+        __syncthreads();
+        const int koff = wave * 16 + kb * 8;  // this wave's K-step of the tile
+        half8 bh[3], bl[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            bh[t] = *reinterpret_cast<const half8 *>(Bs + (t * 32 + j) * BF_AP + koff);
+            bl[t] = *reinterpret_cast<const half8 *>(Bs + BF_A_PART + (t * 32 + j) * BF_AP + koff);
+        }
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const half8 ah = *reinterpret_cast<const half8 *>(As + (m * 32 + j) * BF_AP + koff);
+            const half8 al = *reinterpret_cast<const half8 *>(As + BF_A_PART + (m * 32 + j) * BF_AP + koff);
+#pragma unroll
+            for (int t = 0; t < 3; ++t) { BF_MFMA3(acc[m][t], ah, al, bh[t], bl[t]) }
+        }
+    }
+    // combine the eight waves' partial sums in LDS — eight plain read-add-write rounds (LDS float atomics retire about
+    // one lane per cycle on gfx950: 74 k of them per workgroup cost more than the whole GEMM) — then one slab write
+    __syncthreads();
+    float *sum = reinterpret_cast<float *>(smem);  // [96][96]
+    for (int w = 0; w < 8; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        float *q = sum + (m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kb) * 96 + t * 32 + j;
+                        *q = w == 0 ? acc[m][t][reg] : *q + acc[m][t][reg];
+                    }
+        }
+        __syncthreads();
+    }
+    const float unscale = gscale[1] * (1.0f / BF_X_SCALE);
+    float *slab = slabs + (size_t)blockIdx.z * Co * Ci;
+    for (int i = tid; i < 96 * 96; i += 512) {
+        const int co = co0 + i / 96, ci = ci0 + i % 96;
+        if (co < Co && ci < Ci) slab[(size_t)co * Ci + ci] = sum[i] * unscale;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+slab_reduce_plain_kernel(const float *__restrict__ slabs, float *__restrict__ out, size_t n, int splits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = sum_slabs(slabs, splits, n, i);
+}
+
 // ---- gradient preparation: per-(n,c) plane sums (-> bias gradient) and max|dy| (-> f16 scale) in one pass ----
 constexpr int GP_CHUNK = 8192;  // floats per workgroup
 __global__ void __launch_bounds__(256)
@@ -330,19 +440,44 @@ static void bwf_plan(int N, int Ci, int Co, int D, int H, int W, int &splits, in
     splits = (int)((ntiles + tps - 1) / tps);
 }
 
-bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k) {
-    return k == 3 && N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0 && W % 8 == 0;
+static void bwf_k1_plan(int N, int Ci, int Co, int DHW, int &splits, int &tps) {
+    const long ntiles = (long)N * (DHW / 128);
+    const int bxy = ((Ci + 95) / 96) * ((Co + 95) / 96);
+    long sp = bxy >= 256 ? 1 : 256 / bxy;
+    if (sp > ntiles) sp = ntiles;
+    if (sp < 1) sp = 1;
+    tps = (int)((ntiles + sp - 1) / sp);
+    splits = (int)((ntiles + tps - 1) / tps);
 }
 
-size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W) {
+bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k) {
+    if (N <= 0 || Ci <= 0 || Co <= 0 || D <= 0 || H <= 0 || W <= 0) return false;
+    if (k == 1) return ((long)D * H * W) % 128 == 0;
+    return k == 3 && W % 8 == 0;
+}
+
+size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k) {
     int splits, tps;
+    if (k == 1) {
+        bwf_k1_plan(N, Ci, Co, D * H * W, splits, tps);
+        return (size_t)splits * Co * Ci * sizeof(float);
+    }
     bwf_plan(N, Ci, Co, D, H, W, splits, tps);
     return (size_t)splits * Co * Ci * 27 * sizeof(float);
 }
 
 int bwd_weight_f16x3_launch(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co, int D,
-                            int H, int W, void *workspace, hipStream_t s) {
+                            int H, int W, int k, void *workspace, hipStream_t s) {
     int splits, tps;
+    if (k == 1) {
+        bwf_k1_plan(N, Ci, Co, D * H * W, splits, tps);
+        dim3 grid(((Ci + 95) / 96) * ((Co + 95) / 96), 1, splits);
+        hipLaunchKernelGGL(conv_bwd_weight_k1_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, (float *)workspace, N, Ci, Co,
+                           D * H * W, tps);
+        const size_t nw = (size_t)Co * Ci;
+        hipLaunchKernelGGL(slab_reduce_plain_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float *)workspace, dw, nw, splits);
+        return check_launch("conv3d_bwd_weight(f16x3, k=1)");
+    }
     bwf_plan(N, Ci, Co, D, H, W, splits, tps);
     dim3 grid(((Ci + 31) / 32) * ((Co + 95) / 96), 1, splits);
     hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, (float *)workspace, N, Ci, Co, D, H, W,

@@ -26,9 +26,9 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)
 bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
-size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W);
+size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
 int bwd_weight_f16x3_launch(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co, int D,
-                            int H, int W, void *workspace, hipStream_t s);
+                            int H, int W, int k, void *workspace, hipStream_t s);
 
 // norm.hip: GroupNorm statistics of x [N,C,S] -> stats [N*G][2] (workspace sized by groupnorm_ws_bytes)
 size_t groupnorm_ws_bytes(int N, int C, int S, int G);

@@ -565,7 +565,9 @@ namespace mphip {
 // coordinate gradient of each channel slice): a workgroup owns a 4x16x16 tile of output voxels (4 per thread) and WB_CH
 // channels.  With a smooth field the source voxels of the tile form a small box (as in K2): dv contributions are
 // accumulated in an LDS image of that box (ds_add_f32) and flushed with ONE global atomic per box element, in
-// coalesced rows — ~1.7 global atomics per output value instead of 8 scattered ones.  A box that does not fit
+// coalesced rows — ~1.7 global atomics per output value instead of 8 scattered ones.  (Tried on top, both without gain:
+// explicit ds_add_f32 instead of flat atomics, +-0 %; handing x1 contributions to the x-neighbour lane by DPP to halve the
+// LDS atomics, -20 %: the LDS atomics are not what bounds this kernel.)  A box that does not fit
 // (wild field) falls back to direct global atomics for that tile.
 constexpr int WB_CH = 8;
 constexpr int WB_LDS = 16384;  // floats: 64 KB of accumulation image
@@ -765,6 +767,28 @@ resize_trilinear_adjoint_kernel(const float *__restrict__ gout, float *__restric
     gin[t] = acc;
 }
 
+// one axis of the same adjoint (the trilinear resize is separable): gin[outer][i][inner] = sum_o w(o -> i) * gout[outer][o][inner].
+// Three of these replace the 3-D gather when the candidate box is large (16 -> 64 upsampling: ~8^3 outputs per input).
+template <bool ALIGN>
+__global__ void __launch_bounds__(256)
+resize_adjoint_axis_kernel(const float *__restrict__ gout, float *__restrict__ gin, size_t outer, int in_len, int out_len,
+                           size_t inner) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= outer * in_len * inner) return;
+    const size_t q = t % inner;
+    const int i = (int)((t / inner) % in_len);
+    const size_t o_ = t / (inner * in_len);
+    int lo, hi;
+    adj_bounds<ALIGN>(i, in_len, out_len, lo, hi);
+    const float *p = gout + (o_ * out_len) * inner + q;
+    float acc = 0.0f;
+    for (int o = lo; o <= hi; ++o) {
+        const float w = adj_w<ALIGN>(o, i, in_len, out_len);
+        if (w != 0.0f) acc += w * p[(size_t)o * inner];
+    }
+    gin[t] = acc;
+}
+
 // dtheta[b][j][k] = sum_p dw[b][j][p] * (x_p, y_p, z_p, 1)[k]   (F.affine_grid backward); partial sums per chunk
 constexpr int TG_CHUNK = 8192;
 __global__ void __launch_bounds__(256)
@@ -945,7 +969,9 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
 
 extern "C" size_t mphip_warp_field_compose_bwd_workspace_bytes(int B, int G) {
     if (B <= 0 || G <= 0) return 0;
-    return (size_t)B * 3 * cdiv((size_t)G * G * G, TG_CHUNK) * 4 * sizeof(double);
+    const size_t theta = (size_t)B * 3 * cdiv((size_t)G * G * G, TG_CHUNK) * 4 * sizeof(double);
+    const size_t axis = (size_t)B * 3 * G * G * G * sizeof(float) * 2;  // two intermediates of the separable adjoint (upper bound)
+    return theta + axis;
 }
 
 extern "C" int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *dtheta, float *dem, int B, int eD,
@@ -966,9 +992,22 @@ extern "C" int mphip_warp_field_compose_bwd(const float *dw, const float *base_t
                            B * 12, chunks);
     }
     if (dem) {
-        const size_t ne = (size_t)B * 3 * eD * eH * eW;
-        hipLaunchKernelGGL(resize_trilinear_adjoint_kernel<false>, dim3(cdiv(ne, 256)), dim3(256), 0, s, dw, dem, B, 3, eD, eH, eW,
-                           G, G, G, 1, 0);
+        const size_t need = mphip_warp_field_compose_bwd_workspace_bytes(B, G);
+        if (!workspace || workspace_bytes < need) {
+            set_error("warp_field_compose_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+            return MPHIP_EWORKSPACE;
+        }
+        // separable: W, then H, then D (each pass gathers <= ~10 outputs per input along one axis)
+        const size_t theta_bytes = (size_t)B * 3 * cdiv((size_t)G * G * G, TG_CHUNK) * 4 * sizeof(double);
+        float *t1 = (float *)((char *)workspace + theta_bytes);          // [B*3][G][G][eW]
+        float *t2 = t1 + (size_t)B * 3 * G * G * eW;                     // [B*3][G][eH][eW]
+        const size_t n1 = (size_t)B * 3 * G * G * eW, n2 = (size_t)B * 3 * G * eH * eW, n3 = (size_t)B * 3 * eD * eH * eW;
+        hipLaunchKernelGGL(resize_adjoint_axis_kernel<false>, dim3(cdiv(n1, 256)), dim3(256), 0, s, dw, t1, (size_t)B * 3 * G * G, eW, G,
+                           (size_t)1);
+        hipLaunchKernelGGL(resize_adjoint_axis_kernel<false>, dim3(cdiv(n2, 256)), dim3(256), 0, s, (const float *)t1, t2,
+                           (size_t)B * 3 * G, eH, G, (size_t)eW);
+        hipLaunchKernelGGL(resize_adjoint_axis_kernel<false>, dim3(cdiv(n3, 256)), dim3(256), 0, s, (const float *)t2, dem,
+                           (size_t)B * 3, eD, G, (size_t)eH * eW);
     }
     return check_launch("warp_field_compose_bwd");
 }
