@@ -565,16 +565,8 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     float *dst = y;
     const size_t n_out = (size_t)N * Co * D * H * W;
     const size_t slab_bytes = (splits > 1 && !keep_split) ? (size_t)splits * n_out * sizeof(float) : 0;
-    // statistics of the output: a separate pass by default.  MPHIP_GN_EPILOGUE=1 computes them in the f16x3 kernel's
-    // epilogue instead (direct launches) — measured 1.2 % SLOWER end to end on MI355X (same-box A/B, 1637 vs 1657
-    // frames/s): the 960 cross-lane shuffles per wave cost more than a pass the Infinity Cache mostly serves.
-    static const bool epilogue_on = getenv("MPHIP_GN_EPILOGUE") && getenv("MPHIP_GN_EPILOGUE")[0] == '1';
-    const bool gn_epilogue = epilogue_on && gn_stats && precision == 1 && splits == 1 && gn_groups > 0 &&
-                             Co % gn_groups == 0 && 96 % (Co / gn_groups) == 0;
-    const int gn_tiles = gn_epilogue ? (int)(fp.grid.x / N) : 0;
-    const size_t gn_bytes = !gn_stats ? 0
-                            : gn_epilogue ? (size_t)N * gn_groups * gn_tiles * 2 * sizeof(double)
-                                          : groupnorm_ws_bytes(N, Co, D * H * W, gn_groups);
+    // (statistics in the f16x3 kernel's epilogue were tried and measured 1.2 % slower end to end: DESIGN.md §3)
+    const size_t gn_bytes = gn_stats ? groupnorm_ws_bytes(N, Co, D * H * W, gn_groups) : 0;
     if (slab_bytes + gn_bytes > 0) {
         if (!workspace || workspace_bytes < slab_bytes + gn_bytes) {
             set_error("conv3d_fwd: workspace %zu bytes < required %zu", workspace_bytes, slab_bytes + gn_bytes);
@@ -589,8 +581,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
     if (precision == 1) {
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_scale,
-                          gn_epilogue ? (double *)gn_ws : nullptr, gn_epilogue ? Co / gn_groups : 0, s);
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_scale, s);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -613,10 +604,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         rc = check_launch("conv3d_fwd(splitk_reduce)");
         if (rc) return rc;
     }
-    if (gn_epilogue)
-        rc = groupnorm_finalize_launch((const double *)gn_ws, gn_stats, N * gn_groups, gn_tiles, (double)(Co / gn_groups) * S, gn_eps, s);
-    else if (gn_stats)
-        rc = groupnorm_stats_launch(y, gn_stats, N, Co, S, gn_groups, gn_eps, gn_ws, s);
+    if (gn_stats) rc = groupnorm_stats_launch(y, gn_stats, N, Co, S, gn_groups, gn_eps, gn_ws, s);
     return rc;
 }
 
@@ -640,12 +628,7 @@ extern "C" int mphip_conv3d_fwd_split(const float *x, const void *w_packed, cons
 extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
                                                   int gn_groups) {
     if (gn_groups <= 0 || Co % gn_groups) return 0;
-    size_t gnb = groupnorm_ws_bytes(N, Co, D * H * W, gn_groups);
-    if (precision == 1 && mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) {
-        const F16x3Plan fp = f16x3_plan(N, Ci, Co, D, H, W);  // direct launch: per-tile partials of the epilogue statistics
-        if (fp.splits == 1) gnb = std::max(gnb, (size_t)fp.grid.x * gn_groups * 2 * sizeof(double));
-    }
-    return mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, k, precision) + gnb;
+    return mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, k, precision) + groupnorm_ws_bytes(N, Co, D * H * W, gn_groups);
 }
 
 extern "C" int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias, float *y, float *gn_stats,

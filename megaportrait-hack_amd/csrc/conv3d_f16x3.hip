@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(NWAVES * 64)
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p, double *__restrict__ gn_partial, int gn_cpg) {
+                       const float *__restrict__ x_scale_p) {
     constexpr int MT = 3, KC = F16X3_KC;
     // activation scale: the fixed X_SCALE for forward activations; a per-tensor power of two from mphip_grad_prep
     // when the input is a gradient (bwd-data), whose magnitude is arbitrary
@@ -362,54 +362,8 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-                const float o = acc[m][t][reg] * unscale + bv[m][reg];
-                acc[m][t][reg] = o;
-                dv[(size_t)co * DHW] = o;
+                dv[(size_t)co * DHW] = acc[m][t][reg] * unscale + bv[m][reg];
             }
-        }
-    }
-    // GroupNorm statistics of the output, folded into the epilogue (direct launches only): per-channel sum / sum of
-    // squares of this tile -> per-group double partials [n][group][tile]; groupnorm's finalize kernel turns them
-    // into (mean, rstd).  Saves the separate statistics pass over the tensor the conv has just written.
-    if (gn_partial != nullptr) {
-        __syncthreads();  // every wave is done with the operand tiles: smem is reused below
-        float *red = reinterpret_cast<float *>(smem);  // [NWAVES][96][2]
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                float s1 = 0.0f, s2 = 0.0f;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    s1 += acc[m][t][reg];
-                    s2 += acc[m][t][reg] * acc[m][t][reg];
-                }
-#pragma unroll
-                for (int sft = 16; sft >= 1; sft >>= 1) {  // the 32 lanes that share this row (same kg)
-                    s1 += __shfl_xor(s1, sft, 64);
-                    s2 += __shfl_xor(s2, sft, 64);
-                }
-                if (j == 0) {
-                    const int ch = m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-                    red[(wave * 96 + ch) * 2] = s1;
-                    red[(wave * 96 + ch) * 2 + 1] = s2;
-                }
-            }
-        }
-        __syncthreads();
-        const int groups_here = F16X3_COT / gn_cpg;
-        if (tid < groups_here) {
-            double a = 0.0, b = 0.0;
-            for (int c = tid * gn_cpg; c < (tid + 1) * gn_cpg; ++c)
-                for (int w = 0; w < NWAVES; ++w) {
-                    a += (double)red[(w * 96 + c) * 2];
-                    b += (double)red[(w * 96 + c) * 2 + 1];
-                }
-            const int tiles = tiles_w * tiles_h * tiles_d;
-            const int tile = blockIdx.x % tiles;
-            const int grp = n * (Co / gn_cpg) + co0 / gn_cpg + tid;
-            gn_partial[((size_t)grp * tiles + tile) * 2] = a;
-            gn_partial[((size_t)grp * tiles + tile) * 2 + 1] = b;
         }
     }
 }
@@ -457,12 +411,7 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, int transposed, hipStr
 }
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, double *gn_partial,
-                 int gn_cpg, hipStream_t s) {
-    if (gn_partial && (p.splits != 1 || gn_cpg <= 0 || F16X3_COT % gn_cpg)) {
-        set_error("conv3d_fwd(f16x3): epilogue statistics need a direct launch and a group size dividing %d", F16X3_COT);
-        return MPHIP_EINVAL;
-    }
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s) {
     if (in_affine && Ci > 768) {
         set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
         return MPHIP_EINVAL;
@@ -472,13 +421,13 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
     if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, gn_partial, gn_cpg);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
     else if (p.td == 4)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, gn_partial, gn_cpg);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
     else
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, gn_partial, gn_cpg);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
     return check_launch("conv3d_fwd(f16x3)");
 }
 

@@ -667,12 +667,6 @@ size_t groupnorm_ws_bytes(int N, int C, int S, int G) {
     return (size_t)N * G * chunks * 2 * sizeof(double);
 }
 
-int groupnorm_finalize_launch(const double *partial, float *stats, int ngroups, int chunks, double cnt, float eps,
-                               hipStream_t s) {
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(ngroups, 256)), dim3(256), 0, s, partial, stats, ngroups, chunks, cnt, eps);
-    return check_launch("groupnorm_stats(finalize)");
-}
-
 int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, int G, float eps, void *workspace,
                            hipStream_t s) {
     size_t cnt = (size_t)(C / G) * S;

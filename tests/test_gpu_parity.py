@@ -316,8 +316,7 @@ def test_groupnorm_folded_into_conv(ops, dev):
 def test_conv_with_groupnorm_statistics(ops, dev, shape):
     """conv + the following GroupNorm's (mean, rstd) in one call (mphip_conv3d_gn_fwd / mphip_conv3d_gnin_gn_fwd): same
     numbers as the separate statistics pass over the stored output, for the plain conv and for the conv with the
-    previous norm folded into its input.  (MPHIP_GN_EPILOGUE=1 moves the statistics into the f16x3 epilogue: an
-    opt-in that measured slower; this test passes in both modes.)"""
+    previous norm folded into its input."""
     n, ci, co, d, h, w = shape
     x = R.seeded_tensor((n, ci, d, h, w), 821, scale=1.7) + 0.3
     wt = R.seeded_tensor((co, ci, 3, 3, 3), 822, scale=(ci * 27) ** -0.5)
