@@ -32,3 +32,20 @@ def oracle_c():
     from oracle import hotpath_c
 
     return hotpath_c
+
+
+@pytest.fixture
+def c_abi_exe(tmp_path):
+    """tests/c_abi/c_abi_smoke.c built with gcc as C99 against include/mphip.h + libmphip.so (+ the HIP runtime for
+    device memory).  Compiling/linking needs no GPU; running it does."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "megaportrait-hack_amd")
+    exe = os.path.join(str(tmp_path), "c_abi_smoke")
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(root, "include"),
+           "-I", "/opt/rocm/include", os.path.join(root, "tests", "c_abi", "c_abi_smoke.c"), "-o", exe, "-L", pkg, "-lmphip",
+           "-L", "/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+    return exe

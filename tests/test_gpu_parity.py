@@ -510,3 +510,13 @@ def test_errors_are_loud(ops, M, dev):
     bad = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 1, D=8, H=8, W=8).items()}
     with torch.no_grad(), pytest.raises(AssertionError):
         hot(**bad)                                       # model.py:1157 shape assert is preserved
+
+
+def test_c_abi_from_plain_c(c_abi_exe):
+    """tests/c_abi/c_abi_smoke.c: a C99 program (gcc; HIP runtime for memory, no Python/torch) drives libmphip.so through
+    include/mphip.h — conv + pool vs host references computed in the C file, and the error-code convention."""
+    import subprocess
+
+    r = subprocess.run([c_abi_exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "C ABI OK" in r.stdout

@@ -128,3 +128,8 @@ def test_captured_tables_match_this_host_or_warn():
     for n, t in cap["linspace"].items():
         assert t[0] == -1.0 and t[-1] == 1.0 and (t[1:] > t[:-1]).all()
         assert (t - torch.linspace(-1, 1, n)).abs().max() < 2e-7   # same values up to the host's last-bit choices
+
+
+def test_c_abi_compiles_and_links_from_plain_c(c_abi_exe):
+    """gcc (C99, no C++/torch) against include/mphip.h + libmphip.so: the boundary is usable from plain C."""
+    assert os.path.isfile(c_abi_exe)
