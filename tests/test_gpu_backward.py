@@ -388,3 +388,37 @@ def test_autocast_inputs_are_computed_in_fp32(dev, M):
     assert x16.grad is not None and x16.grad.dtype == torch.float16
     with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16):
         assert torch.equal(blk(x16), blk(x32))
+
+
+def test_distributed_data_parallel_wraps_the_hot_slice(dev, M):
+    """torch's DistributedDataParallel (bucketed, backward-overlapped RCCL all-reduce) works on the HIP modules: its
+    autograd hooks fire through the custom Functions, gradients equal the unwrapped model's (world size 1 here; the
+    multi-rank averaging itself is covered on CPU by tests/test_dp.py).  adaptive_matrix_beta is unused in forward
+    (model.py:958-963), hence find_unused_parameters."""
+    import socket
+
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel as DDP
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+    try:
+        sd = R.seeded_gbase_hot_state_dict(7)
+        plain, wrapped = M.GbaseHotSlice(), M.GbaseHotSlice()
+        M.load_hot_state_dict(plain, sd)
+        M.load_hot_state_dict(wrapped, sd)
+        plain, wrapped = plain.to(dev).train(), wrapped.to(dev).train()
+        ddp = DDP(wrapped, device_ids=[dev.index], find_unused_parameters=True, bucket_cap_mb=64)
+        inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 45, D=16, H=32, W=32).items()}
+        # DDP forwards kwargs to module.forward, which keeps the reference's 512^2-only assert: call the any-size entry
+        wrapped.forward, plain.forward = wrapped.forward_any_size, plain.forward_any_size
+        ddp(**inp).square().mean().backward()
+        plain(**inp).square().mean().backward()
+        ref = {n: (None if p.grad is None else p.grad.detach().cpu()) for n, p in plain.named_parameters()}
+        # (the warp scatter uses fp32 atomics: two runs differ in the last bits, so not bitwise)
+        _check_param_grads(wrapped.named_parameters(), lambda n: ref[n], 1e-4)
+        assert ref["warp_generator_s2c.adaptive_matrix_beta"] is None
+    finally:
+        dist.destroy_process_group()
