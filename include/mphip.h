@@ -195,7 +195,8 @@ int mphip_add_matmul(const float *a, const float *a2, const float *m, const floa
  *                    operand scale for this tensor (scale: 4 floats of device memory).
  * conv3d_bwd_data:   dx = conv(dy, Wt), Wt[ci][co][a][b][c] = W[co][ci][k-1-a][k-1-b][k-1-c]; same kernels as
  *                    mphip_conv3d_fwd (Ci/Co = channels of dy/dx).  mphip_pack_conv_weight_bwd_data packs Wt straight
- *                    from the original OIDHW weight W (its Co/Ci = Wt's: the original conv's Ci/Co).
+ *                    from the original OIDHW weight W (its Co/Ci = Wt's: the original conv's Ci/Co); `_like` reuses the scale header
+ *                    of W's own f16x3 forward pack instead of scanning W again.
  * conv3d_bwd_weight: dW[co][ci][tap] = sum_{n,v} dY[n][co][v] * X[n][ci][v+tap]  (nn.Conv3d model.py:505-510, 591).
  *                    precision 0: exact fp32 MFMA, any shape, k in {1,3}; precision 1: f16x3 (k=3: W%8==0; k=1: D*H*W%128==0).
  *                    Split over voxels, deterministic slab reduce.
@@ -214,6 +215,8 @@ size_t mphip_grad_prep_workspace_bytes(int N, int C, int S);
 int mphip_grad_prep(const float *dy, float *dbias, float *scale, int N, int C, int S, void *workspace,
                     size_t workspace_bytes, void *stream);
 int mphip_pack_conv_weight_bwd_data(const float *w, void *wp, int Co, int Ci, int k, int precision, void *stream);
+int mphip_pack_conv_weight_bwd_data_like(const float *w, void *wp, int Co, int Ci, int k, int precision,
+                                         const void *fwd_pack, void *stream);
 int mphip_conv3d_bwd_data(const float *dy, const void *wt_packed, float *dx, const float *dy_scale, int N, int Ci,
                           int Co, int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
                           void *stream);

@@ -53,6 +53,7 @@ SIGNATURES = {
     "mphip_grad_prep_workspace_bytes": (_sz, [_i, _i, _i]),
     "mphip_grad_prep": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),
     "mphip_pack_conv_weight_bwd_data": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mphip_pack_conv_weight_bwd_data_like": (_i, [_p, _p, _i, _i, _i, _i, _p, _p]),
     "mphip_conv3d_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
     "mphip_conv3d_bwd_weight_supported": (_i, [_i] * 8),
     "mphip_conv3d_bwd_weight_workspace_bytes": (_sz, [_i] * 8),

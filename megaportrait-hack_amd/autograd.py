@@ -25,7 +25,9 @@ def _bwd_pack(conv) -> ops.PackedConv:
     key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device), ops.weight_epoch())
     hit = conv.__dict__.get("_mphip_bwd_pack")
     if hit is None or hit[0] != key or ops.repacking():
-        hit = (key, ops.PackedConv(w, None, transposed=True))
+        fwd = conv.__dict__.get("_mphip_pack")  # the forward pack — usable only if it was made from these very weights
+        same = fwd is not None and fwd[0][0] == w.data_ptr() and fwd[0][1] == w._version and fwd[0][-1] == ops.weight_epoch()
+        hit = (key, ops.PackedConv(w, None, transposed=True, header_from=fwd[1] if same else None))
         conv.__dict__["_mphip_bwd_pack"] = hit
     return hit[1]
 

@@ -464,24 +464,34 @@ extern "C" size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision
     return 0;
 }
 
-static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, int transposed, void *stream);
+static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, int transposed, const void *header_from,
+                            void *stream);
 
 extern "C" int mphip_pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, void *stream) {
-    return pack_conv_weight(w, wp, Co, Ci, k, precision, 0, stream);
+    return pack_conv_weight(w, wp, Co, Ci, k, precision, 0, nullptr, stream);
 }
 
 // packs the bwd-data conv of the conv whose OIDHW weight is `w` [Ci][Co][k^3] (Co/Ci are the bwd-data conv's own
 // output/input channels = the original conv's input/output channels): no flipped/transposed copy is materialised
 extern "C" int mphip_pack_conv_weight_bwd_data(const float *w, void *wp, int Co, int Ci, int k, int precision, void *stream) {
-    return pack_conv_weight(w, wp, Co, Ci, k, precision, 1, stream);
+    return pack_conv_weight(w, wp, Co, Ci, k, precision, 1, nullptr, stream);
 }
 
-static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, int transposed, void *stream) {
+// same, reusing the per-tensor scale header of an f16x3 pack of the SAME weight tensor (its forward pack): training
+// re-packs both directions every step, and max|w| does not depend on the direction — saves the second absmax pass
+extern "C" int mphip_pack_conv_weight_bwd_data_like(const float *w, void *wp, int Co, int Ci, int k, int precision,
+                                                    const void *fwd_pack, void *stream) {
+    MPHIP_REQUIRE(precision != 1 || fwd_pack, "pack_conv_weight_bwd_data_like: null forward pack");
+    return pack_conv_weight(w, wp, Co, Ci, k, precision, 1, precision == 1 ? fwd_pack : nullptr, stream);
+}
+
+static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int precision, int transposed, const void *header_from,
+                            void *stream) {
     MPHIP_REQUIRE(w && wp, "pack_conv_weight: null pointer");
     MPHIP_REQUIRE(Co > 0 && Ci > 0 && (k == 1 || k == 3), "pack_conv_weight: bad dims");
     MPHIP_REQUIRE(mphip_packed_weight_bytes(Co, Ci, k, precision) > 0,
                   "pack_conv_weight: precision %d not available for Co=%d Ci=%d k=%d", precision, Co, Ci, k);
-    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, transposed, (hipStream_t)stream);
+    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, transposed, header_from, (hipStream_t)stream);
     size_t n = packed_elems_f32(Co, Ci, k);
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -400,13 +400,18 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     return p;
 }
 
-int f16x3_pack(const float *w, void *out, int Co, int Ci, int transposed, hipStream_t s) {
-    unsigned *hdr = (unsigned *)out;
-    zero_fill(out, 16, s);  // header: the absmax kernel accumulates with atomicMax
-    const size_t n = (size_t)Co * Ci * 27;
-    hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(256, (n + 8191) / 8192)), dim3(256), 0, s, w, n, hdr);
-    hipLaunchKernelGGL(f16x3_pack_kernel, dim3(2048), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), (const unsigned *)hdr,
-                       (float *)out, Co, Ci, transposed);
+int f16x3_pack(const float *w, void *out, int Co, int Ci, int transposed, const void *header_from, hipStream_t s) {
+    const unsigned *hdr = (const unsigned *)out;
+    if (header_from) {
+        hdr = (const unsigned *)header_from;  // max|w| already known (the same weight tensor packed for the other direction)
+    } else {
+        zero_fill(out, 16, s);  // header: the absmax kernel accumulates with atomicMax
+        const size_t n = (size_t)Co * Ci * 27;
+        hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(256, (n + 8191) / 8192)), dim3(256), 0, s, w, n,
+                           (unsigned *)out);
+    }
+    hipLaunchKernelGGL(f16x3_pack_kernel, dim3(2048), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), hdr, (float *)out, Co, Ci,
+                       transposed);
     return check_launch("pack_conv_weight(f16x3)");
 }
 

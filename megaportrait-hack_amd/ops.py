@@ -175,13 +175,15 @@ class PackedConv:
     """One Conv3d / 1x1 Conv2d: OIDHW fp32 weight + bias, packed lazily per precision into the
     kernel layouts described in include/mphip.h."""
 
-    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed", "transposed")
+    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed", "transposed", "header_from")
 
-    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool = False):
+    def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool = False,
+                 header_from: Optional["PackedConv"] = None):
         """transposed: this object is the bwd-data conv of the conv whose weight is `weight` (Co/Ci swapped, taps
         flipped); the packing kernels read the original layout directly."""
         weight = _req(weight.detach(), "conv weight")
         self.transposed = bool(transposed)
+        self.header_from = header_from  # (transposed packs) the forward PackedConv of the same weight: shares its f16x3 scale
         co, ci = (weight.shape[1], weight.shape[0]) if transposed else (weight.shape[0], weight.shape[1])
         k = weight.shape[2]
         if weight.dim() == 4:  # Conv2d 1x1 (model.py:425)
@@ -202,8 +204,13 @@ class PackedConv:
             if nbytes == 0:
                 raise RuntimeError(f"PackedConv: precision {precision} not available for Co={self.co} Ci={self.ci} k={self.k}")
             wp = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=self.weight.device)
-            fn = lib.mphip_pack_conv_weight_bwd_data if self.transposed else lib.mphip_pack_conv_weight
-            _lib.check(fn(_ptr(self.weight), _ptr(wp), self.co, self.ci, self.k, precision, _stream()), "mphip_pack_conv_weight")
+            src = self.header_from._packed.get(1) if (self.transposed and precision == 1 and self.header_from is not None) else None
+            if src is not None:
+                _lib.check(lib.mphip_pack_conv_weight_bwd_data_like(_ptr(self.weight), _ptr(wp), self.co, self.ci, self.k, precision,
+                                                                    _ptr(src), _stream()), "mphip_pack_conv_weight_bwd_data_like")
+            else:
+                fn = lib.mphip_pack_conv_weight_bwd_data if self.transposed else lib.mphip_pack_conv_weight
+                _lib.check(fn(_ptr(self.weight), _ptr(wp), self.co, self.ci, self.k, precision, _stream()), "mphip_pack_conv_weight")
             self._packed[precision] = wp
         return wp
 
