@@ -30,6 +30,7 @@ namespace mphip {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float X_SCALE = 16.0f;          // activations: |x| < 4094 stays finite in f16; lo subnormal only below |x| ~ 8e-3
 constexpr float F16_CLAMP = 65000.0f;
@@ -44,6 +45,19 @@ __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     hi = (_Float16)v;
     lo = (_Float16)(v - (float)hi);
 }
+
+#ifdef MPHIP_PROFILE_PHASES
+// dev instrumentation: cycles (s_memtime) per phase, summed over all waves: [0] prologue [1] X-load issue [2] DMA issue
+// [3] tap loop (fragment reads + MFMAs) [4] wait at the group barrier [5] X write + its barrier [6] epilogue [7] waves
+__device__ unsigned long long g_f16x3_prof[8];
+#define PROF_DECL unsigned long long pt_ = __builtin_readcyclecounter(), pa_[7] = {0, 0, 0, 0, 0, 0, 0}
+#define PROF_ADD(slot) { const unsigned long long n_ = __builtin_readcyclecounter(); pa_[slot] += n_ - pt_; pt_ = n_; }
+#define PROF_FLUSH if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_f16x3_prof[q_], pa_[q_]); atomicAdd(&g_f16x3_prof[7], 1ull); }
+#else
+#define PROF_DECL
+#define PROF_ADD(slot)
+#define PROF_FLUSH
+#endif
 
 // ---- weight packing ----------------------------------------------------------------------------
 // header (16 B): [0] inv_scale (float)  [1] scale (float)  [2] max|w| bits (uint)  [3] unused
@@ -120,7 +134,6 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     constexpr int HD = TD + 2, HH = TH + 2, HWp = TW + 2;
     constexpr int XV = HD * HH * HWp;                 // halo voxels
     constexpr int X_PART = 2 * XV * 8;                // halfs per part (hi or lo): [kg][vox][8]
-    constexpr int XI = (8 * XV + NTHR - 1) / NTHR;    // (channel pair, voxel) items per thread
     constexpr int W_BUF = GS * SLAB_HALFS;            // halfs per weight buffer (GS consecutive slabs)
     constexpr int W_PIECES = W_BUF * 2 / 1024;        // 1-KiB DMA pieces per group (18 per slab)
     constexpr int NGRP = F16X3_NG / GS;               // barrier intervals per chunk
@@ -153,24 +166,24 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
 
-    // X staging: item e = i*256+tid -> (channel pair p = e / XV, halo voxel r = e % XV); the source
-    // offset / LDS slot of an item are recomputed when needed instead of living in 2*XI registers.
+    // X staging, by halo ROW: a row is [left edge][TW interior voxels][right edge] of one channel.  An interior item is
+    // (channel pair p, row, quad q): two 16-byte loads (channels 2p, 2p+1; voxels 4q..4q+3 — aligned, always inside the
+    // volume in w) instead of eight 4-byte ones; edge items are the two single voxels.  A row outside the volume in d or h
+    // is all padding: its loads get the out-of-range offset and return 0.  (Phase timing showed the previous
+    // one-voxel-per-load staging spending 12 % of every wave's time issuing loads into a full VMEM queue, which also
+    // delayed the weight DMAs behind it.)  Offsets are recomputed when needed instead of living in registers.
     const unsigned chan_stride = (unsigned)DHW * 4u;
     const long nbase = (long)n * Ci * DHW;
-    auto x_src = [&](int i, int tid_) -> unsigned {
-        const int e = i * NTHR + tid_;
-        if (e >= 8 * XV) return OOB;
-        const int p = e / XV, r = e % XV;
-        const int gd = d0 - 1 + r / (HH * HWp), gh = h0 - 1 + (r / HWp) % HH, gw = w0 - 1 + r % HWp;
-        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W)
-            return (unsigned)((nbase + (long)(2 * p) * DHW + (long)gd * HW + gh * W + gw) * 4);
+    constexpr int ROWS = HD * HH;
+    constexpr int QPR = TW / 4;                        // interior quads per row
+    constexpr int NQ = 8 * ROWS * QPR;                 // interior items per chunk
+    constexpr int QI = (NQ + NTHR - 1) / NTHR;
+    constexpr int NE = 8 * ROWS * 2;                   // edge items per chunk
+    constexpr int EI = (NE + NTHR - 1) / NTHR;
+    auto row_src = [&](int row) -> unsigned {          // byte offset of (n, channel 0, row, w0) or OOB
+        const int gd = d0 - 1 + row / HH, gh = h0 - 1 + row % HH;
+        if ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) return (unsigned)((nbase + (long)gd * HW + gh * W + w0) * 4);
         return OOB;
-    };
-
-    auto x_valid = [&](int e) -> bool {
-        const int r = e % XV;
-        const int gd = d0 - 1 + r / (HH * HWp), gh = h0 - 1 + (r / HWp) % HH, gw = w0 - 1 + r % HWp;
-        return (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && (unsigned)gw < (unsigned)W;
     };
     const bool fuse_in = in_affine != nullptr;  // block-uniform
     if (fuse_in) {
@@ -180,41 +193,70 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         __syncthreads();
     }
 
-    float xr0[XI], xr1[XI];
+    f32x4 xq0[QI], xq1[QI];
+    float xe0[EI], xe1[EI];
 #define F16X3_LOAD_X(chunk)                                                                       \
     {                                                                                             \
         const unsigned soff_ = (unsigned)((long)(chunk) * KC * DHW * 4);                          \
         int tid_ = tid;                                                                           \
         asm volatile("" : "+v"(tid_)); /* opaque: keeps the plan out of registers across the K loop */ \
-        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                          \
-            const unsigned o_ = x_src(i, tid_);                                                   \
-            xr0[i] = buf_load_f(rsrc, o_, soff_);                                                 \
-            xr1[i] = buf_load_f(rsrc, o_ == OOB ? OOB : o_ + chan_stride, soff_);                 \
+        _Pragma("unroll") for (int i = 0; i < QI; ++i) {                                          \
+            const int e_ = i * NTHR + tid_;                                                       \
+            const int p_ = e_ / (ROWS * QPR), rem_ = e_ % (ROWS * QPR);                           \
+            unsigned o_ = e_ < NQ ? row_src(rem_ / QPR) : OOB;                                    \
+            if (o_ != OOB) o_ += (unsigned)(2 * p_) * chan_stride + (unsigned)(rem_ % QPR) * 16u; \
+            xq0[i] = buf_load_f4(rsrc, o_, soff_);                                                \
+            xq1[i] = buf_load_f4(rsrc, o_ == OOB ? OOB : o_ + chan_stride, soff_);                \
         }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < EI; ++i) {                                          \
+            const int e_ = i * NTHR + tid_;                                                       \
+            const int p_ = e_ / (ROWS * 2), rem_ = e_ % (ROWS * 2), side_ = rem_ & 1;             \
+            unsigned o_ = e_ < NE ? row_src(rem_ >> 1) : OOB;                                     \
+            const bool in_w_ = side_ ? w0 + TW < W : w0 > 0;                                      \
+            o_ = (o_ != OOB && in_w_) ? o_ + (unsigned)(2 * p_) * chan_stride + (side_ ? TW * 4 : -4) : OOB; \
+            xe0[i] = buf_load_f(rsrc, o_, soff_);                                                 \
+            xe1[i] = buf_load_f(rsrc, o_ == OOB ? OOB : o_ + chan_stride, soff_);                 \
+        }                                                                                         \
+    }
+    /* one (channel pair, voxel) -> LDS: the preceding GroupNorm (+ReLU) if fused, scale, split, two b32 writes */ \
+#define F16X3_PUT(chunk, p_, r_, va_, vb_, valid_)                                                \
+    {                                                                                             \
+        float v0_ = (va_), v1_ = (vb_);                                                           \
+        if (fuse_in && (valid_)) {                                                                \
+            const float4 sc_ = *reinterpret_cast<const float4 *>(aff + ((chunk) * KC + 2 * (p_)) * 2); \
+            v0_ = v0_ * sc_.x + sc_.y;                                                            \
+            v1_ = v1_ * sc_.z + sc_.w;                                                            \
+            if (in_relu) {                                                                        \
+                v0_ = fmaxf(v0_, 0.0f);                                                           \
+                v1_ = fmaxf(v1_, 0.0f);                                                           \
+            }                                                                                     \
+        }                                                                                         \
+        const int dst_ = ((((p_) / 4) * XV + (r_)) * 8) + ((p_) % 4) * 2;                         \
+        _Float16 h0_, l0_, h1_, l1_;                                                              \
+        split_f16(v0_ * x_scale, h0_, l0_);                                                       \
+        split_f16(v1_ * x_scale, h1_, l1_);                                                       \
+        half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                                \
+        *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                             \
+        *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                                    \
     }
 #define F16X3_WRITE_X(chunk)                                                                      \
     {                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < XI; ++i) {                                          \
+        _Pragma("unroll") for (int i = 0; i < QI; ++i) {                                          \
             const int e_ = i * NTHR + tid;                                                        \
-            if (e_ < 8 * XV) {                                                                    \
-                const int p_ = e_ / XV, r_ = e_ % XV;                                             \
-                const int dst_ = (((p_ / 4) * XV + r_) * 8) + (p_ % 4) * 2;                       \
-                float v0_ = xr0[i], v1_ = xr1[i];                                                 \
-                if (fuse_in && x_valid(e_)) {                                                     \
-                    const float4 sc_ = *reinterpret_cast<const float4 *>(aff + ((chunk) * KC + 2 * p_) * 2); \
-                    v0_ = v0_ * sc_.x + sc_.y;                                                    \
-                    v1_ = v1_ * sc_.z + sc_.w;                                                    \
-                    if (in_relu) {                                                                \
-                        v0_ = fmaxf(v0_, 0.0f);                                                   \
-                        v1_ = fmaxf(v1_, 0.0f);                                                   \
-                    }                                                                             \
-                }                                                                                 \
-                _Float16 h0_, l0_, h1_, l1_;                                                      \
-                split_f16(v0_ * x_scale, h0_, l0_);                                               \
-                split_f16(v1_ * x_scale, h1_, l1_);                                               \
-                half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                        \
-                *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                     \
-                *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                            \
+            if (e_ < NQ) {                                                                        \
+                const int p_ = e_ / (ROWS * QPR), rem_ = e_ % (ROWS * QPR), row_ = rem_ / QPR;    \
+                const int r_ = row_ * HWp + 1 + (rem_ % QPR) * 4;                                 \
+                const bool ok_ = fuse_in && row_src(row_) != OOB;                                 \
+                _Pragma("unroll") for (int k = 0; k < 4; ++k) F16X3_PUT(chunk, p_, r_ + k, xq0[i][k], xq1[i][k], ok_) \
+            }                                                                                     \
+        }                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < EI; ++i) {                                          \
+            const int e_ = i * NTHR + tid;                                                        \
+            if (e_ < NE) {                                                                        \
+                const int p_ = e_ / (ROWS * 2), rem_ = e_ % (ROWS * 2), side_ = rem_ & 1, row_ = rem_ >> 1; \
+                const int r_ = row_ * HWp + (side_ ? HWp - 1 : 0);                                \
+                const bool ok_ = fuse_in && row_src(row_) != OOB && (side_ ? w0 + TW < W : w0 > 0); \
+                F16X3_PUT(chunk, p_, r_, xe0[i], xe1[i], ok_)                                     \
             }                                                                                     \
         }                                                                                         \
     }
@@ -256,10 +298,12 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
     // prologue: X(chunk0) -> LDS, W(chunk0, group 0) -> buffer 0
+    PROF_DECL;
     F16X3_DMA_W(c_begin, 0, 0);
     F16X3_LOAD_X(c_begin);
     F16X3_WRITE_X(c_begin);
     __syncthreads();
+    PROF_ADD(0)
 
     int wb = 0;
     for (int c = c_begin; c < c_end; ++c) {
@@ -267,6 +311,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #ifndef MPHIP_ABL_NOX
         if (more) F16X3_LOAD_X(c + 1);
 #endif
+        PROF_ADD(1)
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             // stream the next group of slabs while this one is consumed
@@ -277,6 +322,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
                 F16X3_DMA_W(c + 1, 0, wb ^ 1);
             }
 #endif
+            PROF_ADD(2)
             const _Float16 *wsb = Ws + wb * W_BUF + a_base;
             // Fragments are double buffered in registers by hand: the 10 ds_read_b128 of tap tg+1 are
             // issued before the 18 MFMAs of tap tg, so LDS latency hides under 576 MFMA cycles (left to
@@ -328,7 +374,9 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #ifdef MPHIP_ABL_NOMFMA
 #undef __builtin_amdgcn_mfma_f32_32x32x16_f16
 #endif
+            PROF_ADD(3)
             __syncthreads();  // slab (g+1) landed (DMA drained by the barrier's vmcnt(0)); slab g free
+            PROF_ADD(4)
             wb ^= 1;
         }
 #ifndef MPHIP_ABL_NOX
@@ -337,9 +385,11 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             __syncthreads();
         }
 #endif
+        PROF_ADD(5)
     }
 #undef F16X3_LOAD_X
 #undef F16X3_WRITE_X
+#undef F16X3_PUT
 #undef F16X3_DMA_W
 
     const bool direct = gridDim.z == 1;
@@ -366,6 +416,8 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             }
         }
     }
+    PROF_ADD(6)
+    PROF_FLUSH
 }
 
 bool f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k) {
@@ -437,3 +489,14 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
 }
 
 }  // namespace mphip
+
+#ifdef MPHIP_PROFILE_PHASES
+extern "C" int mphip_debug_f16x3_profile(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mphip::g_f16x3_prof), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mphip::g_f16x3_prof), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -10,6 +10,12 @@ __device__ __forceinline__ float buf_load_f(__amdgpu_buffer_rsrc_t rsrc, unsigne
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)soff, 0));
 }
 
+typedef float mphip_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ mphip_f32x4 buf_load_f4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned soff) {
+    typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+    return __builtin_bit_cast(mphip_f32x4, (u32x4_)__builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0));
+}
+
 struct F16x3Plan {
     int td, variant, splits, chunks_per_split;
     dim3 grid;
