@@ -118,11 +118,11 @@ __global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restr
 // GS = packed slabs (of 3 taps) streamed per barrier interval: 3 -> 4 barriers per chunk and 110 KB of
 // weight buffers (one workgroup per CU), 1 -> 10 barriers per chunk and 37 KB.
 template <int TD, int TH, int TW, int NWAVES, int GS>
-__global__ void __launch_bounds__(NWAVES * 64)
+__global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // 256 registers: two waves per SIMD
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p) {
+                       const float *__restrict__ x_scale_p, int tiles_total) {
     constexpr int MT = 3, KC = F16X3_KC;
     // activation scale: the fixed X_SCALE for forward activations; a per-tensor power of two from mphip_grad_prep
     // when the input is a gradient (bwd-data), whose magnitude is arbitrary
@@ -152,12 +152,20 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     const int HW = H * W, DHW = D * HW;
 
     const int tiles_w = W / TW, tiles_h = H / TH, tiles_d = D / TD;
-    int bid = blockIdx.x;
-    const int tw = bid % tiles_w; bid /= tiles_w;
-    const int th = bid % tiles_h; bid /= tiles_h;
-    const int td = bid % tiles_d;
-    const int n = bid / tiles_d;
-    const int d0 = td * TD, h0 = th * TH, w0 = tw * TW;
+    // Persistent over tiles: gridDim.x is sized to what the chip holds at once and a workgroup walks tiles blockIdx.x,
+    // +gridDim.x, ... — the output stores of one tile drain while the next tile's weight DMA and halo loads are already
+    // in flight, and the per-workgroup launch / teardown gaps disappear (phase timing: prologue + epilogue were 15-25 %
+    // of a wave's time with one tile per workgroup).
+    int n, d0, h0, w0;
+    auto decode_tile = [&](int tile_id) {
+        int bid = tile_id;
+        const int tw = bid % tiles_w; bid /= tiles_w;
+        const int th = bid % tiles_h; bid /= tiles_h;
+        const int td = bid % tiles_d;
+        n = bid / tiles_d;
+        d0 = td * TD; h0 = th * TH; w0 = tw * TW;
+    };
+    decode_tile(blockIdx.x);
     const int cot = blockIdx.y;
     const int nchunks = Ci / KC;
     const int c_begin = blockIdx.z * chunks_per_split;
@@ -169,11 +177,10 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     // X staging, by halo ROW: a row is [left edge][TW interior voxels][right edge] of one channel.  An interior item is
     // (channel pair p, row, quad q): two 16-byte loads (channels 2p, 2p+1; voxels 4q..4q+3 — aligned, always inside the
     // volume in w) instead of eight 4-byte ones; edge items are the two single voxels.  A row outside the volume in d or h
-    // is all padding: its loads get the out-of-range offset and return 0.  (Phase timing showed the previous
-    // one-voxel-per-load staging spending 12 % of every wave's time issuing loads into a full VMEM queue, which also
-    // delayed the weight DMAs behind it.)  Offsets are recomputed when needed instead of living in registers.
+    // is all padding: its loads get the out-of-range offset and return 0.  (12 load instructions per thread and chunk
+    // instead of 68; +3 % on the full-resolution layers.)  Offsets are recomputed when needed instead of living in registers.
     const unsigned chan_stride = (unsigned)DHW * 4u;
-    const long nbase = (long)n * Ci * DHW;
+    long nbase = 0;
     constexpr int ROWS = HD * HH;
     constexpr int QPR = TW / 4;                        // interior quads per row
     constexpr int NQ = 8 * ROWS * QPR;                 // interior items per chunk
@@ -186,12 +193,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         return OOB;
     };
     const bool fuse_in = in_affine != nullptr;  // block-uniform
-    if (fuse_in) {
-        // the GroupNorm (+ReLU) that precedes this conv (model.py:506-507 -> 517 -> 518) is applied while the halo
-        // tile is staged: x' = relu(x*scale[n,c] + shift[n,c]) inside the volume, 0 in the padding
-        for (int i = tid; i < Ci * 2; i += NTHR) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
-        __syncthreads();
-    }
+    int aff_n = -1;
 
     f32x4 xq0[QI], xq1[QI];
     float xe0[EI], xe1[EI];
@@ -242,7 +244,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #define F16X3_WRITE_X(chunk)                                                                      \
     {                                                                                             \
         _Pragma("unroll") for (int i = 0; i < QI; ++i) {                                          \
-            const int e_ = i * NTHR + tid;                                                        \
+            const int e_ = i * NTHR + tid + tz;                                                   \
             if (e_ < NQ) {                                                                        \
                 const int p_ = e_ / (ROWS * QPR), rem_ = e_ % (ROWS * QPR), row_ = rem_ / QPR;    \
                 const int r_ = row_ * HWp + 1 + (rem_ % QPR) * 4;                                 \
@@ -251,7 +253,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             }                                                                                     \
         }                                                                                         \
         _Pragma("unroll") for (int i = 0; i < EI; ++i) {                                          \
-            const int e_ = i * NTHR + tid;                                                        \
+            const int e_ = i * NTHR + tid + tz;                                                   \
             if (e_ < NE) {                                                                        \
                 const int p_ = e_ / (ROWS * 2), rem_ = e_ % (ROWS * 2), side_ = rem_ & 1, row_ = rem_ >> 1; \
                 const int r_ = row_ * HWp + (side_ ? HWp - 1 : 0);                                \
@@ -289,6 +291,19 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         b_base[t] = (kg * XV + (vd * HH + vh) * HWp + vw) * 8;
     }
 
+    PROF_DECL;
+  for (int tile_id = blockIdx.x; tile_id < tiles_total; tile_id += gridDim.x) {
+    decode_tile(tile_id);
+    nbase = (long)n * Ci * DHW;
+    int tz = 0;
+    asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps per-tile-invariant index math / bias loads from being hoisted into registers
+    if (fuse_in && n != aff_n) {  // (workgroup-uniform; every wave is past the previous tile's last LDS read: final group barrier)
+        // the GroupNorm (+ReLU) that precedes this conv (model.py:506-507 -> 517 -> 518) is applied while the halo
+        // tile is staged: x' = relu(x*scale[n,c] + shift[n,c]) inside the volume, 0 in the padding
+        for (int i = tid; i < Ci * 2; i += NTHR) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
+        aff_n = n;
+        __syncthreads();
+    }
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -298,7 +313,6 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
     // prologue: X(chunk0) -> LDS, W(chunk0, group 0) -> buffer 0
-    PROF_DECL;
     F16X3_DMA_W(c_begin, 0, 0);
     F16X3_LOAD_X(c_begin);
     F16X3_WRITE_X(c_begin);
@@ -401,7 +415,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     for (int m = 0; m < MT; ++m)
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-            bv[m][reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg] : 0.0f;
+            bv[m][reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg + tz] : 0.0f;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int v = (wave * NT + t) * 32 + jv;
@@ -411,12 +425,13 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
-                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg + tz;
                 dv[(size_t)co * DHW] = acc[m][t][reg] * unscale + bv[m][reg];
             }
         }
     }
     PROF_ADD(6)
+  }  // tiles
     PROF_FLUSH
 }
 
@@ -476,15 +491,24 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const float *hdr = (const float *)wpacked;
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
+    // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
+    // the (2,8,8) one), each walking its share of the tiles
+    const int tiles_total = (int)p.grid.x;
+    const int per_cu = (p.variant == 1 || p.td == 4) ? 1 : 2;
+    const long others = (long)p.grid.y * p.grid.z;
+    long gx = (256L * per_cu + others - 1) / others;
+    if (gx < 1) gx = 1;
+    if (gx > tiles_total || getenv("MPHIP_F16X3_NO_PERSIST")) gx = tiles_total;
+    dim3 grid((unsigned)gx, p.grid.y, p.grid.z);
     if (p.variant == 1)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
     else if (p.td == 4)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), p.grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
     else
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), p.grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale);
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
     return check_launch("conv3d_fwd(f16x3)");
 }
 
