@@ -292,18 +292,30 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     }
 
     PROF_DECL;
-  for (int tile_id = blockIdx.x; tile_id < tiles_total; tile_id += gridDim.x) {
-    decode_tile(tile_id);
-    nbase = (long)n * Ci * DHW;
-    int tz = 0;
-    asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps per-tile-invariant index math / bias loads from being hoisted into registers
-    if (fuse_in && n != aff_n) {  // (workgroup-uniform; every wave is past the previous tile's last LDS read: final group barrier)
+    // first tile's prologue: X(chunk0) -> LDS, W(chunk0, group 0) -> buffer 0.  Later tiles find theirs already staged:
+    // the last chunk of a tile loads the NEXT tile's first halo chunk and weight slab (cross-tile software pipeline).
+    auto load_aff = [&]() {
         // the GroupNorm (+ReLU) that precedes this conv (model.py:506-507 -> 517 -> 518) is applied while the halo
         // tile is staged: x' = relu(x*scale[n,c] + shift[n,c]) inside the volume, 0 in the padding
         for (int i = tid; i < Ci * 2; i += NTHR) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
         aff_n = n;
+    };
+    nbase = (long)n * Ci * DHW;
+    if (fuse_in) {
+        load_aff();
         __syncthreads();
     }
+    int tz = 0;
+    F16X3_DMA_W(c_begin, 0, 0);
+    F16X3_LOAD_X(c_begin);
+    F16X3_WRITE_X(c_begin);
+    __syncthreads();
+    PROF_ADD(0)
+    int wb = 0;
+  for (int tile_id = blockIdx.x; tile_id < tiles_total; tile_id += gridDim.x) {
+    const int en = n, ed0 = d0, eh0 = h0, ew0 = w0;  // this tile's coordinates (the staging variables move on to the next tile)
+    const bool has_next = tile_id + (int)gridDim.x < tiles_total;
+    asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps per-tile-invariant index math / bias loads from being hoisted into registers
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -312,18 +324,18 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
-    // prologue: X(chunk0) -> LDS, W(chunk0, group 0) -> buffer 0
-    F16X3_DMA_W(c_begin, 0, 0);
-    F16X3_LOAD_X(c_begin);
-    F16X3_WRITE_X(c_begin);
-    __syncthreads();
-    PROF_ADD(0)
-
-    int wb = 0;
     for (int c = c_begin; c < c_end; ++c) {
         const bool more = c + 1 < c_end;
 #ifndef MPHIP_ABL_NOX
-        if (more) F16X3_LOAD_X(c + 1);
+        if (more) {
+            F16X3_LOAD_X(c + 1);
+        } else if (has_next) {
+            decode_tile(tile_id + (int)gridDim.x);  // staging now addresses the next tile (the epilogue uses en, ed0, ...)
+            nbase = (long)n * Ci * DHW;
+            // (the previous affine table was last read by the WRITE_X that ended the previous chunk, a barrier ago)
+            if (fuse_in && n != aff_n) load_aff();
+            F16X3_LOAD_X(c_begin);
+        }
 #endif
         PROF_ADD(1)
 #pragma unroll
@@ -334,6 +346,8 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
                 F16X3_DMA_W(c, g + 1, wb ^ 1);
             } else if (more) {
                 F16X3_DMA_W(c + 1, 0, wb ^ 1);
+            } else if (has_next) {
+                F16X3_DMA_W(c_begin, 0, wb ^ 1);  // the next tile's first slab (weights do not depend on the tile)
             }
 #endif
             PROF_ADD(2)
@@ -397,11 +411,13 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         if (more) {
             F16X3_WRITE_X(c + 1);  // every wave is past its last read of the X tile (barrier above)
             __syncthreads();
+        } else if (has_next) {
+            F16X3_WRITE_X(c_begin);  // the next tile's first halo chunk; its barrier doubles as the next tile's "prologue done"
+            __syncthreads();
         }
 #endif
         PROF_ADD(5)
     }
-#undef F16X3_LOAD_X
 #undef F16X3_WRITE_X
 #undef F16X3_PUT
 #undef F16X3_DMA_W
@@ -420,7 +436,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     for (int t = 0; t < NT; ++t) {
         const int v = (wave * NT + t) * 32 + jv;
         const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
-        float *dv = dst + (size_t)n * Co * DHW + (size_t)(d0 + vd) * HW + (h0 + vh) * W + w0 + vw;
+        float *dv = dst + (size_t)en * Co * DHW + (size_t)(ed0 + vd) * HW + (eh0 + vh) * W + ew0 + vw;
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
 #pragma unroll
@@ -432,6 +448,10 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     }
     PROF_ADD(6)
   }  // tiles
+#undef F16X3_LOAD_X
+#undef F16X3_WRITE_X
+#undef F16X3_PUT
+#undef F16X3_DMA_W
     PROF_FLUSH
 }
 
