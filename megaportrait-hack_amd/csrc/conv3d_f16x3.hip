@@ -136,9 +136,8 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     constexpr int X_PART = 2 * XV * 8;                // halfs per part (hi or lo): [kg][vox][8]
     constexpr int W_BUF = GS * SLAB_HALFS;            // halfs per weight buffer (GS consecutive slabs)
     constexpr int W_PIECES = W_BUF * 2 / 1024;        // 1-KiB DMA pieces per group (18 per slab)
-    constexpr int NGRP = F16X3_NG / GS;               // barrier intervals per chunk
-    constexpr int GT = GS * F16X3_TG;                 // taps per interval
-    static_assert(F16X3_NG % GS == 0, "group size");
+    constexpr int NGRP = (F16X3_NG + GS - 1) / GS;    // barrier intervals per chunk (the last group may be shorter)
+    constexpr int GT = GS * F16X3_TG;                 // taps per full interval
     constexpr int AFF_MAX_CI = 768;          // per-channel (scale, shift) of the fused input GroupNorm, kept in LDS
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * W_BUF + 2 * X_PART + AFF_MAX_CI * 4];
     _Float16 *const Ws = smem;               // [2 buffers][part][tap][kg][co][8]
@@ -266,9 +265,10 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #define F16X3_DMA_W(chunk, grp, wbuf)                                                             \
     {                                                                                             \
         const _Float16 *src_ = wslabs + (((size_t)cot * nchunks + (chunk)) * F16X3_NG + (grp) * GS) * SLAB_HALFS + lane * 8; \
+        const int npieces_ = (((grp) + 1) * GS <= F16X3_NG ? GS : F16X3_NG - (grp) * GS) * (SLAB_HALFS * 2 / 1024); \
         _Pragma("unroll") for (int q = 0; q < (W_PIECES + NWAVES - 1) / NWAVES; ++q) {            \
             const int piece_ = q * NWAVES + wave;                                                 \
-            if (piece_ < W_PIECES)                                                                \
+            if (piece_ < npieces_)                                                                \
                 __builtin_amdgcn_global_load_lds(                                                 \
                     (const __attribute__((address_space(1))) void *)(src_ + piece_ * 512),        \
                     (__attribute__((address_space(3))) void *)(Ws + (wbuf) * W_BUF + piece_ * 512), 16, 0, 0); \
@@ -370,11 +370,13 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             bl[set][t] = *reinterpret_cast<const half8 *>(Xs + X_PART + b_base[t] + toff_);               \
         }                                                                                                 \
     }
+            const int gt = ((g + 1) * GS <= F16X3_NG ? GS : F16X3_NG - g * GS) * F16X3_TG;  // taps in this group
             F16X3_LOAD_FRAGS(0, 0);
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) {
+                if (tg < gt) {
                 const int cur = tg & 1;
-                if (tg + 1 < GT) F16X3_LOAD_FRAGS(cur ^ 1, tg + 1);
+                if (tg + 1 < gt) F16X3_LOAD_FRAGS(cur ^ 1, tg + 1);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this tap's MFMAs
                 // three passes over the 6 accumulators: consecutive MFMAs never share an accumulator
 #ifdef MPHIP_ABL_NOMFMA
@@ -397,6 +399,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #pragma unroll
                     for (int t = 0; t < NT; ++t)
                         acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][m], bh[cur][t], acc[m][t], 0, 0, 0);
+                }
             }
 #undef F16X3_LOAD_FRAGS
 #ifdef MPHIP_ABL_NOMFMA
@@ -520,6 +523,8 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     if (gx < 1) gx = 1;
     if (gx > tiles_total || getenv("MPHIP_F16X3_NO_PERSIST")) gx = tiles_total;
     dim3 grid((unsigned)gx, p.grid.y, p.grid.z);
+    // (two-slab groups for the 512-voxel tile — 5 instead of 9 barriers per chunk, 147 KB of LDS — were tried: the
+    //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
     if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
                            D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
