@@ -22,6 +22,7 @@ from . import autograd as ag
 from . import ops
 
 COMPRESS_DIM = 512  # model.py:48
+_C2D_EARLY = __import__("os").environ.get("MPHIP_C2D_EARLY", "0") == "1"
 
 
 def _f32(*tensors):
@@ -265,13 +266,19 @@ class ResBlock3D(nn.Module):
         y = ag.conv3d(y, self.conv2, _packs.get(self.conv2))
         return ag.groupnorm(y, self.gn2, residual=identity, relu=True)
 
-    def forward(self, x, _pool_after: bool = False):
+    def forward(self, x, _pool_after: bool = False, _after_conv1=None):
+        """`_after_conv1`: host-side hook called right after conv1 has been launched (GbaseHotSlice issues the side-stream
+        generator there, once the GPU has a long kernel queued)."""
         x = _f32(x)
         if ag.needs_grad(self, x):
             y = self._forward_train(x)
+            if _after_conv1 is not None:
+                _after_conv1()
             return ag.AvgPool2Fn.apply(y) if _pool_after else y
         identity = x if isinstance(self.shortcut, nn.Identity) else ops.conv3d_split(x, _packs.get(self.shortcut))
         y = ops.conv3d_split(x, _packs.get(self.conv1), gn_groups=32, gn_eps=self.gn1.eps)  # + GN1's statistics
+        if _after_conv1 is not None:
+            _after_conv1()
         st = ops.groupnorm_stats(y, 32, self.gn1.eps)
         pc2 = _packs.get(self.conv2)
         if y.splits == 1 and ops.gn_in_conv_ok(y.shape, pc2):
@@ -305,12 +312,12 @@ class G3d(nn.Module):
         )
         self.final_conv = nn.Conv3d(96, 96, kernel_size=3, padding=1)
 
-    def forward(self, x):
+    def forward(self, x, _after_first_conv=None):
         x = _f32(x)
         train = ag.needs_grad(self, x)
         up = ag.UpsampleTrilinear2Fn.apply if train else ops.upsample_trilinear2
         d = self.downsampling
-        x = d[0](x, _pool_after=True)   # AvgPool3d fused into the block's last elementwise pass (inference)
+        x = d[0](x, _pool_after=True, _after_conv1=_after_first_conv)   # AvgPool3d fused into the block's last elementwise pass (inference)
         x = d[2](x, _pool_after=True)
         x = d[4](x, _pool_after=True)
         x = d[6](x)
@@ -417,16 +424,26 @@ class GbaseHotSlice(nn.Module):
         side = self._side_stream(main) if (self.overlap_generators and not train) else None
         if side is not None:
             side.wait_stream(main)  # inputs produced on the main stream are visible
-        # critical path first: the host issues S2C's launches before it spends time on the side stream's
+        # Critical path first, in HOST order too: S2C, warp #1 and G3d's first (0.6 ms) conv are launched before the host
+        # spends its ~0.3 ms issuing the C2D generator's ~25 launches on the side stream.  Issued earlier, they leave the
+        # main stream idle between S2C and warp #1 whenever the host is not running ahead (first step, profiled runs);
+        # in the steady-state throughput loop the host is ahead anyway and the order is worth +0.3 % only.
         w_s2c = self.warp_generator_s2c(Rs, ts, zs, es)
-        if side is not None:
+        c2d = {}
+
+        def issue_c2d():
             with torch.cuda.stream(side):
-                w_c2d = self.warp_generator_c2d(Rd, td, zd, es)
+                c2d["w"] = self.warp_generator_c2d(Rd, td, zd, es)
+
+        early = side is not None and _C2D_EARLY  # dev switch: the old issue order, for same-box A/B runs
+        if early:
+            issue_c2d()
         vc = apply_warping_field(vs, w_s2c)
         if check_shape:
             assert vc.shape[1:] == (96, 16, 64, 64), f"Expected vc shape (_, 96, 16, 64, 64), got {vc.shape}"
-        vc2d = self.G3d(vc)
+        vc2d = self.G3d(vc, _after_first_conv=issue_c2d if (side is not None and not early) else None)
         if side is not None:
+            w_c2d = c2d["w"]
             main.wait_stream(side)
             w_c2d.record_stream(main)
         else:
