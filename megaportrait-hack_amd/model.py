@@ -14,6 +14,7 @@ and csrc/warp.hip (K9/K10); under torch.no_grad() the fused inference path runs.
 from __future__ import annotations
 
 import logging
+import os
 
 import torch
 import torch.nn as nn
@@ -22,7 +23,7 @@ from . import autograd as ag
 from . import ops
 
 COMPRESS_DIM = 512  # model.py:48
-_C2D_EARLY = __import__("os").environ.get("MPHIP_C2D_EARLY", "0") == "1"
+_C2D_EARLY = os.environ.get("MPHIP_C2D_EARLY", "0") == "1"  # dev switch, see GbaseHotSlice._run
 
 
 def _f32(*tensors):

@@ -9,6 +9,8 @@ from __future__ import annotations
 import ctypes
 from typing import Optional, Tuple
 
+import os as _os
+
 import torch
 
 from . import _lib
@@ -155,8 +157,6 @@ def warp_volume_dsum(v: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
 # Conv precision: 0 = exact fp32 MFMA; 1 = "f16x3" (split-f16, 3 MFMAs per product, fp32-class
 # accuracy, ~3x faster).  "auto" uses f16x3 wherever the kernel supports the shape (all 3x3x3 convs
 # of G3d) and exact fp32 elsewhere.  Override with MPHIP_CONV_PRECISION=fp32|f16x3|auto.
-import os as _os
-
 _PRECISION_NAMES = {"fp32": 0, "exact": 0, "0": 0, "f16x3": 1, "1": 1, "auto": 1}
 _default_precision = _PRECISION_NAMES.get(_os.environ.get("MPHIP_CONV_PRECISION", "auto").lower(), 1)
 

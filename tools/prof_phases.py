@@ -1,3 +1,6 @@
+"""Phase timing of the dominant f16x3 conv (s_memtime instrumentation).  Needs a library built with
+-DMPHIP_PROFILE_PHASES:  MPHIP_EXTRA_FLAGS=-DMPHIP_PROFILE_PHASES MPHIP_BUILD_DIR=/tmp/b bash megaportrait-hack_amd/csrc/build.sh /path/lib.so;
+MPHIP_LIB=/path/lib.so python tools/prof_phases.py"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
