@@ -32,6 +32,10 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
                            f"{type(t).__name__} on {getattr(t, 'device', None)}")
     if t.dtype != dtype:
         raise RuntimeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if t.device.index != torch.cuda.current_device():
+        # kernels launch on the calling thread's current device and stream (one process per GPU)
+        raise RuntimeError(f"{name}: tensor lives on {t.device} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device(tensor.device) (or use `with torch.cuda.device(...)`) first")
     return t if t.is_contiguous() else t.contiguous()
 
 
