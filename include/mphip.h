@@ -263,6 +263,11 @@ int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *
 int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
                        int invert, void *stream);
 
+/* Diagnostic (synchronous, not stream-ordered): the number of activation elements the f16x3 conv kernels had to clamp
+ * because |x * scale| left the f16 range (|x| >= 4062 in the forward pass) since the last reset.  0 in normal operation;
+ * non-zero means those launches returned finite but wrong values — rerun with precision 0 (exact fp32).            */
+int mphip_f16x3_saturation_count(unsigned long long *count, int reset);
+
 #ifdef __cplusplus
 }
 #endif

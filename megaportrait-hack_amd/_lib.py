@@ -69,6 +69,7 @@ SIGNATURES = {
     "mphip_warp_field_compose_bwd_workspace_bytes": (_sz, [_i, _i]),
     "mphip_warp_field_compose_bwd": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_rt_theta_bwd": (_i, [_p] * 5 + [_i, _i, _p]),
+    "mphip_f16x3_saturation_count": (_i, [_p, _i]),
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
 }

@@ -40,6 +40,11 @@ constexpr int F16X3_NG = 27 / F16X3_TG;   // slabs per 16-channel chunk
 constexpr int F16X3_COT = 96;             // output channels per workgroup (3 MFMA row tiles)
 constexpr int SLAB_HALFS = 2 * F16X3_TG * 2 * F16X3_COT * 8;  // [part][tap][kg][co][8] = 9216 halfs = 18432 B
 
+// Range guard: activations beyond +-65000/scale (|x| >= 4062 at the forward scale 16) are clamped by split_f16 — finite but
+// wrong.  The kernels count such elements here (one atomic per wavefront that saw any, i.e. none in normal operation);
+// mphip_f16x3_saturation_count() reads the counter so a caller can verify a run stayed in range.
+__device__ unsigned long long g_f16x3_saturated;
+
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
     v = fminf(fmaxf(v, -F16_CLAMP), F16_CLAMP);
     hi = (_Float16)v;
@@ -57,6 +62,12 @@ __device__ unsigned long long g_f16x3_prof[8];
 #define PROF_DECL
 #define PROF_ADD(slot)
 #define PROF_FLUSH
+#endif
+
+#ifdef MPHIP_NO_SAT_GUARD  /* dev: same-box A/B of the range guard's cost */
+#define F16X3_SAT_COUNT(a_, b_)
+#else
+#define F16X3_SAT_COUNT(a_, b_) sat_ += (fabsf((a_) * x_scale) > F16_CLAMP) + (fabsf((b_) * x_scale) > F16_CLAMP);
 #endif
 
 // ---- weight packing ----------------------------------------------------------------------------
@@ -234,6 +245,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         }                                                                                         \
         const int dst_ = ((((p_) / 4) * XV + (r_)) * 8) + ((p_) % 4) * 2;                         \
         _Float16 h0_, l0_, h1_, l1_;                                                              \
+        F16X3_SAT_COUNT(v0_, v1_)                                                                 \
         split_f16(v0_ * x_scale, h0_, l0_);                                                       \
         split_f16(v1_ * x_scale, h1_, l1_);                                                       \
         half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                                \
@@ -306,6 +318,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         __syncthreads();
     }
     int tz = 0;
+    unsigned sat_ = 0;  // halo elements that left the f16 range (counted once per staging; halos overlap between tiles)
     F16X3_DMA_W(c_begin, 0, 0);
     F16X3_LOAD_X(c_begin);
     F16X3_WRITE_X(c_begin);
@@ -455,6 +468,12 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #undef F16X3_WRITE_X
 #undef F16X3_PUT
 #undef F16X3_DMA_W
+    if (__builtin_amdgcn_ballot_w64(sat_ != 0) != 0) {  // never taken in normal operation
+        unsigned tot = sat_;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft, 64);
+        if (lane == 0) atomicAdd(&g_f16x3_saturated, (unsigned long long)tot);
+    }
     PROF_FLUSH
 }
 
@@ -549,3 +568,20 @@ extern "C" int mphip_debug_f16x3_profile(unsigned long long *out8, int reset) {
     return 0;
 }
 #endif
+
+extern "C" int mphip_f16x3_saturation_count(unsigned long long *count, int reset) {
+    // synchronous (copies from the device): a diagnostic, not part of the stream-ordered path
+    MPHIP_REQUIRE(count, "f16x3_saturation_count: null pointer");
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(mphip::g_f16x3_saturated), sizeof(unsigned long long)) != hipSuccess) {
+        mphip::set_error("f16x3_saturation_count: hipMemcpyFromSymbol failed");
+        return MPHIP_ELAUNCH;
+    }
+    if (reset) {
+        const unsigned long long z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mphip::g_f16x3_saturated), &z, sizeof(z)) != hipSuccess) {
+            mphip::set_error("f16x3_saturation_count: hipMemcpyToSymbol failed");
+            return MPHIP_ELAUNCH;
+        }
+    }
+    return MPHIP_OK;
+}

@@ -175,6 +175,15 @@ def get_conv_precision() -> int:
     return _default_precision
 
 
+def f16x3_saturation_count(reset: bool = False) -> int:
+    """Elements the f16x3 conv kernels clamped (|x| >= 4062 forward) since the last reset — 0 unless an activation left
+    the range the split-f16 arithmetic covers, in which case those results are wrong: use set_conv_precision('fp32').
+    Synchronises the device (a diagnostic, not for the hot loop)."""
+    c = ctypes.c_ulonglong(0)
+    _lib.check(_lib.load().mphip_f16x3_saturation_count(ctypes.byref(c), int(reset)), "mphip_f16x3_saturation_count")
+    return int(c.value)
+
+
 class PackedConv:
     """One Conv3d / 1x1 Conv2d: OIDHW fp32 weight + bias, packed lazily per precision into the
     kernel layouts described in include/mphip.h."""

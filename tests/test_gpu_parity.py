@@ -512,6 +512,23 @@ def test_errors_are_loud(ops, M, dev):
         hot(**bad)                                       # model.py:1157 shape assert is preserved
 
 
+def test_f16x3_range_guard(ops, dev):
+    """Activations beyond the split-f16 range are clamped (finite, wrong) — and counted, so a caller can tell."""
+    x = R.seeded_tensor((1, 96, 4, 8, 16), 831, scale=1.7)
+    pc = ops.PackedConv(R.seeded_tensor((96, 96, 3, 3, 3), 832, scale=0.02).to(dev), None)
+    ops.f16x3_saturation_count(reset=True)
+    ops.conv3d(x.to(dev), pc, precision=1)
+    assert ops.f16x3_saturation_count() == 0
+    big = x.clone()
+    big[0, 5, 2, 3, 7] = 5000.0
+    y = ops.conv3d(big.to(dev), pc, precision=1)
+    assert torch.isfinite(y).all()
+    assert ops.f16x3_saturation_count(reset=True) >= 1
+    assert ops.f16x3_saturation_count() == 0
+    want = F.conv3d(big, pc.weight.cpu(), None, padding=1)
+    assert maxabs(ops.conv3d(big.to(dev), pc, precision=0), want) < 1e-3     # the exact kernel has no such limit
+
+
 def test_c_abi_from_plain_c(c_abi_exe):
     """tests/c_abi/c_abi_smoke.c: a C99 program (gcc; HIP runtime for memory, no Python/torch) drives libmphip.so through
     include/mphip.h — conv + pool vs host references computed in the C file, and the error-code convention."""
