@@ -567,7 +567,8 @@ namespace mphip {
 // accumulated in an LDS image of that box (ds_add_f32) and flushed with ONE global atomic per box element, in
 // coalesced rows — ~1.7 global atomics per output value instead of 8 scattered ones.  (Tried on top, both without gain:
 // explicit ds_add_f32 instead of flat atomics, +-0 %; handing x1 contributions to the x-neighbour lane by DPP to halve the
-// LDS atomics, -20 %: the LDS atomics are not what bounds this kernel.)  A box that does not fit
+// LDS atomics, -20 %; storing the box image to a per-tile scratch slot and summing covering boxes per dv element in a second
+// pass instead of the atomic flush, -60 %, and still not bitwise reproducible because the ds_add_f32 order varies.)  A box that does not fit
 // (wild field) falls back to direct global atomics for that tile.
 constexpr int WB_CH = 8;
 constexpr int WB_LDS = 16384;  // floats: 64 KB of accumulation image
