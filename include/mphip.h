@@ -14,7 +14,8 @@
  *  - Tensors are float32, contiguous, NCDHW (N,C,D,H,W), exactly the layout the reference's
  *    modules exchange (model.py:271 defines the volume layout: channel c*16+d -> (c,d)).
  *  - Every function returns 0 on success or a negative MPHIP_E* code, never throws, never
- *    allocates device memory, never synchronises the stream.  Work is stream-ordered;
+ *    allocates device memory, never synchronises the stream (the one diagnostic that does,
+ *    mphip_f16x3_saturation_count, says so).  Work is stream-ordered;
  *    borrowed pointers must stay valid until the stream reaches the end of the call's work.
  *    mphip_last_error() returns a thread-local message for the last failing call.
  *  - Scratch memory is caller-supplied: query with the matching *_workspace_bytes().

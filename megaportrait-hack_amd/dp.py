@@ -4,7 +4,7 @@ The hot slice has no cross-frame operation (GroupNorm is per sample, model.py:11
 inference needs NO data-path collective: each rank runs its contiguous slice of the batch and
 keeps its outputs.  `all_gather_frames` exists for callers that want the full
 result on every rank (and for the world_size-2 gloo tests); it is not used by bench.py.
-Training-time gradient all-reduce over RCCL is the next scope row.
+Training-time gradient averaging over RCCL lives in training.py (allreduce_gradients / train_step).
 """
 from __future__ import annotations
 

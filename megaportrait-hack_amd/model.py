@@ -332,7 +332,7 @@ class G3d(nn.Module):
 
 
 class Eapp3DTail(nn.Module):
-    """Next scope row: the 3D tail of Eapp, model.py:217-226 + 271-290.  Attribute names are
+    """Scope row f1: the 3D tail of Eapp, model.py:217-226 + 271-290.  Attribute names are
     the reference Eapp's, so `appearanceEncoder.resblock3D_*` checkpoint keys load into this module directly.
     The reference assigns `resblock3D_96_2` twice (model.py:218,225): five blocks exist, one is applied twice."""
 
@@ -357,7 +357,7 @@ class Eapp3DTail(nn.Module):
 
 
 class G2dHead(nn.Module):
-    """Next scope row: the entry of G2d, model.py:718-719 + 756-757 — `reshape` Conv2d(96,1536,1)
+    """Scope row f3: the entry of G2d, model.py:718-719 + 756-757 — `reshape` Conv2d(96,1536,1)
     followed directly by `conv1x1` Conv2d(1536,512,1).  There is no nonlinearity between them, so at inference the two
     collapse into ONE 96->512 product (W = W2 @ W1, b = W2 @ b1 + b2): 19x fewer FLOPs and the 25 MB/frame 1536-channel
     intermediate never exists.  Attribute names are G2d's, so `G2d.reshape.*` / `G2d.conv1x1.*` checkpoint keys load
