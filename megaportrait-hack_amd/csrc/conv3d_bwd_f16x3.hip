@@ -13,6 +13,11 @@
 // 27 taps = 9 (kd,kh) rows: wave w owns row w (3 kw x 3 co-tiles = 9 accumulators); row 8 is spread over waves
 // 0..2 (one co-tile each) so the four SIMDs carry 21/21/21/18 MFMA units instead of 27/18/18/18.
 // Partial sums go to slab[blockIdx.z]; the ordered slab reduce makes the result deterministic.
+// Staging goes through registers between two barriers (40 % of the kernel's time, not overlapped with the MFMAs: the
+// accumulators leave no registers for a prefetch).  An asynchronous variant was built and measured — next tile's raw fp32
+// rows by LDS-DMA during the MFMAs, then an LDS->LDS split pass, 1x8x8 tiles so both copies fit in 138 KB — and was 35 %
+// SLOWER (0.82 vs 0.60 ms on the full-resolution layer): the conversion pass with its 2-byte LDS writes and the doubled
+// barrier / halo count of the smaller tile cost more than the hidden latency.
 #include "mphip_common.h"
 #include "mphip_conv.h"
 
