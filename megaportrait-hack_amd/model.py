@@ -419,6 +419,8 @@ class GbaseHotSlice(nn.Module):
 
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
+        if vs.shape[0] == 0:  # an empty frame shard (dp.shard_inputs with more ranks than frames): nothing to launch
+            return vs.new_zeros((0, vs.shape[1]) + tuple(vs.shape[3:]))
         main = torch.cuda.current_stream(vs.device)
         train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
         # training: one stream (autograd replays each op's backward on its forward stream; the overlap is an inference trick)

@@ -512,6 +512,14 @@ def test_errors_are_loud(ops, M, dev):
         hot(**bad)                                       # model.py:1157 shape assert is preserved
 
 
+def test_empty_frame_shard(hot, dev):
+    """More ranks than frames: a rank's shard is empty; the slice returns an empty projection instead of launching."""
+    inp = {k: v.to(dev)[:0] for k, v in R.seeded_hot_inputs(1, 3).items()}
+    with torch.no_grad():
+        out = hot(**inp)
+    assert out.shape == (0, 96, 64, 64)
+
+
 def test_f16x3_range_guard(ops, dev):
     """Activations beyond the split-f16 range are clamped (finite, wrong) — and counted, so a caller can tell."""
     x = R.seeded_tensor((1, 96, 4, 8, 16), 831, scale=1.7)
