@@ -72,11 +72,53 @@ def make_g2d_head():
     print("g2d_head.npz", os.path.getsize(os.path.join(OUT, "g2d_head.npz")))
 
 
+def make_backward():
+    """(11) row f2: gradients autograd produces THROUGH THE REFERENCE'S OWN MODULES (imported), for seeded inputs and
+    weights — pins the backward oracle (torch CPU autograd of oracle/hotpath_ref.py) the GPU backward tests compare with.
+      * apply_warping_field: d/dv and d/dfield for v [1,8,8,16,16], a wide field
+      * WarpGeneratorS2C: d/d(R,t,z,e) and two parameter gradients
+      * G3d on 96x8x8x8: d/dx and the gradients of the first and last conv weights / one GroupNorm"""
+    m = load_reference_model()
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    sd = R.seeded_gbase_hot_state_dict(WEIGHT_SEED)
+    out = {}
+    # warp
+    v = R.seeded_tensor((1, 8, 8, 16, 16), 130, scale=1.7).requires_grad_(True)
+    f = ((R.seeded_tensor((1, 3, 64, 64, 64), 131) + 1.0) * torch.tensor([9.0, 9.0, 5.0]).view(1, 3, 1, 1, 1) - 1.5).requires_grad_(True)
+    g = R.seeded_tensor((1, 8, 8, 16, 16), 132)
+    m.apply_warping_field(v, f).backward(g)
+    out["warp_dv"], out["warp_dfield_s2"] = v.grad.numpy(), f.grad[:, :, ::2, ::2, ::2].contiguous().numpy()
+    out["warp_dfield_sum"] = f.grad.double().sum(dim=(2, 3, 4)).numpy()
+    # generator
+    s2c = _load(m.WarpGeneratorS2C(512), sd, "warp_generator_s2c.").train()
+    inp = {k: t.clone().requires_grad_(True) for k, t in R.seeded_hot_inputs(1, INPUT_SEED).items() if k in ("Rs", "ts", "zs", "es")}
+    w = s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
+    w.backward(R.seeded_tensor(tuple(w.shape), 133))
+    for k in inp:
+        out["s2c_d" + k] = inp[k].grad.numpy()
+    out["s2c_dgamma_s8"] = s2c.adaptive_matrix_gamma.grad[::8, ::8].contiguous().numpy()
+    out["s2c_dconv3x3x3"] = s2c.flowfield.conv3x3x3.weight.grad.numpy()
+    # G3d
+    g3d = _load(m.G3d(96), sd, "G3d.").train()
+    x = R.seeded_tensor((1, 96, 8, 8, 8), 134, scale=1.7).requires_grad_(True)
+    y = g3d(x)
+    y.backward(R.seeded_tensor(tuple(y.shape), 135))
+    out["g3d_dx"] = x.grad.numpy()
+    out["g3d_dfirst_s4"] = g3d.downsampling[0].conv1.weight.grad[::4, ::4].contiguous().numpy()
+    out["g3d_dfinal_s4"] = g3d.final_conv.weight.grad[::4, ::4].contiguous().numpy()
+    out["g3d_dgn"] = g3d.downsampling[2].gn1.weight.grad.numpy()
+    np.savez(os.path.join(OUT, "backward.npz"), **out)
+    print("backward.npz", os.path.getsize(os.path.join(OUT, "backward.npz")))
+
+
 def main():
     import sys
 
     if "--only-g2d-head" in sys.argv:
         return make_g2d_head()
+    if "--only-backward" in sys.argv:
+        return make_backward()
     capture_tables()
     m = load_reference_model()
     os.makedirs(OUT, exist_ok=True)
@@ -181,6 +223,7 @@ def main():
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     make_g2d_head()
+    make_backward()
     for fn in sorted(os.listdir(OUT)):
         print(fn, os.path.getsize(os.path.join(OUT, fn)))
 

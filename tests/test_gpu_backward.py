@@ -422,3 +422,49 @@ def test_distributed_data_parallel_wraps_the_hot_slice(dev, M):
         assert ref["warp_generator_s2c.adaptive_matrix_beta"] is None
     finally:
         dist.destroy_process_group()
+
+
+def test_backward_vs_reference_gradient_goldens(dev, M):
+    """HIP backward vs tests/golden/backward.npz: gradients that torch autograd computed through the REFERENCE's own
+    modules (oracle/make_golden.py::make_backward) for the warp, a whole warp generator and G3d."""
+    import os
+
+    import numpy as np
+
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "backward.npz"))
+    sd = R.seeded_gbase_hot_state_dict(7)
+
+    def check(name, got, tol):
+        want = torch.as_tensor(g[name]).double()
+        err = (got.detach().cpu().double() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert err < tol, (name, err)
+
+    # apply_warping_field (model.py:1028-1065)
+    v = R.seeded_tensor((1, 8, 8, 16, 16), 130, scale=1.7).to(dev).requires_grad_(True)
+    f = ((R.seeded_tensor((1, 3, 64, 64, 64), 131) + 1.0) * torch.tensor([9.0, 9.0, 5.0]).view(1, 3, 1, 1, 1) - 1.5).to(dev).requires_grad_(True)
+    M.apply_warping_field(v, f).backward(R.seeded_tensor((1, 8, 8, 16, 16), 132).to(dev))
+    check("warp_dv", v.grad, 1e-5)
+    check("warp_dfield_s2", f.grad[:, :, ::2, ::2, ::2], 1e-4)
+    check("warp_dfield_sum", f.grad.double().sum(dim=(2, 3, 4)), 1e-4)
+    # WarpGeneratorS2C (model.py:927-975)
+    gen = M.WarpGeneratorS2C(num_channels=512)
+    M.load_hot_state_dict(gen, {k[len("warp_generator_s2c."):]: t for k, t in sd.items() if k.startswith("warp_generator_s2c.")})
+    gen = gen.to(dev).train()
+    inp = {k: t.to(dev).requires_grad_(True) for k, t in R.seeded_hot_inputs(1, 3).items() if k in ("Rs", "ts", "zs", "es")}
+    w = gen(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
+    w.backward(R.seeded_tensor(tuple(w.shape), 133).to(dev))
+    for k in inp:
+        check("s2c_d" + k, inp[k].grad, 1e-3)
+    check("s2c_dgamma_s8", gen.adaptive_matrix_gamma.grad[::8, ::8], 1e-3)
+    check("s2c_dconv3x3x3", gen.flowfield.conv3x3x3.weight.grad, 1e-3)
+    # G3d (model.py:571-597)
+    g3d = M.G3d(96)
+    g3d.load_state_dict({k[len("G3d."):]: t for k, t in sd.items() if k.startswith("G3d.")})
+    g3d = g3d.to(dev).train()
+    x = R.seeded_tensor((1, 96, 8, 8, 8), 134, scale=1.7).to(dev).requires_grad_(True)
+    y = g3d(x)
+    y.backward(R.seeded_tensor(tuple(y.shape), 135).to(dev))
+    check("g3d_dx", x.grad, 1e-3)
+    check("g3d_dfirst_s4", g3d.downsampling[0].conv1.weight.grad[::4, ::4], 1e-3)
+    check("g3d_dfinal_s4", g3d.final_conv.weight.grad[::4, ::4], 1e-3)
+    check("g3d_dgn", g3d.downsampling[2].gn1.weight.grad, 1e-3)

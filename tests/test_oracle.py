@@ -163,3 +163,41 @@ def test_restatement_equals_reference_modules(sd):
         vc = m.apply_warping_field(inp["vs"], w)
         assert torch.equal(vc, R.apply_warping_field(inp["vs"], w))
         assert torch.equal(g3d(vc.clone()), R.g3d(vc, sd))
+
+
+def _backward_cases(sd):
+    """(name, gradient tensor) pairs of the oracle's autograd for the cases of tests/golden/backward.npz
+    (oracle/make_golden.py::make_backward ran the same inputs through the REFERENCE's modules)."""
+    out = {}
+    v = R.seeded_tensor((1, 8, 8, 16, 16), 130, scale=1.7).requires_grad_(True)
+    f = ((R.seeded_tensor((1, 3, 64, 64, 64), 131) + 1.0) * torch.tensor([9.0, 9.0, 5.0]).view(1, 3, 1, 1, 1) - 1.5).requires_grad_(True)
+    R.apply_warping_field(v, f).backward(R.seeded_tensor((1, 8, 8, 16, 16), 132))
+    out["warp_dv"], out["warp_dfield_s2"] = v.grad, f.grad[:, :, ::2, ::2, ::2]
+    out["warp_dfield_sum"] = f.grad.double().sum(dim=(2, 3, 4))
+    inp = {k: t.clone().requires_grad_(True) for k, t in R.seeded_hot_inputs(1, INPUT_SEED).items() if k in ("Rs", "ts", "zs", "es")}
+    p = {k: t.clone().requires_grad_(True) for k, t in sd.items()}
+    w = R.warp_generator(inp["Rs"], inp["ts"], inp["zs"], inp["es"], p, "warp_generator_s2c.", invert=True)
+    w.backward(R.seeded_tensor(tuple(w.shape), 133))
+    for k in inp:
+        out["s2c_d" + k] = inp[k].grad
+    out["s2c_dgamma_s8"] = p["warp_generator_s2c.adaptive_matrix_gamma"].grad[::8, ::8]
+    out["s2c_dconv3x3x3"] = p["warp_generator_s2c.flowfield.conv3x3x3.weight"].grad
+    x = R.seeded_tensor((1, 96, 8, 8, 8), 134, scale=1.7).requires_grad_(True)
+    p = {k: t.clone().requires_grad_(True) for k, t in sd.items()}
+    y = R.g3d(x, p)
+    y.backward(R.seeded_tensor(tuple(y.shape), 135))
+    out["g3d_dx"] = x.grad
+    out["g3d_dfirst_s4"] = p["G3d.downsampling.0.conv1.weight"].grad[::4, ::4]
+    out["g3d_dfinal_s4"] = p["G3d.final_conv.weight"].grad[::4, ::4]
+    out["g3d_dgn"] = p["G3d.downsampling.2.gn1.weight"].grad
+    return out
+
+
+def test_backward_oracle_pinned_by_reference_gradients(sd):
+    """The backward oracle (torch CPU autograd of this restatement) reproduces the gradients autograd computed through
+    the reference's own modules (tests/golden/backward.npz)."""
+    g = np.load(os.path.join(GOLD, "backward.npz"))
+    for name, t in _backward_cases(sd).items():
+        want = torch.as_tensor(g[name]).double()
+        err = (t.detach().double() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
+        assert err < 1e-5, (name, err)
