@@ -9,6 +9,7 @@ No torch eager / CPU fallback: a shape the kernels do not cover raises.
 from __future__ import annotations
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import ops
 
@@ -44,6 +45,7 @@ class Conv3dFn(torch.autograd.Function):
         return ops.conv3d(x, fwd_pack)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
@@ -78,6 +80,7 @@ class GroupNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dy):
         want_res = ctx.has_res and ctx.needs_input_grad[5]
@@ -98,6 +101,7 @@ class AvgPool2Fn(torch.autograd.Function):
         return ops.avgpool2(x.contiguous())
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dout):
         return ops.avgpool2_bwd(dout.contiguous())
@@ -110,6 +114,7 @@ class UpsampleTrilinear2Fn(torch.autograd.Function):
         return ops.upsample_trilinear2(x.contiguous())
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dout):
         return ops.upsample_trilinear2_bwd(dout.contiguous())
@@ -145,6 +150,7 @@ class WarpVolumeFn(torch.autograd.Function):
         return ops.warp_volume_dsum(v, field) if dsum else ops.warp_volume(v, field)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dout):
         v, field = ctx.saved_tensors
@@ -162,6 +168,7 @@ class WarpFieldComposeFn(torch.autograd.Function):
         return ops.warp_field_compose(theta, em, grid_size)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dw):
         dtheta, dem = ops.warp_field_compose_bwd(dw.contiguous(), ctx.em_shape, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
@@ -179,6 +186,7 @@ class RtThetaFn(torch.autograd.Function):
         return ops.rt_theta(rotation, translation, invert)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dtheta):
         rotation, translation = ctx.saved_tensors
@@ -196,6 +204,7 @@ class UpsampleNearestFn(torch.autograd.Function):
         return ops.upsample_nearest(x.contiguous(), ctx.scale)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dout):
         return ops.upsample_nearest_bwd(dout.contiguous(), ctx.scale), None
@@ -211,6 +220,7 @@ class AddMatmulFn(torch.autograd.Function):
         return ops.add_matmul(z, e, gamma)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, ds):
         z, e, gamma = ctx.saved_tensors
@@ -230,6 +240,7 @@ class Conv1x1OnVectorFn(torch.autograd.Function):
         return ops.add_matmul(s, None, w_kn, bias)
 
     @staticmethod
+    @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dx):
         s, weight = ctx.saved_tensors
