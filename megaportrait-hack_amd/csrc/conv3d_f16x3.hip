@@ -490,11 +490,13 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     F16x3Plan p;
     p.td = D % 4 == 0 ? 4 : 2;
     // variant: 0 = (td,8,8) tile, 256 voxels per workgroup; 1 = (4,8,16) tile, 512 voxels per workgroup (halves the
-    // weight stream per MFMA) — only when that still gives every CU two workgroups' worth of tiles.
+    // weight stream per MFMA) — whenever that still gives every CU a workgroup (the persistent grid needs no second one;
+    // measured at B=8: 192->192 @8x32x32 0.371 vs 0.420 ms, 96->192 0.181 vs 0.194 ms; below one workgroup per CU
+    // the smaller tile wins: 192->96 0.203 vs 0.214 ms).
     static const char *force = getenv("MPHIP_F16X3_TILE");
     const int cot = Co / F16X3_COT;
     const long tiles1 = (p.td == 4 && W % 16 == 0) ? (long)N * (D / 4) * (H / 8) * (W / 16) : 0;
-    p.variant = (tiles1 * cot >= 512) ? 1 : 0;
+    p.variant = (tiles1 * cot >= 256) ? 1 : 0;
     if (force && force[0] == '0') p.variant = 0;
     if (force && force[0] == '1' && tiles1) p.variant = 1;
     const long tiles = p.variant ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
