@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_e
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p, int tiles_total) {
+                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware) {
     constexpr int MT = 3, KC = F16X3_KC;
     // activation scale: the fixed X_SCALE for forward activations; a per-tensor power of two from mphip_grad_prep
     // when the input is a gradient (bwd-data), whose magnitude is arbitrary
@@ -175,7 +175,10 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
         n = bid / tiles_d;
         d0 = td * TD; h0 = th * TH; w0 = tw * TW;
     };
-    decode_tile(blockIdx.x);
+    // XCD-aware start: workgroup ids go round-robin over the 8 XCDs, so consecutive ids get consecutive RANGES of tiles —
+    // neighbouring tiles (which share halo rows) then run on the same XCD and meet in its L2
+    const int tile0 = xcd_aware ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    decode_tile(tile0);
     const int cot = blockIdx.y;
     const int nchunks = Ci / KC;
     const int c_begin = blockIdx.z * chunks_per_split;
@@ -325,7 +328,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     __syncthreads();
     PROF_ADD(0)
     int wb = 0;
-  for (int tile_id = blockIdx.x; tile_id < tiles_total; tile_id += gridDim.x) {
+  for (int tile_id = tile0; tile_id < tiles_total; tile_id += gridDim.x) {
     const int en = n, ed0 = d0, eh0 = h0, ew0 = w0;  // this tile's coordinates (the staging variables move on to the next tile)
     const bool has_next = tile_id + (int)gridDim.x < tiles_total;
     asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps per-tile-invariant index math / bias loads from being hoisted into registers
@@ -544,17 +547,18 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     if (gx < 1) gx = 1;
     if (gx > tiles_total || getenv("MPHIP_F16X3_NO_PERSIST")) gx = tiles_total;
     dim3 grid((unsigned)gx, p.grid.y, p.grid.z);
+    static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');  // dev switch for same-box A/B
     // (two-slab groups for the 512-voxel tile — 5 instead of 9 barriers per chunk, 147 KB of LDS — were tried: the
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
     if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
     else if (p.td == 4)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
     else
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
     return check_launch("conv3d_fwd(f16x3)");
 }
 
