@@ -56,7 +56,60 @@ def parse():
                     help="infer (default) = the graded metric, BASELINE config 2; train = one training step of the hot slice "
                          "(forward + backward + SGD, BASELINE config 3's per-GPU shard: --batch 4) with the RCCL gradient "
                          "all-reduce when --gpus > 1 — a side measurement, separate JSON line")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="with --gpus N > 1 and no torchrun environment: print the torch.distributed.run command the "
+                         "self-launcher would execute (one JSON line) and exit")
+    ap.add_argument("--stub-worker", action="store_true",
+                    help="launcher self-test (CPU, gloo): every rank joins the process group, rank 0 prints "
+                         '{"stub_worker": true, "ranks": N}; no GPU work')
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the side measurements on the line (fp32_exact, roofline_hbm, end_to_end)")
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a torchrun environment: re-executes itself under torch.distributed.run
+    (one rank per GPU, rendezvous on 127.0.0.1), exactly the command the driver uses for N > 1.  Rank 0's JSON line
+    passes through on stdout; the exit code is the launcher's."""
+    import subprocess
+
+    port = int(os.environ.get("MASTER_PORT", 0)) or _free_port()
+    argv = [a for a in sys.argv[1:] if a != "--dry-launch"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    if args.dry_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    if not args.stub_worker:
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def stub_worker(args, rank, world):
+    """CPU self-test of the launch path: rendezvous + one all-reduce over gloo, rank 0 reports."""
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"stub_worker": True, "ranks": dist.get_world_size(), "n_gpus": args.gpus, "sum": t.item()}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 class DominantKernelTimer:
@@ -152,6 +205,57 @@ def cpu_baseline(frames):
                       f"(ATen CPU fp32, {threads} threads), {dt:.1f} s"}
 
 
+def end_to_end(dev, B, steps=8, warmup=3):
+    """Gbase.forward(xs, xd) -> (image, pyramids) on synthetic 512x512 RGB pairs (xs, xd ~ U[0,1)): the
+    full generator — Eapp / Emtn / G2d bodies on PyTorch-ROCm (MIOpen), the 3D tail, the hot slice and G2d's head on
+    the HIP kernels.  Random-init weights (gbase.Gbase builds offline).  Side measurement: the hot slice is ~10 % of
+    the generator's FLOPs, the 2D convs dominate."""
+    from megaportrait_hack_amd import gbase
+
+    torch.manual_seed(20240501)
+    g = gbase.Gbase().to(dev).eval()
+    gen = torch.Generator(device="cpu").manual_seed(20240501)
+    xs = torch.rand(B, 3, 512, 512, generator=gen).to(dev)
+    xd = torch.rand(B, 3, 512, 512, generator=gen).to(dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            img, pyr = g(xs, xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            img, pyr = g(xs, xd)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    assert img.shape == (B, 3, 512, 512) and torch.isfinite(img).all()
+    del g
+    torch.cuda.empty_cache()
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "batch": B, "steps": steps,
+            "workload": "gbase.Gbase.forward(xs, xd) -> (image [B,3,512,512], pyramids), xs/xd ~ U[0,1), random init; "
+                        "2D encoders/decoder on PyTorch-ROCm (MIOpen fp32), 3D tail + hot slice + G2d head on libmphip"}
+
+
+def fp32_exact(hot, inp, B, steps=10, warmup=2):
+    """The same hot slice with every conv on the exact fp32 MFMA kernels (precision 0) — beside the default f16x3 line."""
+    from megaportrait_hack_amd import ops
+
+    old = ops.get_conv_precision()
+    ops.set_conv_precision("fp32")
+    try:
+        with torch.no_grad():
+            for _ in range(warmup):
+                hot(**inp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                hot(**inp)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        ops.set_conv_precision(old)
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
+
+
 def train_mode(args, rank, world, dev, dist):
     """Side measurement (not the graded metric): training step of the hot slice, frames sharded over ranks, gradients
     averaged with bucketed RCCL all-reduces (training.train_step); --graph 1 replays the step as one hipGraph (1 GPU)."""
@@ -217,9 +321,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_ranks(args)          # self-launch: N ranks under torch.distributed.run
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.stub_worker:
+        return stub_worker(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -279,10 +386,13 @@ def main():
         sync_all()
         dom.active = not args.graph
         lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 and not args.graph else None
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if lanes is None else None
         t0 = time.perf_counter()
         if lanes is None:
-            for _ in range(args.steps):
+            marks[0].record()
+            for i in range(args.steps):
                 out = step(**inp)
+                marks[i + 1].record()      # device-side step boundaries (an event record, no sync): the spread of the K steps
         else:
             for lane in lanes:
                 lane.wait_stream(torch.cuda.current_stream())
@@ -301,6 +411,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])) if marks else []
     dom_ms = dom.mean_ms()
     dom_flops = 2.0 * B * 16 * 64 * 64 * 96 * 96 * 27
     line = None
@@ -324,6 +435,9 @@ def main():
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": f"dp{world} (frame shards, no collective)",
                        "launch": "hipGraph replay of the captured step" if args.graph else "eager stream launches",
                        "batches_in_flight": 1 if (args.graph or args.inflight < 2) else args.inflight},
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "step_ms": ({"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)}
+                        if step_ms else None),
             "hot_slice_tflops": round(fps * FRAME_FLOPS / 1e12, 2),
             "hot_slice_vs_f32_mfma_peak": round(fps * FRAME_FLOPS / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "hot_slice_layerwise_GBps": round(fps * FRAME_BYTES / 1e9, 1),
@@ -338,6 +452,11 @@ def main():
                                   f"{round(achieved / PEAK_F32_MFMA_TFLOPS, 2)}x") if f16x3 else
                                  "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         }
+        if world == 1 and not args.no_extras:
+            ops.set_conv_hook(None)
+            if f16x3:
+                line["fp32_exact"] = fp32_exact(hot, inp, B)
+            line["end_to_end"] = end_to_end(dev, B)
         if world == 1 and args.torch_gpu_baseline:
             line["torch_rocm_baseline"] = torch_rocm_baseline(dev, B)
         if world == 1 and not args.no_cpu_baseline:
@@ -349,4 +468,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -79,6 +79,12 @@ int mphip_warp_volume(const float *v, const float *field, const float *lin_d, co
 int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
                            const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
                            int fH, int fW, void *workspace, size_t workspace_bytes, void *stream);
+/* Cross-reenactment (BASELINE config 5, the reference recomputes G3d per pair: inference.py:35 / model.py:1160-1171):
+ * ONE source volume v [1,C,D,H,W] warped by B driver fields [B,3,fD,fH,fW] -> out [B,C,H,W]; the volume is read in
+ * place (no B-fold expanded copy).  Same workspace as mphip_warp_volume_dsum.                          */
+int mphip_warp_volume_dsum_shared(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                                  const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
+                                  int fH, int fW, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ K4/K5  Conv3d k=3 / k=1
  * Replaces nn.Conv3d(Ci,Co,3,padding=1) (model.py:505,507,591,374-375,458) and

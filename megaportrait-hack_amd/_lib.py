@@ -28,6 +28,7 @@ SIGNATURES = {
     "mphip_warp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_warp_volume_dsum_shared": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_conv3d_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mphip_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),

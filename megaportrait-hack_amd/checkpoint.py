@@ -119,3 +119,24 @@ def load_training_checkpoint(path, model_G: torch.nn.Module, model_D: Optional[t
     if optimizer_D is not None and "optimizer_D_state_dict" in ck:
         optimizer_D.load_state_dict(ck["optimizer_D_state_dict"])
     return int(ck.get("epoch", -1)) + 1
+
+
+def load_gbase(gbase: torch.nn.Module, checkpoint, strict: bool = False, map_location="cpu") -> Tuple[list, list]:
+    """inference.py:59-60 for the whole generator: `Gbase.load_state_dict(torch.load(path), strict=False)`, accepting
+    the raw layout (train.py:429 `Gbase.pth`) and the wrapped training checkpoint (train.py:348-355) alike.
+    Returns (missing, unexpected).  With strict=True anything missing except the adaptive_matrix_* keys of a
+    GPU-built reference checkpoint (model.py:934-935) raises; shape mismatches always raise."""
+    obj = torch.load(checkpoint, map_location=map_location) if isinstance(checkpoint, (str, os.PathLike)) else checkpoint
+    sd = generator_state_dict(obj)
+    own = gbase.state_dict()
+    usable = {k: v for k, v in sd.items() if k in own}
+    bad = [k for k, v in usable.items() if tuple(v.shape) != tuple(own[k].shape)]
+    if bad:
+        raise ValueError(f"shape mismatch for {bad[0]}: checkpoint {tuple(usable[bad[0]].shape)} vs model {tuple(own[bad[0]].shape)}")
+    missing = [k for k in own if k not in usable]
+    unexpected = [k for k in sd if k not in own]
+    hard = [k for k in missing if "adaptive_matrix_" not in k]
+    if strict and hard:
+        raise KeyError(f"checkpoint lacks {len(hard)} Gbase keys, e.g. {hard[:4]}")
+    gbase.load_state_dict(usable, strict=False)
+    return missing, unexpected

@@ -379,7 +379,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
 template <int CPB>
 __global__ void __launch_bounds__(256)
 warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
-                        int B, int C, int D, int H, int W) {
+                        int B, int C, int D, int H, int W, size_t v_frame_stride /* floats; 0 = one shared source volume */) {
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
@@ -405,7 +405,7 @@ warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ c
     const int bvol = bx.ex * bx.ey * bx.ez;
     const int cs_pad = lds_pitch_for(cs);
     const bool staged = bvol * cs_pad <= STAGE_FLOATS;  // block-uniform
-    const float *vb = v + (size_t)b * C * vol;
+    const float *vb = v + (size_t)b * v_frame_stride;
     if (staged) {
         stage_box(vb, lds, bx, c0, cs, cs_pad, H, W, vol);
         __syncthreads();
@@ -533,14 +533,14 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     return check_launch("warp_volume");
 }
 
-extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
-                                      const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
-                                      int fH, int fW, void *workspace, size_t workspace_bytes, void *stream) {
-    int rc = check_warp_args("warp_volume_dsum", v, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
+static int warp_volume_dsum_impl(const char *name, const float *v, size_t v_frame_stride, const float *field,
+                                 const float *lin_d, const float *lin_h, const float *lin_w, float *out, int B, int C, int D,
+                                 int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = check_warp_args(name, v, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
     if (rc) return rc;
     size_t need = mphip_warp_workspace_bytes(B, D, H, W);
     if (!workspace || workspace_bytes < need) {
-        set_error("warp_volume_dsum: workspace %zu bytes < required %zu", workspace_bytes, need);
+        set_error("%s: workspace %zu bytes < required %zu", name, workspace_bytes, need);
         return MPHIP_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -550,8 +550,22 @@ extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const 
     constexpr int CPB = 16;
     const int tiles = (H * W + 255) / 256;
     hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles), cdiv(C, CPB)), dim3(256), 0, s, v,
-                       coords, out, B, C, D, H, W);
-    return check_launch("warp_volume_dsum");
+                       coords, out, B, C, D, H, W, v_frame_stride);
+    return check_launch(name);
+}
+
+extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                                      const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
+                                      int fH, int fW, void *workspace, size_t workspace_bytes, void *stream) {
+    return warp_volume_dsum_impl("warp_volume_dsum", v, (size_t)C * D * H * W, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD,
+                                 fH, fW, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mphip_warp_volume_dsum_shared(const float *v, const float *field, const float *lin_d, const float *lin_h,
+                                             const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
+                                             int fH, int fW, void *workspace, size_t workspace_bytes, void *stream) {
+    return warp_volume_dsum_impl("warp_volume_dsum_shared", v, 0, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW,
+                                 workspace, workspace_bytes, stream);
 }
 
 // =====================================================================================================

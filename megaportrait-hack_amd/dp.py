@@ -75,5 +75,5 @@ def cross_reenact(hot, vs, es, Rs, ts, zs, Rd, td, zd, rank: int = 0, world: int
             j = min(e, i + chunk)
             n = j - i
             w_c2d = hot.warp_generator_c2d(Rd[i:j], td[i:j], zd[i:j], es.expand(n, -1).contiguous())
-            outs.append(ops.warp_volume_dsum(vc2d.expand(n, -1, -1, -1, -1).contiguous(), w_c2d))
+            outs.append(ops.warp_volume_dsum(vc2d, w_c2d))   # one shared source volume, n driver fields (no expanded copy)
     return torch.cat(outs, dim=0) if outs else None

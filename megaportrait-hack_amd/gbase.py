@@ -1,0 +1,83 @@
+"""`Gbase` — the orchestrator at the drop-in boundary (reference model.py:1127-1180).
+
+Same attribute names as the reference (`appearanceEncoder, motionEncoder, warp_generator_s2c, warp_generator_c2d, G3d,
+G2d, image_pyramid` — model.py:1130-1137) and therefore the same state-dict keys; `forward(xs, xd)` returns
+`(xhat_base [B,3,512,512], {'prediction_0.5': ..., 'prediction_0.25': ...})` like model.py:1180, so `train.py:194,283`
+(`pred, pyramids = Gbase(src, drv)`), `PairwiseTransferLoss` (model.py:2192-2214: sub-module calls) and a fixed
+`inference.py` drop in.
+
+Hot path (model.py:1151-1171) = the HIP kernels, through model._HotSliceRunner; Eapp's 3D tail and G2d's entry are the
+HIP rows f1/f3; everything else is PyTorch-ROCm (encoders2d.py, or whatever modules the caller injects).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import encoders2d as E
+from . import model as M
+
+
+class Gbase(M._HotSliceRunner, nn.Module):
+    """model.py:1127-1180.  `Gbase()` (no arguments, like the reference) builds this repo's own 2D modules with random
+    init — the reference's constructor downloads weights and calls `.cuda(0)`.  Pass
+    `appearanceEncoder` / `motionEncoder` / `G2d` / `image_pyramid` to inject other modules (any nn.Module with the
+    reference's forward signature)."""
+
+    def __init__(self, appearanceEncoder: Optional[nn.Module] = None, motionEncoder: Optional[nn.Module] = None,
+                 G2d: Optional[nn.Module] = None, image_pyramid: Optional[nn.Module] = None):
+        super().__init__()
+        self.appearanceEncoder = appearanceEncoder if appearanceEncoder is not None else E.Eapp()
+        self.motionEncoder = motionEncoder if motionEncoder is not None else E.Emtn()
+        self.warp_generator_s2c = M.WarpGeneratorS2C(num_channels=512)
+        self.warp_generator_c2d = M.WarpGeneratorC2D(num_channels=512)
+        self.G3d = M.G3d(in_channels=96)
+        self.G2d = G2d if G2d is not None else E.G2d(in_channels=96)
+        self.image_pyramid = image_pyramid if image_pyramid is not None else E.ImagePyramide(scales=[0.5, 0.25], num_channels=3)
+
+    def hot_slice(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool = True):
+        """model.py:1151-1171 on already-encoded inputs -> projected features [B,96,H,W] (what GbaseHotSlice computes)."""
+        return self._run(vs, es, Rs, ts, zs, Rd, td, zd, check_shape)
+
+    def encode(self, xs, xd):
+        """model.py:1141-1145: (vs, es, Rs, ts, zs, Rd, td, zd)."""
+        vs, es = self.appearanceEncoder(xs)
+        Rs, ts, zs = self.motionEncoder(xs)
+        Rd, td, zd = self.motionEncoder(xd)
+        return vs, es, Rs, ts, zs, Rd, td, zd
+
+    def forward(self, xs, xd):
+        vs, es, Rs, ts, zs, Rd, td, zd = self.encode(xs, xd)
+        vc2d_projected = self._run(vs, es, Rs, ts, zs, Rd, td, zd, True)   # asserts the 96x16x64x64 volume (model.py:1157,1168)
+        xhat_base = self.G2d(vc2d_projected)
+        return xhat_base, self.image_pyramid(xhat_base)
+
+    def forward_any_size(self, xs, xd):
+        """Same graph without the 512^2-only asserts (BASELINE config 1: 256x256 frames; small parity cases)."""
+        vs, es, Rs, ts, zs, Rd, td, zd = self.encode(xs, xd)
+        xhat_base = self.G2d(self._run(vs, es, Rs, ts, zs, Rd, td, zd, False))
+        return xhat_base, self.image_pyramid(xhat_base)
+
+    @torch.no_grad()
+    def reenact(self, xs, xd, chunk: int = 16, rank: int = 0, world: int = 1):
+        """BASELINE config 5: ONE source image x N driver frames -> images [n_local,3,H,W] of this rank's driver shard.
+        The source-side half (Eapp, Emtn(xs), S2C field, warp #1, G3d: model.py:1141-1160) runs once; per driver chunk
+        only Emtn(xd), the C2D field, the fused warp + depth sum and G2d run (model.py:1145,1163-1174).  Results equal
+        calling forward() on every (source, driver) pair."""
+        from . import dp, ops
+
+        if xs.shape[0] != 1:
+            raise ValueError("reenact expects a single source image [1,3,H,W]")
+        vs, es = self.appearanceEncoder(xs)
+        Rs, ts, zs = self.motionEncoder(xs)
+        vc2d = self.G3d(M.apply_warping_field(vs, self.warp_generator_s2c(Rs, ts, zs, es)))
+        b, e = dp.shard_range(xd.shape[0], rank, world)
+        outs = []
+        for i in range(b, e, chunk):
+            j = min(e, i + chunk)
+            Rd, td, zd = self.motionEncoder(xd[i:j])
+            w_c2d = self.warp_generator_c2d(Rd, td, zd, es.expand(j - i, -1).contiguous())
+            outs.append(self.G2d(ops.warp_volume_dsum(vc2d, w_c2d)))
+        return torch.cat(outs, dim=0) if outs else xs.new_zeros((0,) + tuple(xs.shape[1:]))

@@ -393,16 +393,9 @@ class G2dHead(nn.Module):
         return y.reshape(b, 512, h, w)
 
 
-class GbaseHotSlice(nn.Module):
-    """The slice of Gbase.forward between the 2D encoders and G2d (model.py:1151-1171), with the
-    reference's attribute names so a Gbase checkpoint's `warp_generator_s2c.*`,
-    `warp_generator_c2d.*` and `G3d.*` keys load unchanged."""
-
-    def __init__(self):
-        super().__init__()
-        self.warp_generator_s2c = WarpGeneratorS2C(num_channels=512)
-        self.warp_generator_c2d = WarpGeneratorC2D(num_channels=512)
-        self.G3d = G3d(in_channels=96)
+class _HotSliceRunner:
+    """model.py:1151-1171 over `self.warp_generator_s2c`, `self.warp_generator_c2d`, `self.G3d` — shared by
+    GbaseHotSlice (the slice alone) and gbase.Gbase (the orchestrator)."""
 
     # The C2D generator depends only on (Rd, td, zd, es): its ~25 small, latency-bound launches run on
     # a second HIP stream underneath G3d's MFMA-bound kernels instead of in front of the last warp.
@@ -455,6 +448,19 @@ class GbaseHotSlice(nn.Module):
         if train:
             return ag.WarpVolumeFn.apply(vc2d, w_c2d, True)
         return ops.warp_volume_dsum(vc2d, w_c2d)
+
+
+
+class GbaseHotSlice(_HotSliceRunner, nn.Module):
+    """The slice of Gbase.forward between the 2D encoders and G2d (model.py:1151-1171), with the
+    reference's attribute names so a Gbase checkpoint's `warp_generator_s2c.*`,
+    `warp_generator_c2d.*` and `G3d.*` keys load unchanged."""
+
+    def __init__(self):
+        super().__init__()
+        self.warp_generator_s2c = WarpGeneratorS2C(num_channels=512)
+        self.warp_generator_c2d = WarpGeneratorC2D(num_channels=512)
+        self.G3d = G3d(in_channels=96)
 
     def forward(self, vs, es, Rs, ts, zs, Rd, td, zd):
         return self._run(vs, es, Rs, ts, zs, Rd, td, zd, True)

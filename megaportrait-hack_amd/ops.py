@@ -142,15 +142,18 @@ def warp_volume(v: torch.Tensor, field: torch.Tensor, return_coords: bool = Fals
 def warp_volume_dsum(v: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
     v = _req(v, "v")
     field = _req(field, "warp_field")
-    if v.dim() != 5 or field.dim() != 5 or field.shape[0] != v.shape[0] or field.shape[1] != 3:
+    if v.dim() != 5 or field.dim() != 5 or (field.shape[0] != v.shape[0] and v.shape[0] != 1) or field.shape[1] != 3:
         raise RuntimeError(f"warp_volume_dsum: bad shapes v={tuple(v.shape)} field={tuple(field.shape)}")
-    b, c, d, h, w = v.shape
+    _, c, d, h, w = v.shape
+    b = field.shape[0]
     out = torch.empty((b, c, h, w), dtype=torch.float32, device=v.device)
     dev = v.device
     lib = _lib.load()
     ws_bytes = lib.mphip_warp_workspace_bytes(b, d, h, w)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
-    _lib.check(lib.mphip_warp_volume_dsum(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
+    # one source volume for B driver fields (dp.cross_reenact): the kernel reads it in place, no expanded copy
+    fn = lib.mphip_warp_volume_dsum_shared if (v.shape[0] == 1 and b > 1) else lib.mphip_warp_volume_dsum
+    _lib.check(fn(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
                                           _ptr(linspace_table(w, dev)), _ptr(out), b, c, d, h, w, field.shape[2],
                                           field.shape[3], field.shape[4], _ptr(ws), ws_bytes, _stream()),
                "mphip_warp_volume_dsum")

@@ -328,6 +328,48 @@ def test_hot_slice_backward(dev, M):
     _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3)
 
 
+def test_config3_train_step_full_size(dev, M):
+    """BASELINE config 3's per-GPU shard at its own size: B=4 frames of the 512^2 volume (96x16x64x64) through the
+    whole hot slice under autograd — the full-resolution bwd-weight split/slab-reduce plan, warp_volume_bwd at
+    16x64x64 and the batch-4 paths.  Loss gradient wrt EVERY input (vs, es, Rs, ts, zs, Rd, td, zd) and EVERY
+    parameter vs CPU autograd of oracle/hotpath_ref.py (the reference's module graph) evaluated in FLOAT64, bar 2e-3
+    of each gradient's max-abs (the end-to-end bar of the smaller cases).  Float64 because at this size the fp32 CPU
+    oracle is itself off by up to 5.9e-3 (G3d.downsampling.4.conv1.weight: oneDNN's fp32 weight-gradient
+    accumulation over 4x4096 voxels; tools/grad_truth.py on the GPU box: HIP 1.6e-6 vs fp32-CPU 5.9e-3 against the
+    fp64 truth for that tensor, HIP worst case 5.4e-4 overall) — an fp32 CPU comparison would grade the checker."""
+    sd = R.seeded_gbase_hot_state_dict(7)
+    hot = M.GbaseHotSlice()
+    M.load_hot_state_dict(hot, sd)
+    hot = hot.to(dev).train()
+    inp = R.seeded_hot_inputs(4, 47)
+    cpu_in = {k: v.double().requires_grad_(True) for k, v in inp.items()}
+    cpu_sd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    out_ref = R.hot_slice(sd=cpu_sd, **cpu_in)
+    dout = R.seeded_tensor(tuple(out_ref.shape), 93)
+    out_ref.backward(dout.double())
+    gpu_in = {k: v.clone().to(dev).requires_grad_(True) for k, v in inp.items()}
+    out = hot(**gpu_in)                                   # the reference's 512^2-only entry (model.py:1157 assert holds)
+    assert out.shape == (4, 96, 64, 64)
+    assert (out.detach().cpu().double() - out_ref.detach()).abs().max().item() < 1e-3
+    out.backward(dout.to(dev))
+    for k in inp:
+        assert rel_err(gpu_in[k].grad, cpu_in[k].grad) < 2e-3, k
+    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3)
+
+
+@pytest.mark.parametrize("precision", [1, 0])
+def test_conv3d_bwd_weight_full_resolution(dev, precision):
+    """conv3d_bwd_weight at config 3's largest layer (B=4, 96->96 @16x64x64, k=3), both precisions, vs CPU autograd."""
+    from megaportrait_hack_amd import ops
+
+    x = R.seeded_tensor((4, 96, 16, 64, 64), 61, scale=1.3)
+    dy = R.seeded_tensor((4, 96, 16, 64, 64), 62, scale=0.01)
+    want = torch.nn.grad.conv3d_weight(x, (96, 96, 3, 3, 3), dy, padding=1)
+    _, scale = ops.grad_prep(dy.to(dev), want_bias=False)
+    got = ops.conv3d_bwd_weight(x.to(dev), dy.to(dev), 3, dy_scale=scale, precision=precision)
+    assert rel_err(got, want) < 2e-5
+
+
 def test_graphed_train_step_matches_eager(dev, M):
     """training.GraphedTrainStep (forward + backward + SGD replayed as one hipGraph, weights re-packed inside the
     graph) walks the parameters exactly like the eager step."""

@@ -357,6 +357,31 @@ def test_cross_reenactment_equals_pairwise(M, dev, hot):
         assert (torch.cat(parts, dim=0) - fast).abs().max().item() < 2e-4
 
 
+def test_config5_cross_reenactment_1024_drivers_8_ranks(M, dev, hot, sd):
+    """BASELINE config 5 at its own size: 1 source x 1024 driver frames sharded by driver frame over 8 (virtual) ranks.
+    (a) concatenating the 8 rank shards == the unsharded run, bit for bit (same kernels, same chunking grid);
+    (b) sampled drivers across the range (incl. shard boundaries) against the CPU ORACLE run pairwise on
+        (source, driver) — not against another HIP path."""
+    from megaportrait_hack_amd import dp
+
+    n_drv, world = 1024, 8
+    src = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 31).items()}
+    drv_cpu = R.seeded_hot_inputs(n_drv, 33, D=1, H=1, W=1)      # only Rd/td/zd are used (tiny volumes keep this cheap)
+    drv = {k: drv_cpu[k].to(dev) for k in ("Rd", "td", "zd")}
+    args = (hot, src["vs"], src["es"], src["Rs"], src["ts"], src["zs"], drv["Rd"], drv["td"], drv["zd"])
+    full = dp.cross_reenact(*args, chunk=16)
+    assert full.shape == (n_drv, 96, 64, 64) and torch.isfinite(full).all()
+    parts = [dp.cross_reenact(*args, rank=r, world=world, chunk=16) for r in range(world)]
+    assert [p.shape[0] for p in parts] == [128] * 8
+    assert torch.equal(torch.cat(parts, dim=0), full)
+    src_cpu = R.seeded_hot_inputs(1, 31)
+    for i in (0, 127, 128, 517, 1023):
+        want = R.hot_slice(vs=src_cpu["vs"], es=src_cpu["es"], Rs=src_cpu["Rs"], ts=src_cpu["ts"], zs=src_cpu["zs"],
+                           Rd=drv_cpu["Rd"][i:i + 1], td=drv_cpu["td"][i:i + 1], zd=drv_cpu["zd"][i:i + 1], sd=sd)
+        err = maxabs(full[i:i + 1], want)
+        assert err < 1e-3, (i, err)
+
+
 # ------------------------------------------------------------------------------- blocks / graph
 def test_resblocks_golden(M, dev, hot):
     g = gold("resblocks")
@@ -396,6 +421,51 @@ def test_g3d_golden(dev, hot, sd):
         got = hot.G3d(x16.to(dev))
         assert maxabs(got[:, :, ::2, ::2, ::2], g["mid_s2"]) < 1e-3
         assert maxabs(got, R.g3d(x16, sd)) < 1e-3
+
+
+def _sha1(t):
+    import hashlib
+
+    return hashlib.sha1(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+
+def test_full_size_goldens_of_the_reference(dev, hot, ops):
+    """The full-size (96x16x64x64) fixtures oracle/make_golden.py captured from the imported reference, through the
+    HIP path end to end (HIP S2C generator -> K2 -> G3d): warp #1 vs the strided samples / per-channel sums (and the
+    reference's sha1 whenever the HIP generator happens to reproduce the reference field's bits), G3d vs `full_s4`,
+    the per-channel means and the per-channel abs-max of the reference's output."""
+    ga, gg, gw = gold("apply_warping_field"), gold("g3d"), gold("warp_generator")
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, INPUT_SEED).items()}
+    with torch.no_grad():
+        w1 = hot.warp_generator_s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
+        vc = ops.warp_volume(inp["vs"], w1)
+        assert maxabs(vc[:, :, ::2, ::4, ::4], ga["full_s4"]) < 1e-5
+        assert np.abs(vc.double().sum(dim=(2, 3, 4)).cpu().numpy() - ga["full_chan_sum"]).max() < 1e-2  # sums of 65 536 values
+        field_bits_equal = _sha1(w1) == str(gw["s2c_sha1"])
+        if field_bits_equal:   # FlowField's convs reproduce ATen's bits only by luck; the warp itself is bit-exact (below)
+            assert _sha1(vc) == str(ga["full_sha1"])
+        vc2d = hot.G3d(vc)
+        assert maxabs(vc2d[:, :, ::2, ::4, ::4], gg["full_s4"]) < 1e-3
+        assert np.abs(vc2d.double().mean(dim=(2, 3, 4)).cpu().numpy() - gg["full_chan_mean"]).max() < 1e-4
+        assert np.abs(vc2d.abs().amax(dim=(2, 3, 4)).cpu().numpy() - gg["full_chan_absmax"]).max() < 1e-3
+
+
+def test_k2_full_size_bit_exact_vs_reference_sha1(dev, ops, sd):
+    """`apply_warping_field.npz["full_sha1"]` = sha1 of the REFERENCE's apply_warping_field(vs, w_s2c) at 96x16x64x64.
+    Feeding K2 the bit-identical field (the oracle restatement's S2C field — torch.equal to the reference's in the build
+    container, tests/test_oracle.py) must reproduce every output bit when this host's ATen CPU kernels produce the
+    golden's field bits; on hosts whose oneDNN/ATen rounds FlowField's convs differently the field sha1 differs and the
+    test falls back to bit-equality with the C oracle's warp of that same field."""
+    ga, gw = gold("apply_warping_field"), gold("warp_generator")
+    inp = R.seeded_hot_inputs(1, INPUT_SEED)
+    with torch.no_grad():
+        w1 = R.warp_generator(inp["Rs"], inp["ts"], inp["zs"], inp["es"], sd, "warp_generator_s2c.", invert=True)
+        vc = ops.warp_volume(inp["vs"].to(dev), w1.to(dev))
+    if _sha1(w1) == str(gw["s2c_sha1"]):
+        assert _sha1(vc) == str(ga["full_sha1"]), "K2 differs from the reference's apply_warping_field at full size"
+    else:
+        assert torch.equal(vc.cpu(), R.apply_warping_field(inp["vs"], w1)) or maxabs(vc, R.apply_warping_field(inp["vs"], w1)) < 1e-6
+    assert maxabs(vc[:, :, ::2, ::4, ::4], ga["full_s4"]) < 1e-5
 
 
 def test_eapp_tail_golden_and_full_size(M, dev):

@@ -133,3 +133,24 @@ def test_captured_tables_match_this_host_or_warn():
 def test_c_abi_compiles_and_links_from_plain_c(c_abi_exe):
     """gcc (C99, no C++/torch) against include/mphip.h + libmphip.so: the boundary is usable from plain C."""
     assert os.path.isfile(c_abi_exe)
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus N` with no torchrun environment must start N ranks itself (the driver's
+    SCALE command).  --dry-launch shows the command; --stub-worker runs the real launch path on CPU over gloo."""
+    import json
+    import subprocess
+    import sys
+
+    bench = os.path.join(ROOT, "bench.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, bench, "--gpus", "8", "--steps", "3", "--dry-launch"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode == 0, r.stderr
+    cmd = json.loads(r.stdout.strip().splitlines()[-1])["launch"]
+    assert "torch.distributed.run" in cmd and "--nproc-per-node=8" in cmd and "127.0.0.1" in cmd
+    assert cmd[-4:] == ["--gpus", "8", "--steps", "3"] and "--dry-launch" not in cmd
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--stub-worker"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines == [{"stub_worker": True, "ranks": 2, "n_gpus": 2, "sum": 3.0}]   # exactly ONE line, from rank 0
