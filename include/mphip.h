@@ -68,9 +68,11 @@ int mphip_warp_field_compose(const float *theta, const float *em, const float *b
  * coords_out [B,D,H,W,3] float (clipped x,y,z; when given it replaces the workspace),
  * idx_out [B,D,H,W,3] int32 (floor indices; requires coords_out). */
 size_t mphip_warp_workspace_bytes(int B, int D, int H, int W);
+/* out_range (optional, 16 B): range descriptor of `out` (see "Range descriptors" below) — the gather pass folds
+ * max|out| in, so the conv that consumes the warped volume (G3d's first, model.py:1160) needs no extra pass. */
 int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
-                      const float *lin_w, float *out, float *coords_out, int32_t *idx_out, int B, int C,
-                      int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
+                      const float *lin_w, float *out, float *coords_out, int32_t *idx_out, float *out_range, int B,
+                      int C, int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
                       void *stream);
 
 /* ------------------------------------------------------------------ K3  warp + depth projection
@@ -92,20 +94,34 @@ int mphip_warp_volume_dsum_shared(const float *v, const float *field, const floa
  * x [N,Ci,D,H,W] fp32 -> y [N,Co,D,H,W] fp32 in both precisions.
  * precision 0: exact fp32 (v_mfma_f32_32x32x2_f32, bitwise an fmaf chain), any shape.
  * precision 1: "f16x3" — operands split into two f16 halves, 3 f16 MFMAs per product, fp32
- *              accumulate (~2^-21 relative per term, fp32 class; needs |x| < 4094).  Only for
+ *              accumulate (~2^-21 relative per term, fp32 class, for tensors of ANY magnitude: every
+ *              operand tensor is scaled by its own power of two, see "Range descriptors").  Only for
  *              k=3, Ci%16==0, Co%96==0, H%8==0, W%8==0, D%2==0: ask mphip_conv3d_supported().
+ *
+ * Range descriptors (precision 1).  x_range = 4 floats on the device describing the magnitude of x:
+ *   [0] scale  [1] 1/scale  [2] max|x| (or a rigorous upper bound)  [3] unused
+ *   [0] != 0: explicit power-of-two operand scale (mphip_grad_prep writes gradients' this way);
+ *   [0] == 0: the kernel derives it from [2] — the power of two with max|x|*scale in [2^13, 2^14).
+ * Producers that already stream the tensor fill one for free (mphip_warp_volume, mphip_groupnorm_apply*,
+ * mphip_groupnorm_affine_table — `out_range` arguments), mphip_absmax_range() makes one for a tensor of unknown
+ * origin, and x_range == NULL lets the conv do that itself (one extra read of x; 16 bytes of workspace).  With a
+ * correct descriptor no finite value can leave the f16 range — the reference's fp32 conv has no range cliff, neither
+ * has this; Inf/NaN inputs (and finite ones beyond a WRONG descriptor) are not clamped, they propagate as Inf/NaN and
+ * are counted (mphip_f16x3_saturation_count).  precision 0 ignores x_range.
  * Weights are used in a packed layout built once per weight version and per precision:
  *   precision 0: OIDHW -> [k^3][CiP][CoP] fp32 (CoP = Co up to 32, CiP = Ci up to 2, zero padded)
  *   precision 1: 16-byte header (1/scale, scale) + the LDS image of every (96-channel tile,
  *                16-channel chunk, 3-tap group) slab as f16 hi/lo planes.
- * workspace: split-K partial sums for small volumes (0 when not needed).                  */
+ * workspace: 16 bytes for a library-computed range descriptor (precision 1) + split-K partial sums for small
+ * volumes; mphip_conv3d_workspace_bytes() gives the total.                                   */
 int mphip_conv3d_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision);
 int mphip_pack_conv_weight(const float *w_oidhw, void *w_packed, int Co, int Ci, int k, int precision,
                            void *stream);
 size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
-int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
-                     int Co, int D, int H, int W, int k, int precision, void *workspace,
+int mphip_absmax_range(const float *x, size_t n, float *range, void *stream);   /* x, range 16-byte aligned */
+int mphip_conv3d_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, int N,
+                     int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                      size_t workspace_bytes, void *stream);
 
 /* conv + the statistics of the GroupNorm that follows it (nn.Conv3d -> nn.GroupNorm pairs at
@@ -113,7 +129,7 @@ int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, fl
  * (mean, rstd) of y, identical to mphip_groupnorm_stats(y) — one host call for the conv -> GN pair. */
 size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
                                        int gn_groups);
-int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias, float *y, float *gn_stats,
+int mphip_conv3d_gn_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, float *gn_stats,
                         int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups,
                         float gn_eps, void *workspace, size_t workspace_bytes, void *stream);
 
@@ -121,13 +137,16 @@ int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias,
  * 390-396): mphip_groupnorm_affine_table turns (mean, rstd) + gamma/beta (+ AdaptiveGroupNorm's w2/b2) into
  * table[N][C][2] = (scale, shift); mphip_conv3d_gnin_fwd applies x' = x*scale + shift (then ReLU if in_relu)
  * to every in-volume voxel while it stages its input tile (padding stays 0), so the normalised tensor is never
- * written.  precision 1 (f16x3) only, Ci <= 768.                                                      */
+ * written.  precision 1 (f16x3) only, Ci <= 768.  The table call also fills out_range, the range descriptor of the
+ * NORMALISED tensor the conv will see, from a data-independent bound: |x-mean|*rstd <= sqrt(elements per group), so
+ * |x'[c]| <= sqrt(C/G*S)*|gamma*w2| + |beta*w2 + b2| (S = D*H*W of x); pass it as x_range.               */
 int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const float *beta, const float *w2,
-                                 const float *b2, float *table, int N, int C, int G, void *stream);
-int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+                                 const float *b2, float *table, float *out_range, int N, int C, int S, int G,
+                                 void *stream);
+int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,
                           const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
                           int precision, void *workspace, size_t workspace_bytes, void *stream);
-int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,
                              const float *bias, float *y, float *gn_stats, int N, int Ci, int Co, int D, int H, int W,
                              int k, int precision, int gn_groups, float gn_eps, void *workspace,
                              size_t workspace_bytes, void *stream);
@@ -136,10 +155,12 @@ int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, int in_relu
  * its result as `splits` partial slabs out[z][N,Co,D,H,W] (bias NOT added) and the GroupNorm statistics /
  * apply kernels that consume it sum the slabs on the fly (z ascending + bias, the same order as the
  * reduce of mphip_conv3d_fwd), so the separate reduce launch and pass disappear.
- * mphip_conv3d_splits() == 1 means the conv is not split: out is then the plain result (bias added). */
+ * mphip_conv3d_splits() == 1 means the conv is not split: out is then the plain result (bias added).
+ * workspace: only the 16 bytes of a library-computed range descriptor (precision 1 and x_range == NULL).  */
 int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
-int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bias, float *out, int N, int Ci,
-                           int Co, int D, int H, int W, int k, int precision, void *stream);
+int mphip_conv3d_fwd_split(const float *x, const float *x_range, const void *w_packed, const float *bias, float *out,
+                           int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ K6  GroupNorm
  * Replaces nn.GroupNorm(G,C) eps=1e-5 (model.py:506,508,460,309) and what the reference
@@ -150,13 +171,14 @@ int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bi
  *         model.py:314-316);  if residual: y += residual  (model.py:522);  if relu: max(y,0)
  *         (model.py:517,523);  if tanh_: y = tanh(y) after relu (model.py:462-465).
  *         pool2 != 0 additionally averages 2x2x2 cells (nn.AvgPool3d(2,2), model.py:576-580):
- *         then y is [N,C,D/2,H/2,W/2] and D,H,W must be given (S = D*H*W).                 */
+ *         then y is [N,C,D/2,H/2,W/2] and D,H,W must be given (S = D*H*W).
+ *         out_range (optional): range descriptor of y for the conv that reads it (max|y| folded in). */
 size_t mphip_groupnorm_workspace_bytes(int N, int C, int S, int G);
 int mphip_groupnorm_stats(const float *x, float *stats, int N, int C, int S, int G, float eps,
                           void *workspace, size_t workspace_bytes, void *stream);
 int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,
-                          const float *w2, const float *b2, const float *residual, float *y, int N, int C,
-                          int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream);
+                          const float *w2, const float *b2, const float *residual, float *y, float *out_range, int N,
+                          int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream);
 
 /* Split-aware variants (see mphip_conv3d_fwd_split): x and/or residual may be `*_splits` partial slabs with
  * their conv bias passed separately; the output can additionally be nearest-upsampled by (uD,uH,uW) —
@@ -166,9 +188,9 @@ int mphip_groupnorm_stats_split(const float *x, int x_splits, const float *x_bia
                                 int S, int G, float eps, void *stream);
 int mphip_groupnorm_apply_split(const float *x, int x_splits, const float *x_bias, const float *stats,
                                 const float *gamma, const float *beta, const float *w2, const float *b2,
-                                const float *residual, int res_splits, const float *res_bias, float *y, int N,
-                                int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, int uD, int uH,
-                                int uW, void *stream);
+                                const float *residual, int res_splits, const float *res_bias, float *y,
+                                float *out_range, int N, int C, int D, int H, int W, int G, int relu, int tanh_,
+                                int pool2, int uD, int uH, int uW, void *stream);
 
 /* statistics + apply in ONE launch for tiny tensors (a (sample, group) span of <= 12288 floats: every FlowField
  * layer): one workgroup per (sample, group), values cached in LDS between the two passes.  Same arguments
@@ -229,9 +251,10 @@ int mphip_conv3d_bwd_data(const float *dy, const void *wt_packed, float *dx, con
                           void *stream);
 int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
-int mphip_conv3d_bwd_weight(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co,
-                            int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
-                            void *stream);
+/* x_range: the range descriptor the forward conv used for x (precision 1; NULL = computed here, one extra read of x) */
+int mphip_conv3d_bwd_weight(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N,
+                            int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                            size_t workspace_bytes, void *stream);
 size_t mphip_groupnorm_bwd_workspace_bytes(int N, int C, int S);
 int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, const float *stats,
                                const float *gamma, const float *beta, const float *w2, float *dgamma, float *dbeta,
@@ -270,9 +293,9 @@ int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *
 int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
                        int invert, void *stream);
 
-/* Diagnostic (synchronous, not stream-ordered): the number of activation elements the f16x3 conv kernels had to clamp
- * because |x * scale| left the f16 range (|x| >= 4062 in the forward pass) since the last reset.  0 in normal operation;
- * non-zero means those launches returned finite but wrong values — rerun with precision 0 (exact fp32).            */
+/* Diagnostic (synchronous, not stream-ordered): operand elements of the f16x3 conv kernels whose scaled value was outside
+ * the f16 range since the last reset — Inf/NaN inputs, or finite values beyond a wrong caller-supplied range descriptor.
+ * They are NOT clamped (the output carries Inf/NaN like the reference's fp32 conv would); 0 in normal operation.     */
 int mphip_f16x3_saturation_count(unsigned long long *count, int reset);
 
 #ifdef __cplusplus

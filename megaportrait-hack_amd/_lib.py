@@ -26,27 +26,28 @@ SIGNATURES = {
     "mphip_rt_theta": (_i, [_p, _p, _p, _i, _i, _p]),
     "mphip_warp_field_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mphip_warp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
-    "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_volume_dsum_shared": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_conv3d_supported": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "mphip_packed_weight_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_pack_conv_weight": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_conv3d_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "mphip_conv3d_fwd": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_absmax_range": (_i, [_p, _sz, _p, _p]),
+    "mphip_conv3d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_conv3d_gn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
-    "mphip_conv3d_gn_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
-    "mphip_groupnorm_affine_table": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _p]),
-    "mphip_conv3d_gnin_gn_fwd": (_i, [_p, _p, _i, _p, _p, _p, _p] + [_i] * 9 + [ctypes.c_float, _p, _sz, _p]),
-    "mphip_conv3d_gnin_fwd": (_i, [_p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_conv3d_gn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
+    "mphip_groupnorm_affine_table": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
+    "mphip_conv3d_gnin_gn_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p] + [_i] * 9 + [ctypes.c_float, _p, _sz, _p]),
+    "mphip_conv3d_gnin_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_conv3d_splits": (_i, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "mphip_conv3d_fwd_split": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_conv3d_fwd_split": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_groupnorm_stats_split": (_i, [_p, _i, _p, _p, _i, _i, _i, _i, ctypes.c_float, _p]),
-    "mphip_groupnorm_apply_split": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p] + [_i] * 12 + [_p]),
+    "mphip_groupnorm_apply_split": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 12 + [_p]),
     "mphip_groupnorm_small_fused": (_i, [_p, _i, _p, _p, _p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 6 + [ctypes.c_float] + [_i] * 5 + [_p]),
     "mphip_groupnorm_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "mphip_groupnorm_stats": (_i, [_p, _p, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
-    "mphip_groupnorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_groupnorm_apply": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mphip_avgpool2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_nearest": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
@@ -58,7 +59,7 @@ SIGNATURES = {
     "mphip_conv3d_bwd_data": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
     "mphip_conv3d_bwd_weight_supported": (_i, [_i] * 8),
     "mphip_conv3d_bwd_weight_workspace_bytes": (_sz, [_i] * 8),
-    "mphip_conv3d_bwd_weight": (_i, [_p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
+    "mphip_conv3d_bwd_weight": (_i, [_p, _p, _p, _p, _p] + [_i] * 8 + [_p, _sz, _p]),
     "mphip_groupnorm_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "mphip_groupnorm_bwd_reduce": (_i, [_p] * 12 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_groupnorm_bwd_apply": (_i, [_p] * 9 + [_i] * 5 + [_p]),

@@ -41,14 +41,18 @@ class Conv3dFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, conv, fwd_pack):
         ctx.conv = conv
         ctx.has_bias = bias is not None
-        ctx.save_for_backward(x)
-        return ops.conv3d(x, fwd_pack)
+        # weight is saved too (not only read from the module in backward): autograd's version check then catches an
+        # in-place weight update between forward and backward
+        ctx.save_for_backward(x, weight)
+        y = ops.conv3d(x, fwd_pack)
+        ctx.x_range = ops.tensor_range(x)   # the f16x3 operand scale the forward used for x: bwd-weight reuses it
+        return y
 
     @staticmethod
     @once_differentiable  # no double backward (the reference's losses need none): asking for one raises instead of returning zeros
     @_bwd
     def backward(ctx, dy):
-        (x,) = ctx.saved_tensors
+        x, _weight = ctx.saved_tensors
         conv = ctx.conv
         dy = dy.contiguous()
         k = conv.weight.shape[2]
@@ -57,7 +61,7 @@ class Conv3dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv3d_bwd_weight(x, dy, k, scale).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
+            dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
         return dx, dw, db, None, None
 
 

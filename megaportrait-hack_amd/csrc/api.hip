@@ -1,4 +1,6 @@
 // Library-level entry points: version and the thread-local error string.
+#include <algorithm>
+
 #include "mphip_common.h"
 
 namespace mphip {
@@ -21,3 +23,32 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(float4 *__restrict__ p, 
         p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 }  // namespace mphip
+
+namespace mphip {
+__global__ void __launch_bounds__(256) absmax_range_kernel(const float *__restrict__ x, size_t n, float *__restrict__ range) {
+    unsigned m = 0;
+    const size_t n4 = n / 4;
+    const float4 *x4 = reinterpret_cast<const float4 *>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = max(max(m, range_bits(v.x)), max(range_bits(v.y), max(range_bits(v.z), range_bits(v.w))));
+    }
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = max(m, range_bits(x[i]));
+    range_note(m, range);
+}
+
+int absmax_range_launch(const float *x, size_t n, float *range, hipStream_t s) {
+    zero_fill(range, 16, s);
+    const size_t per_block = 256 * 4 * 8;  // ~8 float4 per thread
+    const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + per_block - 1) / per_block);
+    hipLaunchKernelGGL(absmax_range_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, x, n, range);
+    return check_launch("absmax_range");
+}
+}  // namespace mphip
+
+extern "C" int mphip_absmax_range(const float *x, size_t n, float *range, void *stream) {
+    MPHIP_REQUIRE(x && range && n > 0, "absmax_range: null pointer or empty tensor");
+    MPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)range & 15) == 0, "absmax_range: pointers must be 16-byte aligned");
+    return mphip::absmax_range_launch(x, n, range, (hipStream_t)stream);
+}

@@ -495,15 +495,15 @@ extern "C" int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, i
 extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
     if (bwd_weight_direct(N, D, H, W)) return 16;  // unused
-    if (precision == 1) return bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W, k);
+    if (precision == 1) return 16 + bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W, k);  // 16: a library-computed range of x
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int bxy = ((Ci + 31) / 32) * ((Co + 95) / 96) * (k == 3 ? 3 : 1);
     return (size_t)bw_splits(ntiles, bxy) * Co * Ci * k * k * k * sizeof(float);
 }
 
-extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co,
-                                       int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
-                                       void *stream) {
+extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N,
+                                       int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                       size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(x && dy && dw, "conv3d_bwd_weight: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3), "conv3d_bwd_weight: bad dims");
     MPHIP_REQUIRE(mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision),
@@ -532,7 +532,15 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *dy, const fl
                                H, W);
         return check_launch("conv3d_bwd_weight(direct)");
     }
-    if (precision == 1) return bwd_weight_f16x3_launch(x, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, workspace, s);
+    if (precision == 1) {
+        // the saved activation's range descriptor (the forward conv's x_range); none given -> computed into the workspace head
+        if (!x_range) {
+            int rc0 = absmax_range_launch(x, (size_t)N * Ci * D * H * W, (float *)workspace, s);
+            if (rc0) return rc0;
+            x_range = (const float *)workspace;
+        }
+        return bwd_weight_f16x3_launch(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, (char *)workspace + 16, s);
+    }
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;
     const int splits = bw_splits(ntiles, ci_tiles * co_tiles * (k == 3 ? 3 : 1));

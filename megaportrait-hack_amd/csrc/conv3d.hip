@@ -500,10 +500,13 @@ static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int
     return check_launch("pack_conv_weight");
 }
 
+constexpr size_t RANGE_BYTES = 16;
+
 extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
     int splits = precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
-    return splits > 1 ? (size_t)splits * N * Co * D * H * W * sizeof(float) : 0;
+    // precision 1: 16 bytes in front for the range descriptor the library computes itself when the caller passes none
+    return (precision == 1 ? RANGE_BYTES : 0) + (splits > 1 ? (size_t)splits * N * Co * D * H * W * sizeof(float) : 0);
 }
 
 template <int KS, int MT, int NT, int WCO, bool SKIP>
@@ -548,7 +551,7 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
     }
 }
 
-static int conv3d_run(const float *x, const float *in_affine, int in_relu, const float *x_scale, const void *w_packed, const float *bias, float *y,
+static int conv3d_run(const float *x, const float *in_affine, int in_relu, const float *x_range, const void *w_packed, const float *bias, float *y,
                       float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                       size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
@@ -574,6 +577,22 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     }
     float *dst = y;
     const size_t n_out = (size_t)N * Co * D * H * W;
+    // f16x3: the input's range descriptor (mphip_common.h).  None given -> one extra pass computes max|x| into the first 16
+    // bytes of the workspace (a fused input GroupNorm changes the values: its descriptor must come from
+    // mphip_groupnorm_affine_table).
+    const size_t range_bytes = precision == 1 ? RANGE_BYTES : 0;
+    if (precision == 1 && !x_range) {
+        MPHIP_REQUIRE(!in_affine, "conv3d_fwd: the fused input GroupNorm needs the range descriptor of mphip_groupnorm_affine_table");
+        if (!workspace || workspace_bytes < range_bytes) {
+            set_error("conv3d_fwd: workspace %zu bytes < required %zu (no x_range given: 16 bytes for the input's range)", workspace_bytes, range_bytes);
+            return MPHIP_EWORKSPACE;
+        }
+        int rc0 = absmax_range_launch(x, (size_t)N * Ci * D * H * W, (float *)workspace, s);
+        if (rc0) return rc0;
+        x_range = (const float *)workspace;
+    }
+    workspace = workspace ? (char *)workspace + range_bytes : nullptr;
+    workspace_bytes = workspace_bytes > range_bytes ? workspace_bytes - range_bytes : 0;
     const size_t slab_bytes = (splits > 1 && !keep_split) ? (size_t)splits * n_out * sizeof(float) : 0;
     // (statistics in the f16x3 kernel's epilogue were tried and measured 1.2 % slower end to end: DESIGN.md §3)
     const size_t gn_bytes = gn_stats ? groupnorm_ws_bytes(N, Co, D * H * W, gn_groups) : 0;
@@ -591,7 +610,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
     if (precision == 1) {
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_scale, s);
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -618,10 +637,10 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     return rc;
 }
 
-extern "C" int mphip_conv3d_fwd(const float *x, const void *w_packed, const float *bias, float *y, int N, int Ci,
-                                int Co, int D, int H, int W, int k, int precision, void *workspace,
+extern "C" int mphip_conv3d_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, int N,
+                                int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                                 size_t workspace_bytes, void *stream) {
-    return conv3d_run(x, nullptr, 0, nullptr, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }
 
@@ -630,9 +649,12 @@ extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, i
     return precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
 }
 
-extern "C" int mphip_conv3d_fwd_split(const float *x, const void *w_packed, const float *bias, float *out, int N, int Ci,
-                                      int Co, int D, int H, int W, int k, int precision, void *stream) {
-    return conv3d_run(x, nullptr, 0, nullptr, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, nullptr, 0, stream);
+extern "C" int mphip_conv3d_fwd_split(const float *x, const float *x_range, const void *w_packed, const float *bias, float *out,
+                                      int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    // workspace: only the 16 bytes of a library-computed range descriptor (precision 1 with x_range == NULL)
+    return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, workspace,
+                      workspace_bytes, stream);
 }
 
 extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
@@ -641,33 +663,33 @@ extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, 
     return mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, k, precision) + groupnorm_ws_bytes(N, Co, D * H * W, gn_groups);
 }
 
-extern "C" int mphip_conv3d_gn_fwd(const float *x, const void *w_packed, const float *bias, float *y, float *gn_stats,
+extern "C" int mphip_conv3d_gn_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, float *gn_stats,
                                    int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups,
                                    float gn_eps, void *workspace, size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(gn_stats, "conv3d_gn_fwd: null stats pointer");
     MPHIP_REQUIRE(gn_groups > 0 && Co > 0 && Co % gn_groups == 0, "conv3d_gn_fwd: Co=%d not divisible into %d groups", Co,
                   gn_groups);
-    return conv3d_run(x, nullptr, 0, nullptr, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
+    return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }
 
-extern "C" int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+extern "C" int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,
                                      const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
                                      int precision, void *workspace, size_t workspace_bytes, void *stream) {
-    MPHIP_REQUIRE(in_affine, "conv3d_gnin_fwd: null affine table");
-    return conv3d_run(x, in_affine, in_relu, nullptr, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision,
+    MPHIP_REQUIRE(in_affine && x_range, "conv3d_gnin_fwd: null affine table / range descriptor (mphip_groupnorm_affine_table makes both)");
+    return conv3d_run(x, in_affine, in_relu, x_range, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision,
                       workspace, workspace_bytes, stream);
 }
 
 // conv(relu?(GroupNorm(x))) with the statistics of its own output for the NEXT GroupNorm (conv2 of a residual block)
-extern "C" int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, int in_relu, const void *w_packed,
+extern "C" int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,
                                         const float *bias, float *y, float *gn_stats, int N, int Ci, int Co, int D, int H,
                                         int W, int k, int precision, int gn_groups, float gn_eps, void *workspace,
                                         size_t workspace_bytes, void *stream) {
-    MPHIP_REQUIRE(in_affine && gn_stats, "conv3d_gnin_gn_fwd: null pointer");
+    MPHIP_REQUIRE(in_affine && x_range && gn_stats, "conv3d_gnin_gn_fwd: null pointer");
     MPHIP_REQUIRE(gn_groups > 0 && Co > 0 && Co % gn_groups == 0, "conv3d_gnin_gn_fwd: Co=%d not divisible into %d groups", Co,
                   gn_groups);
-    return conv3d_run(x, in_affine, in_relu, nullptr, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k,
+    return conv3d_run(x, in_affine, in_relu, x_range, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k,
                       precision, workspace, workspace_bytes, stream);
 }
 

@@ -28,7 +28,6 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float BF_X_SCALE = 16.0f;  // = the forward kernel's activation scale
 constexpr float BF_CLAMP = 65000.0f;
 constexpr int BF_AP = 136;                    // halves per co row of the dY tile: 128 voxels + 8 (pitch 68 dwords: b128 conflict-free)
 constexpr int BF_XROW = 12;                   // halves per halo row: 10 voxels + 2 (24 B, 8-B aligned)
@@ -36,10 +35,12 @@ constexpr int BF_XCI = 4 * 10 * BF_XROW + 8;  // halves per input channel: 4 pla
 constexpr int BF_A_PART = 96 * BF_AP;
 constexpr int BF_X_PART = 32 * BF_XCI;
 
+// (same split as conv3d_f16x3.hip: operands are pre-scaled by their tensors' range descriptors; a non-finite value is not
+//  clamped but propagates — an overflowed gradient must stay visible to GradScaler, train.py:145,318-320)
 __device__ __forceinline__ void bf_split(float v, _Float16 &hi, _Float16 &lo) {
-    v = fminf(fmaxf(v, -BF_CLAMP), BF_CLAMP);
     hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
+    const float r = v - (float)hi;
+    lo = (fabsf(v) <= BF_CLAMP) ? (_Float16)r : (_Float16)0.0f;
 }
 
 __device__ __forceinline__ half8 as_half8(unsigned a, unsigned b, unsigned c, unsigned d) {
@@ -65,6 +66,7 @@ __device__ __forceinline__ void halo_row_frags(const _Float16 *row, half8 f[3]) 
 
 __global__ void __launch_bounds__(512)
 conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gscale,
+                             const float *__restrict__ x_range,
                              float *__restrict__ slabs, int N, int Ci, int Co, int D, int H, int W, int tiles_per_split) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BF_A_PART + 2 * BF_X_PART];
     _Float16 *const As = smem;                  // [part][co 96][BF_AP]
@@ -81,6 +83,8 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
     const int t_begin = blockIdx.z * tiles_per_split;
     const int t_end = min(ntiles, t_begin + tiles_per_split);
     const float dscale = gscale[0];
+    float BF_X_SCALE, bf_x_unscale;  // the saved activation's own operand scale (its range descriptor)
+    range_scale(x_range, BF_X_SCALE, bf_x_unscale);
     const int kd = wave / 3, kh = wave % 3;  // this wave's tap row; waves 0..2 also take row 8 (kd=kh=2), co-tile `wave`
     const bool heavy = wave < 3;
 
@@ -212,7 +216,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
     }
 
     // slab layout [27][Co][Ci] (a store covers 32 consecutive ci); C/D: column = lane&31 = ci, rows = co
-    const float unscale = gscale[1] * (1.0f / BF_X_SCALE);
+    const float unscale = gscale[1] * bf_x_unscale;
     float *slab = slabs + (size_t)blockIdx.z * Co * Ci * 27;
     const int ci = ci0 + j;
     if (ci < Ci) {
@@ -243,6 +247,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
 // partial sums are combined in LDS before one slab write.  Same split precision as above.
 __global__ void __launch_bounds__(512)
 conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gscale,
+                                const float *__restrict__ x_range,
                                 float *__restrict__ slabs, int N, int Ci, int Co, int DHW, int tiles_per_split) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[4 * BF_A_PART];
     _Float16 *const As = smem;                  // dY [part][96][BF_AP]
@@ -256,6 +261,8 @@ conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__rest
     const int ntiles = N * tiles_per_sample;
     const int t_begin = blockIdx.z * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
     const float dscale = gscale[0];
+    float BF_X_SCALE, bf_x_unscale;  // the saved activation's own operand scale (its range descriptor)
+    range_scale(x_range, BF_X_SCALE, bf_x_unscale);
     f32x16 acc[3][3];
 #pragma unroll
     for (int m = 0; m < 3; ++m)
@@ -333,7 +340,7 @@ conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__rest
         }
         __syncthreads();
     }
-    const float unscale = gscale[1] * (1.0f / BF_X_SCALE);
+    const float unscale = gscale[1] * bf_x_unscale;
     float *slab = slabs + (size_t)blockIdx.z * Co * Ci;
     for (int i = tid; i < 96 * 96; i += 512) {
         const int co = co0 + i / 96, ci = ci0 + i % 96;
@@ -471,13 +478,13 @@ size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int
     return (size_t)splits * Co * Ci * 27 * sizeof(float);
 }
 
-int bwd_weight_f16x3_launch(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co, int D,
-                            int H, int W, int k, void *workspace, hipStream_t s) {
+int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N, int Ci,
+                            int Co, int D, int H, int W, int k, void *workspace, hipStream_t s) {
     int splits, tps;
     if (k == 1) {
         bwf_k1_plan(N, Ci, Co, D * H * W, splits, tps);
         dim3 grid(((Ci + 95) / 96) * ((Co + 95) / 96), 1, splits);
-        hipLaunchKernelGGL(conv_bwd_weight_k1_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, (float *)workspace, N, Ci, Co,
+        hipLaunchKernelGGL(conv_bwd_weight_k1_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, x_range, (float *)workspace, N, Ci, Co,
                            D * H * W, tps);
         const size_t nw = (size_t)Co * Ci;
         hipLaunchKernelGGL(slab_reduce_plain_kernel, dim3(cdiv(nw, 256)), dim3(256), 0, s, (const float *)workspace, dw, nw, splits);
@@ -485,7 +492,7 @@ int bwd_weight_f16x3_launch(const float *x, const float *dy, const float *dy_sca
     }
     bwf_plan(N, Ci, Co, D, H, W, splits, tps);
     dim3 grid(((Ci + 31) / 32) * ((Co + 95) / 96), 1, splits);
-    hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, (float *)workspace, N, Ci, Co, D, H, W,
+    hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, x_range, (float *)workspace, N, Ci, Co, D, H, W,
                        tps);
     const size_t ncc = (size_t)Co * Ci;
     hipLaunchKernelGGL(slab_reduce_f16x3_kernel, dim3(cdiv(ncc, 64)), dim3(256), 0, s, (const float *)workspace, dw, ncc, splits);

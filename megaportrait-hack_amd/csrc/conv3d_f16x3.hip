@@ -32,7 +32,7 @@ typedef _Float16 half2v __attribute__((ext_vector_type(2)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr float X_SCALE = 16.0f;          // activations: |x| < 4094 stays finite in f16; lo subnormal only below |x| ~ 8e-3
+constexpr float X_SCALE = 16.0f;          // legacy fixed activation scale: only when a caller passes no range descriptor
 constexpr float F16_CLAMP = 65000.0f;
 constexpr int F16X3_KC = 16;              // input channels per chunk = K of one MFMA
 constexpr int F16X3_TG = 3;               // taps per packed weight slab
@@ -40,15 +40,17 @@ constexpr int F16X3_NG = 27 / F16X3_TG;   // slabs per 16-channel chunk
 constexpr int F16X3_COT = 96;             // output channels per workgroup (3 MFMA row tiles)
 constexpr int SLAB_HALFS = 2 * F16X3_TG * 2 * F16X3_COT * 8;  // [part][tap][kg][co][8] = 9216 halfs = 18432 B
 
-// Range guard: activations beyond +-65000/scale (|x| >= 4062 at the forward scale 16) are clamped by split_f16 — finite but
-// wrong.  The kernels count such elements here (one atomic per wavefront that saw any, i.e. none in normal operation);
-// mphip_f16x3_saturation_count() reads the counter so a caller can verify a run stayed in range.
+// Range: every operand tensor carries a range descriptor (mphip_common.h) and is scaled by its own power of two before the
+// split, so max|x|*scale < 2^14 and no finite value can leave the f16 range.  Whatever still does — a non-finite input, or a
+// finite one beyond a WRONG descriptor handed in by a caller — is not clamped: hi takes the value itself (Inf/NaN in f16),
+// lo = 0, and the MFMA propagates Inf/NaN into the output exactly like the reference's fp32 conv would.  Such elements are
+// counted (one atomic per wavefront that saw any, i.e. none in normal operation): mphip_f16x3_saturation_count().
 __device__ unsigned long long g_f16x3_saturated;
 
 __device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
-    v = fminf(fmaxf(v, -F16_CLAMP), F16_CLAMP);
-    hi = (_Float16)v;
-    lo = (_Float16)(v - (float)hi);
+    hi = (_Float16)v;                      // |v| > 65504 -> +-Inf, NaN -> NaN
+    const float r = v - (float)hi;
+    lo = (fabsf(v) <= F16_CLAMP) ? (_Float16)r : (_Float16)0.0f;   // (Inf - Inf would be NaN: keep Inf an Inf)
 }
 
 #ifdef MPHIP_PROFILE_PHASES
@@ -67,7 +69,7 @@ __device__ unsigned long long g_f16x3_prof[8];
 #ifdef MPHIP_NO_SAT_GUARD  /* dev: same-box A/B of the range guard's cost */
 #define F16X3_SAT_COUNT(a_, b_)
 #else
-#define F16X3_SAT_COUNT(a_, b_) sat_ += (fabsf((a_) * x_scale) > F16_CLAMP) + (fabsf((b_) * x_scale) > F16_CLAMP);
+#define F16X3_SAT_COUNT(a_, b_) sat_ += !(fabsf((a_) * x_scale) <= F16_CLAMP) + !(fabsf((b_) * x_scale) <= F16_CLAMP);  /* NaN counts */
 #endif
 
 // ---- weight packing ----------------------------------------------------------------------------
@@ -133,11 +135,12 @@ __global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_e
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware) {
+                       const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware) {
     constexpr int MT = 3, KC = F16X3_KC;
-    // activation scale: the fixed X_SCALE for forward activations; a per-tensor power of two from mphip_grad_prep
-    // when the input is a gradient (bwd-data), whose magnitude is arbitrary
-    const float x_scale = x_scale_p ? x_scale_p[0] : X_SCALE;
+    // operand scale of the input tensor: from its range descriptor (activations: max|x| noted by the producing kernel or
+    // mphip_absmax_range; gradients: mphip_grad_prep) — per tensor, a power of two
+    float x_scale = X_SCALE, x_unscale = 1.0f / X_SCALE;
+    if (x_scale_p) range_scale(x_scale_p, x_scale, x_unscale);
     constexpr int TVOX = TD * TH * TW;
     constexpr int NTHR = NWAVES * 64;
     constexpr int NT = TVOX / (32 * NWAVES);          // 32-voxel column tiles per wave
@@ -443,7 +446,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 
     const bool direct = gridDim.z == 1;
     float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
-    const float unscale = whdr[0] * (x_scale_p ? x_scale_p[1] : 1.0f / X_SCALE);
+    const float unscale = whdr[0] * x_unscale;
     const int co0 = cot * F16X3_COT;
     float bv[MT][16];
 #pragma unroll

@@ -26,14 +26,14 @@ size_t f16x3_packed_bytes(int Co, int Ci);
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W);
 int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int transposed, const void *header_from, hipStream_t s);
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s);
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s);
 
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)
 bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
 size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
-int bwd_weight_f16x3_launch(const float *x, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co, int D,
-                            int H, int W, int k, void *workspace, hipStream_t s);
+int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N, int Ci,
+                            int Co, int D, int H, int W, int k, void *workspace, hipStream_t s);
 
 // norm.hip: GroupNorm statistics of x [N,C,S] -> stats [N*G][2] (workspace sized by groupnorm_ws_bytes)
 size_t groupnorm_ws_bytes(int N, int C, int S, int G);

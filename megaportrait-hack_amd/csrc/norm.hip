@@ -166,6 +166,7 @@ struct GnParams {
     float *y;
     int C, cpg;
     int relu, tanh_;
+    float *range;  // optional: range descriptor of y (zeroed by the launcher; max|y| is folded in — the next conv's f16x3 scale)
 };
 
 __device__ __forceinline__ float gn_value(const GnParams &p, float xv, float mean, float rstd, float g, float b,
@@ -182,35 +183,42 @@ __device__ __forceinline__ float gn_value(const GnParams &p, float xv, float mea
 template <int VW>
 __global__ void __launch_bounds__(256) gn_apply_kernel(GnParams p, int S, size_t total_vec) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total_vec) return;
-    const int SV = S / VW;
-    size_t plane = t / SV;  // n*C + c
-    int c = (int)(plane % p.C);
-    int n = (int)(plane / p.C);
-    int grp = n * (p.C / p.cpg) + c / p.cpg;
-    float mean = p.stats[grp * 2], rstd = p.stats[grp * 2 + 1];
-    float g = p.gamma[c], b = p.beta[c];
-    bool has2 = p.w2 != nullptr, has_res = p.residual != nullptr;
-    float w2 = has2 ? p.w2[c] : 1.0f, b2 = has2 ? p.b2[c] : 0.0f;
-    size_t o = t * VW;
-    if (VW == 4) {
-        float4 xv = *reinterpret_cast<const float4 *>(p.x + o);
-        float4 rv = has_res ? *reinterpret_cast<const float4 *>(p.residual + o) : make_float4(0, 0, 0, 0);
-        float4 out;
-        out.x = gn_value(p, xv.x, mean, rstd, g, b, w2, b2, has2, rv.x, has_res);
-        out.y = gn_value(p, xv.y, mean, rstd, g, b, w2, b2, has2, rv.y, has_res);
-        out.z = gn_value(p, xv.z, mean, rstd, g, b, w2, b2, has2, rv.z, has_res);
-        out.w = gn_value(p, xv.w, mean, rstd, g, b, w2, b2, has2, rv.w, has_res);
-        *reinterpret_cast<float4 *>(p.y + o) = out;
-    } else {
-        p.y[o] = gn_value(p, p.x[o], mean, rstd, g, b, w2, b2, has2, has_res ? p.residual[o] : 0.0f, has_res);
+    unsigned mbits = 0;
+    if (t < total_vec) {
+        const int SV = S / VW;
+        size_t plane = t / SV;  // n*C + c
+        int c = (int)(plane % p.C);
+        int n = (int)(plane / p.C);
+        int grp = n * (p.C / p.cpg) + c / p.cpg;
+        float mean = p.stats[grp * 2], rstd = p.stats[grp * 2 + 1];
+        float g = p.gamma[c], b = p.beta[c];
+        bool has2 = p.w2 != nullptr, has_res = p.residual != nullptr;
+        float w2 = has2 ? p.w2[c] : 1.0f, b2 = has2 ? p.b2[c] : 0.0f;
+        size_t o = t * VW;
+        if (VW == 4) {
+            float4 xv = *reinterpret_cast<const float4 *>(p.x + o);
+            float4 rv = has_res ? *reinterpret_cast<const float4 *>(p.residual + o) : make_float4(0, 0, 0, 0);
+            float4 out;
+            out.x = gn_value(p, xv.x, mean, rstd, g, b, w2, b2, has2, rv.x, has_res);
+            out.y = gn_value(p, xv.y, mean, rstd, g, b, w2, b2, has2, rv.y, has_res);
+            out.z = gn_value(p, xv.z, mean, rstd, g, b, w2, b2, has2, rv.z, has_res);
+            out.w = gn_value(p, xv.w, mean, rstd, g, b, w2, b2, has2, rv.w, has_res);
+            *reinterpret_cast<float4 *>(p.y + o) = out;
+            mbits = max(max(range_bits(out.x), range_bits(out.y)), max(range_bits(out.z), range_bits(out.w)));
+        } else {
+            const float v = gn_value(p, p.x[o], mean, rstd, g, b, w2, b2, has2, has_res ? p.residual[o] : 0.0f, has_res);
+            p.y[o] = v;
+            mbits = range_bits(v);
+        }
     }
+    if (p.range) range_note(mbits, p.range);  // all lanes arrive (block-uniform condition)
 }
 
 // apply + AvgPool3d(2,2): one thread per pooled output element (sum order kd,kh,kw then /8 like ATen).
 __global__ void __launch_bounds__(256) gn_apply_pool_kernel(GnParams p, int D, int H, int W, size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
+    unsigned mbits = 0;
+    if (t < total) {
     const int oD = D / 2, oH = H / 2, oW = W / 2;
     int ow = (int)(t % oW);
     size_t r = t / oW;
@@ -237,6 +245,9 @@ __global__ void __launch_bounds__(256) gn_apply_pool_kernel(GnParams p, int D, i
             s += gn_value(p, xv.y, mean, rstd, g, b, w2, b2, has2, rv.y, has_res);
         }
     p.y[t] = s / 8.0f;
+    mbits = range_bits(s / 8.0f);
+    }
+    if (p.range) range_note(mbits, p.range);
 }
 
 // General apply for small tensors: x and/or the residual may still be split-K slabs (value = bias[c] +
@@ -256,8 +267,9 @@ __device__ __forceinline__ float split_value(const float *__restrict__ x, int sp
 
 __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, size_t total) {
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
     const GnParams &p = q.p;
+    unsigned mbits = 0;
+    if (t < total) {
     const int oD = q.pool2 ? q.D / 2 : q.D * q.uD, oH = q.pool2 ? q.H / 2 : q.H * q.uH, oW = q.pool2 ? q.W / 2 : q.W * q.uW;
     int ow = (int)(t % oW);
     size_t r = t / oW;
@@ -286,12 +298,17 @@ __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, si
                     s += gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
                 }
         p.y[t] = s / 8.0f;
+        mbits = range_bits(s / 8.0f);
     } else {
         size_t o = pbase + ((size_t)(od / q.uD) * q.H + oh / q.uH) * q.W + ow / q.uW;
         float xv = split_value(p.x, q.x_splits, q.slab, o, xb);
         float rv = has_res ? split_value(p.residual, q.res_splits, q.slab, o, rb) : 0.0f;
-        p.y[t] = gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
+        const float v = gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
+        p.y[t] = v;
+        mbits = range_bits(v);
     }
+    }
+    if (p.range) range_note(mbits, p.range);
 }
 
 // Tiny tensors (FlowField: a (sample, group) span of <= GN_FUSED_MAX floats): statistics AND apply in one
@@ -350,6 +367,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
     const int oH = q.H * q.uH, oW = q.W * q.uW, oD = q.D * q.uD;
     const size_t oS = (size_t)oD * oH * oW;
     const int n_c0 = (int)(base / S);  // global (n*C + c) index of the group's first channel plane
+    unsigned mbits = 0;
     for (int e = threadIdx.x; e < cnt; e += nthr) {
         const int c = shift >= 0 ? (e >> shift) : e / S;
         const int i = e - c * S;
@@ -361,6 +379,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
         }
         const float v = gn_value(p, vals[e], mean, rstd, p.gamma[ch], p.beta[ch], has2 ? p.w2[ch] : 1.0f,
                                  has2 ? p.b2[ch] : 0.0f, has2, rv, has_res);
+        mbits = max(mbits, range_bits(v));
         const int d = i / HW, h = (i / q.W) % q.H, w = i % q.W;
         float *dst = p.y + (size_t)(n_c0 + c) * oS;
         for (int a = 0; a < q.uD; ++a)
@@ -368,6 +387,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
                 for (int cc = 0; cc < q.uW; ++cc)
                     dst[((size_t)(d * q.uD + a) * oH + h * q.uH + b) * oW + w * q.uW + cc] = v;
     }
+    if (p.range) range_note(mbits, p.range);
 }
 
 __global__ void __launch_bounds__(256) avgpool2_kernel(const float *__restrict__ x, float *__restrict__ y, int D,
@@ -697,13 +717,14 @@ extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C,
 }
 
 extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,
-                                     const float *w2, const float *b2, const float *residual, float *y, int N, int C,
-                                     int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream) {
+                                     const float *w2, const float *b2, const float *residual, float *y, float *out_range, int N,
+                                     int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream) {
     MPHIP_REQUIRE(x && stats && gamma && beta && y, "groupnorm_apply: null pointer");
     MPHIP_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && G > 0 && C % G == 0, "groupnorm_apply: bad dims");
     MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_apply: w2/b2 must both be set or both NULL");
-    GnParams p{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_};
+    GnParams p{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_, out_range};
     hipStream_t s = (hipStream_t)stream;
+    if (out_range) zero_fill(out_range, 16, s);
     const int S = D * H * W;
     if (pool2) {
         MPHIP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "groupnorm_apply: pool2 needs even D,H,W");
@@ -719,32 +740,46 @@ extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const f
     return check_launch("groupnorm_apply");
 }
 
-// table[n][c] = (scale, shift) with GroupNorm(+AdaptiveGroupNorm's second affine) folded to y = x*scale + shift
+// table[n][c] = (scale, shift) with GroupNorm(+AdaptiveGroupNorm's second affine) folded to y = x*scale + shift.
+// range: a rigorous bound of max|y| that needs no pass over x — the normalised value obeys |x - mean| * rstd <= sqrt(Ng)
+// (Ng = elements per group: sum (x-mean)^2 = Ng*var, rstd = 1/sqrt(var+eps)), so |y[c]| <= sqrt(Ng)*|gamma*w2| + |beta*w2 + b2|.
+// Loose by ~100x for real activations, which costs nothing: the f16x3 split still resolves 2^-24 of the bound.
 __global__ void gn_affine_table_kernel(const float *__restrict__ stats, const float *__restrict__ gamma,
                                        const float *__restrict__ beta, const float *__restrict__ w2,
-                                       const float *__restrict__ b2, float *__restrict__ table, int N, int C, int cpg) {
+                                       const float *__restrict__ b2, float *__restrict__ table, float *__restrict__ range, int N,
+                                       int C, int cpg, float sqrt_ng) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * C) return;
-    const int c = i % C, n = i / C;
-    const int grp = n * (C / cpg) + c / cpg;
-    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
-    float scale = rstd * gamma[c];
-    float shift = beta[c] - mean * scale;
-    if (w2) {
-        scale = scale * w2[c];
-        shift = shift * w2[c] + b2[c];
+    unsigned mbits = 0;
+    if (i < N * C) {
+        const int c = i % C, n = i / C;
+        const int grp = n * (C / cpg) + c / cpg;
+        const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+        float scale = rstd * gamma[c];
+        float shift = beta[c] - mean * scale;
+        float amp = gamma[c], off = beta[c];
+        if (w2) {
+            scale = scale * w2[c];
+            shift = shift * w2[c] + b2[c];
+            amp = amp * w2[c];
+            off = off * w2[c] + b2[c];
+        }
+        table[i * 2] = scale;
+        table[i * 2 + 1] = shift;
+        mbits = range_bits((sqrt_ng * fabsf(amp) + fabsf(off)) * 1.0001f);
     }
-    table[i * 2] = scale;
-    table[i * 2 + 1] = shift;
+    if (range) range_note(mbits, range);
 }
 
 extern "C" int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const float *beta, const float *w2,
-                                            const float *b2, float *table, int N, int C, int G, void *stream) {
+                                            const float *b2, float *table, float *out_range, int N, int C, int S, int G,
+                                            void *stream) {
     MPHIP_REQUIRE(stats && gamma && beta && table, "groupnorm_affine_table: null pointer");
-    MPHIP_REQUIRE(N > 0 && C > 0 && G > 0 && C % G == 0, "groupnorm_affine_table: bad dims");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_affine_table: bad dims");
     MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_affine_table: w2/b2 must both be set or both NULL");
-    hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, (hipStream_t)stream, stats, gamma,
-                       beta, w2, b2, table, N, C, C / G);
+    hipStream_t s = (hipStream_t)stream;
+    if (out_range) zero_fill(out_range, 16, s);
+    hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, stats, gamma, beta, w2, b2, table,
+                       out_range, N, C, C / G, sqrtf((float)(C / G) * (float)S));
     return check_launch("groupnorm_affine_table");
 }
 
@@ -761,17 +796,18 @@ extern "C" int mphip_groupnorm_stats_split(const float *x, int x_splits, const f
 
 extern "C" int mphip_groupnorm_apply_split(const float *x, int x_splits, const float *x_bias, const float *stats,
                                            const float *gamma, const float *beta, const float *w2, const float *b2,
-                                           const float *residual, int res_splits, const float *res_bias, float *y, int N,
-                                           int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, int uD,
-                                           int uH, int uW, void *stream) {
+                                           const float *residual, int res_splits, const float *res_bias, float *y,
+                                           float *out_range, int N, int C, int D, int H, int W, int G, int relu, int tanh_,
+                                           int pool2, int uD, int uH, int uW, void *stream) {
     MPHIP_REQUIRE(x && stats && gamma && beta && y, "groupnorm_apply_split: null pointer");
     MPHIP_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && G > 0 && C % G == 0, "groupnorm_apply_split: bad dims");
     MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_apply_split: w2/b2 must both be set or both NULL");
     MPHIP_REQUIRE(x_splits >= 1 && res_splits >= 1 && uD >= 1 && uH >= 1 && uW >= 1, "groupnorm_apply_split: bad split/up");
     MPHIP_REQUIRE(!(pool2 && (uD * uH * uW != 1)), "groupnorm_apply_split: pool2 and upsampling are exclusive");
     MPHIP_REQUIRE(!pool2 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "groupnorm_apply_split: pool2 needs even D,H,W");
-    GnSplitParams q{{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_}, x_splits, res_splits,
+    GnSplitParams q{{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_, out_range}, x_splits, res_splits,
                     (size_t)N * C * D * H * W, x_bias, res_bias, D, H, W, pool2, uD, uH, uW};
+    if (out_range) zero_fill(out_range, 16, (hipStream_t)stream);
     size_t total = pool2 ? (size_t)N * C * (D / 2) * (H / 2) * (W / 2) : (size_t)N * C * D * uD * H * uH * W * uW;
     hipLaunchKernelGGL(gn_apply_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, q, total);
     return check_launch("groupnorm_apply_split");

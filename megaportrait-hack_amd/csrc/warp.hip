@@ -302,7 +302,8 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
 // K2: a workgroup owns 1024 consecutive (h,w) positions of one (b,d) plane, 4 consecutive w per
 // thread (16-byte stores, a wave writes 1 KB contiguous), all C channels.
 __global__ void __launch_bounds__(256)
-warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out, int B,
+warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                   float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */, int B,
                    int C, int D, int H, int W) {
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
@@ -340,6 +341,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     const int cs_max = bvol > 0 ? STAGE_FLOATS / bvol : 0;  // channels that fit one pass of the planar image
     const float *vb = v + (size_t)b * C * vol;
     float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
+    unsigned mbits = 0;
 
     if (cs_max >= 8 || cs_max >= C) {  // block-uniform
         TapOff lt[4];
@@ -359,6 +361,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
                     r.x = gather8_lds(src, lt[0], taps[0].w); r.y = gather8_lds(src, lt[1], taps[1].w);
                     r.z = gather8_lds(src, lt[2], taps[2].w); r.w = gather8_lds(src, lt[3], taps[3].w);
                     *reinterpret_cast<float4 *>(ob + (size_t)(c0 + c) * vol) = r;
+                    mbits = max(max(mbits, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
                 }
             }
         }
@@ -369,8 +372,10 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
             r.x = gather8(src, taps[0]); r.y = gather8(src, taps[1]);
             r.z = gather8(src, taps[2]); r.w = gather8(src, taps[3]);
             *reinterpret_cast<float4 *>(ob + (size_t)c * vol) = r;
+            mbits = max(max(mbits, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
         }
     }
+    if (out_range) range_note(mbits, out_range);
 }
 
 // K3: a workgroup owns 256 consecutive (h,w) positions of one frame and CPB channels; every thread
@@ -503,8 +508,8 @@ static int launch_coords(const float *field, const float *lin_d, const float *li
 }
 
 extern "C" int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
-                                 const float *lin_w, float *out, float *coords_out, int32_t *idx_out, int B, int C,
-                                 int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
+                                 const float *lin_w, float *out, float *coords_out, int32_t *idx_out, float *out_range, int B,
+                                 int C, int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
                                  void *stream) {
     int rc = check_warp_args("warp_volume", v, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
     if (rc) return rc;
@@ -521,10 +526,15 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     hipStream_t s = (hipStream_t)stream;
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
+    if (out_range && W % 4 != 0) {   // (the scalar fallback kernel does not fold the maximum in)
+        rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);   // the warp is a convex combination: max|out| <= max|v|
+        if (rc) return rc;
+    }
     if (W % 4 == 0) {
         const int tiles = (H * W + 1023) / 1024;
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)((size_t)B * D * tiles)), dim3(256), 0, s, v, coords, out, B,
-                           C, D, H, W);
+        if (out_range) zero_fill(out_range, 16, s);
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)((size_t)B * D * tiles)), dim3(256), 0, s, v, coords, out, out_range,
+                           B, C, D, H, W);
     } else {
         const int cpb = C >= 48 ? 12 : C;
         hipLaunchKernelGGL(warp_gather_scalar_kernel, dim3(cdiv((size_t)B * D * H * W, 256), cdiv(C, cpb)), dim3(256), 0, s,

@@ -57,8 +57,13 @@ _packs = _PackCache()
 def compute_rt_warp(rotation, translation, invert=False, grid_size=64):
     """model.py:777-809 — rigid warp grid [B,3,G,G,G] (x,y,z channels)."""
     rotation, translation = _f32(rotation, translation)
-    theta = ops.rt_theta(rotation, translation, invert)
     zero_em = torch.zeros((rotation.shape[0], 3, 1, 1, 1), dtype=torch.float32, device=rotation.device)
+    if torch.is_grad_enabled() and (rotation.requires_grad or translation.requires_grad):
+        # un-swapped reference code that calls this under autograd (the reference's own WarpGenerator*.forward, model.py:965,
+        # 1016, when only integration.patch_functions ran): rt + resize(0) == rt exactly, with the gradient to R and t
+        theta = ag.RtThetaFn.apply(rotation, translation, bool(invert))
+        return ag.WarpFieldComposeFn.apply(theta, zero_em, grid_size)
+    theta = ops.rt_theta(rotation, translation, invert)
     _, rt, _ = ops.warp_field_compose(theta, zero_em, grid_size, parts=True)
     return rt
 

@@ -39,6 +39,42 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+# ------------------------------------------------------------------ range descriptors (f16x3 operand scales)
+# include/mphip.h "Range descriptors": 4 floats on the device per tensor; the f16x3 conv kernels scale their input by the
+# power of two it implies, so activations of any magnitude keep fp32-class accuracy and nothing is ever clamped.  Kernels
+# that already stream a tensor (warp gather, GroupNorm apply) fill the descriptor of their output for free; it rides on the
+# torch.Tensor object as an attribute, guarded by the tensor's version counter (an in-place write invalidates it).
+_RANGES_ENABLED = _os.environ.get("MPHIP_FUSED_RANGES", "1") != "0"  # dev switch: 0 = every f16x3 conv measures its own input
+
+
+def new_range(device) -> torch.Tensor:
+    return torch.empty(4, dtype=torch.float32, device=device)  # zeroed / filled by the kernel call it is handed to
+
+
+def tag_range(t: torch.Tensor, rng: Optional[torch.Tensor]) -> torch.Tensor:
+    if rng is not None:
+        t._mphip_range = (rng, t._version)
+    return t
+
+
+def tensor_range(t: torch.Tensor) -> Optional[torch.Tensor]:
+    hit = getattr(t, "_mphip_range", None)
+    return hit[0] if (hit is not None and hit[1] == t._version) else None
+
+
+def absmax_range(x: torch.Tensor) -> torch.Tensor:
+    """Range descriptor of a tensor of unknown origin: one streaming pass (mphip_absmax_range); cached on the tensor."""
+    x = _req(x, "x")
+    rng = new_range(x.device)
+    _lib.check(_lib.load().mphip_absmax_range(_ptr(x), x.numel(), _ptr(rng), _stream()), "mphip_absmax_range")
+    tag_range(x, rng)
+    return rng
+
+
+def _range_for(x: torch.Tensor, given: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return given if given is not None else (tensor_range(x) if tensor_range(x) is not None else absmax_range(x))
+
+
 # ------------------------------------------------------------------ host-built tables
 _tables = {}
 _captured = None
@@ -124,6 +160,7 @@ def warp_volume(v: torch.Tensor, field: torch.Tensor, return_coords: bool = Fals
         raise RuntimeError(f"warp_volume: bad shapes v={tuple(v.shape)} field={tuple(field.shape)}")
     b, c, d, h, w = v.shape
     out = torch.empty_like(v)
+    rng = new_range(v.device) if _RANGES_ENABLED else None
     coords = idx = None
     if return_coords:
         coords = torch.empty((b, d, h, w, 3), dtype=torch.float32, device=v.device)
@@ -133,9 +170,10 @@ def warp_volume(v: torch.Tensor, field: torch.Tensor, return_coords: bool = Fals
     ws_bytes = 0 if return_coords else lib.mphip_warp_workspace_bytes(b, d, h, w)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev) if ws_bytes else None
     _lib.check(lib.mphip_warp_volume(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
-                                     _ptr(linspace_table(w, dev)), _ptr(out), _ptr(coords), _ptr(idx), b, c, d, h, w,
+                                     _ptr(linspace_table(w, dev)), _ptr(out), _ptr(coords), _ptr(idx), _ptr(rng), b, c, d, h, w,
                                      field.shape[2], field.shape[3], field.shape[4], _ptr(ws), ws_bytes, _stream()),
                "mphip_warp_volume")
+    tag_range(out, rng)
     return (out, coords, idx) if return_coords else out
 
 
@@ -179,8 +217,9 @@ def get_conv_precision() -> int:
 
 
 def f16x3_saturation_count(reset: bool = False) -> int:
-    """Elements the f16x3 conv kernels clamped (|x| >= 4062 forward) since the last reset — 0 unless an activation left
-    the range the split-f16 arithmetic covers, in which case those results are wrong: use set_conv_precision('fp32').
+    """Operand elements of the f16x3 conv kernels whose scaled value was outside the f16 range since the last reset: Inf /
+    NaN inputs (or finite values beyond a stale, hand-supplied range descriptor).  They are not clamped — the result
+    carries Inf/NaN like the reference's fp32 conv — this only counts them.  0 in normal operation.
     Synchronises the device (a diagnostic, not for the hot loop)."""
     c = ctypes.c_ulonglong(0)
     _lib.check(_lib.load().mphip_f16x3_saturation_count(ctypes.byref(c), int(reset)), "mphip_f16x3_saturation_count")
@@ -278,7 +317,7 @@ def set_conv_hook(hook) -> None:
 
 
 def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_groups: Optional[int] = None,
-           gn_eps: float = 1e-5):
+           gn_eps: float = 1e-5, x_range: Optional[torch.Tensor] = None):
     """y = conv(x).  With gn_groups, also returns the (mean, rstd) statistics of y for the GroupNorm that
     follows (one fused pass for split-K convs): -> (y, stats)."""
     x = _req(x, "x")
@@ -290,6 +329,7 @@ def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_
     if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc.co, d, h, w, pc.k, prec):
         prec = 0  # shape outside the fast kernel's tiling: the exact fp32 kernel handles every shape
     wp = pc.packed(prec)
+    xr = _range_for(x, x_range) if prec == 1 else None   # f16x3: the input's own operand scale
     if gn_groups:
         ws_bytes = lib.mphip_conv3d_gn_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, prec, gn_groups)
         stats = torch.empty((n * gn_groups, 2), dtype=torch.float32, device=x.device)
@@ -301,11 +341,11 @@ def conv3d(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = None, gn_
 
     def launch():
         if gn_groups:
-            _lib.check(lib.mphip_conv3d_gn_fwd(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(stats), n, ci, pc.co, d, h, w,
+            _lib.check(lib.mphip_conv3d_gn_fwd(_ptr(x), _ptr(xr), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(stats), n, ci, pc.co, d, h, w,
                                                pc.k, prec, gn_groups, gn_eps, _ptr(ws), ws_bytes, _stream()),
                        "mphip_conv3d_gn_fwd")
         else:
-            _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, prec,
+            _lib.check(lib.mphip_conv3d_fwd(_ptr(x), _ptr(xr), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d, h, w, pc.k, prec,
                                             _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd")
         return y
 
@@ -336,8 +376,9 @@ def conv3d_gn_in(x: torch.Tensor, stats: torch.Tensor, gamma, beta, groups: int,
     if w2 is not None:
         w2, b2 = _req(w2.detach(), "w2").reshape(-1), _req(b2.detach(), "b2").reshape(-1)
     table = torch.empty((n, ci, 2), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphip_groupnorm_affine_table(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(table), n, ci,
-                                                groups, _stream()), "mphip_groupnorm_affine_table")
+    xr = new_range(x.device)  # range of the NORMALISED tensor the conv sees (a data-independent bound, see include/mphip.h)
+    _lib.check(lib.mphip_groupnorm_affine_table(_ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(table), _ptr(xr), n,
+                                                ci, d * h * w, groups, _stream()), "mphip_groupnorm_affine_table")
     wp = pc.packed(1)
     if out_gn_groups:
         ws_bytes = lib.mphip_conv3d_gn_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, 1, out_gn_groups)
@@ -350,11 +391,11 @@ def conv3d_gn_in(x: torch.Tensor, stats: torch.Tensor, gamma, beta, groups: int,
 
     def launch():
         if out_gn_groups:
-            _lib.check(lib.mphip_conv3d_gnin_gn_fwd(_ptr(x), _ptr(table), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(out_stats),
+            _lib.check(lib.mphip_conv3d_gnin_gn_fwd(_ptr(x), _ptr(table), _ptr(xr), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(out_stats),
                                                     n, ci, pc.co, d, h, w, pc.k, 1, out_gn_groups, out_gn_eps, _ptr(ws), ws_bytes,
                                                     _stream()), "mphip_conv3d_gnin_gn_fwd")
         else:
-            _lib.check(lib.mphip_conv3d_gnin_fwd(_ptr(x), _ptr(table), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d,
+            _lib.check(lib.mphip_conv3d_gnin_fwd(_ptr(x), _ptr(table), _ptr(xr), int(relu), _ptr(wp), _ptr(pc.bias), _ptr(y), n, ci, pc.co, d,
                                                  h, w, pc.k, 1, _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_gnin_fwd")
         return y
 
@@ -400,10 +441,11 @@ def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = Non
         return ConvOut(y, 1, None, shape, st, gn_groups)
     out = torch.empty((splits,) + shape if splits > 1 else shape, dtype=torch.float32, device=x.device)
     wp = pc.packed(prec)
+    xr = _range_for(x) if prec == 1 else None
 
     def launch():
-        _lib.check(lib.mphip_conv3d_fwd_split(_ptr(x), _ptr(wp), _ptr(pc.bias), _ptr(out), n, ci, pc.co, d, h, w, pc.k, prec,
-                                              _stream()), "mphip_conv3d_fwd_split")
+        _lib.check(lib.mphip_conv3d_fwd_split(_ptr(x), _ptr(xr), _ptr(wp), _ptr(pc.bias), _ptr(out), n, ci, pc.co, d, h, w, pc.k,
+                                              prec, None, 0, _stream()), "mphip_conv3d_fwd_split")
         return out
 
     if _conv_hook is not None:
@@ -481,17 +523,19 @@ def groupnorm_apply(x, stats, gamma, beta, groups: int, w2=None, b2=None, residu
     else:
         oshape = (n, c, d * up[0], h * up[1], w * up[2])
     y = torch.empty(oshape, dtype=torch.float32, device=xt.device)
+    rng = new_range(xt.device) if _RANGES_ENABLED else None  # max|y| rides along: the next f16x3 conv's operand scale
     if general:
         xb = x.bias if isinstance(x, ConvOut) else None
         rb = residual.bias if isinstance(residual, ConvOut) else None
         _lib.check(lib.mphip_groupnorm_apply_split(_ptr(xt), xs, _ptr(xb), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2),
-                                                   _ptr(rt), rs, _ptr(rb), _ptr(y), n, c, d, h, w, groups, int(relu), int(tanh),
-                                                   int(pool2), up[0], up[1], up[2], _stream()), "mphip_groupnorm_apply_split")
+                                                   _ptr(rt), rs, _ptr(rb), _ptr(y), _ptr(rng), n, c, d, h, w, groups, int(relu),
+                                                   int(tanh), int(pool2), up[0], up[1], up[2], _stream()),
+                   "mphip_groupnorm_apply_split")
     else:
         _lib.check(lib.mphip_groupnorm_apply(_ptr(xt), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(b2), _ptr(rt),
-                                             _ptr(y), n, c, d, h, w, groups, int(relu), int(tanh), int(pool2), _stream()),
-                   "mphip_groupnorm_apply")
-    return y
+                                             _ptr(y), _ptr(rng), n, c, d, h, w, groups, int(relu), int(tanh), int(pool2),
+                                             _stream()), "mphip_groupnorm_apply")
+    return tag_range(y, rng)
 
 
 _GN_FUSED_MAX_SPAN = 12288  # floats per (sample, group): LDS cache of the one-launch GroupNorm
@@ -540,7 +584,7 @@ def avgpool2(x: torch.Tensor) -> torch.Tensor:
     n, c, d, h, w = x.shape
     y = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().mphip_avgpool2(_ptr(x), _ptr(y), n * c, d, h, w, _stream()), "mphip_avgpool2")
-    return y
+    return tag_range(y, tensor_range(x))  # an average: max|y| <= max|x|
 
 
 def upsample_trilinear2(x: torch.Tensor) -> torch.Tensor:
@@ -549,7 +593,7 @@ def upsample_trilinear2(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty((n, c, 2 * d, 2 * h, 2 * w), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().mphip_upsample_trilinear2(_ptr(x), _ptr(y), n * c, d, h, w, _stream()),
                "mphip_upsample_trilinear2")
-    return y
+    return tag_range(y, tensor_range(x))  # convex combinations of x: max|y| <= max|x|
 
 
 def upsample_nearest(x: torch.Tensor, scale: Tuple[int, int, int]) -> torch.Tensor:
@@ -559,7 +603,7 @@ def upsample_nearest(x: torch.Tensor, scale: Tuple[int, int, int]) -> torch.Tens
     y = torch.empty((n, c, d * sd, h * sh, w * sw), dtype=torch.float32, device=x.device)
     _lib.check(_lib.load().mphip_upsample_nearest(_ptr(x), _ptr(y), n * c, d, h, w, sd, sh, sw, _stream()),
                "mphip_upsample_nearest")
-    return y
+    return tag_range(y, tensor_range(x))
 
 
 # ------------------------------------------------------------------ K8
@@ -615,7 +659,7 @@ def conv3d_bwd_data(dy: torch.Tensor, pc_t: "PackedConv", dy_scale: torch.Tensor
 
 
 def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, dy_scale: Optional[torch.Tensor] = None,
-                      precision: Optional[int] = None) -> torch.Tensor:
+                      precision: Optional[int] = None, x_range: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW [Co,Ci,k,k,k] of y = conv3d(x, W, b, padding=k//2) given dy.  precision 1 (f16x3) needs dy_scale (grad_prep)."""
     x, dy = _req(x, "x"), _req(dy, "dy")
     n, ci, d, h, w = x.shape
@@ -631,8 +675,9 @@ def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, dy_scale: Optio
         raise RuntimeError(f"conv3d_bwd_weight: unsupported shape {tuple(x.shape)} k={k}")
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.device)
-    _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(dy), _ptr(dy_scale), _ptr(dw), n, ci, co, d, h, w, k, prec, _ptr(ws),
-                                           ws_bytes, _stream()), "mphip_conv3d_bwd_weight")
+    xr = (x_range if x_range is not None else tensor_range(x)) if prec == 1 else None   # None: the library measures x itself
+    _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(xr), _ptr(dy), _ptr(dy_scale), _ptr(dw), n, ci, co, d, h, w, k, prec,
+                                           _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_bwd_weight")
     return dw
 
 

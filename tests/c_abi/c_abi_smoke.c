@@ -60,7 +60,7 @@ int main(void) {
     if (mphip_pack_conv_weight(dw, dwp, Co, Ci, 1, 0, stream)) { fprintf(stderr, "pack: %s\n", mphip_last_error()); return 1; }
     size_t wbytes = mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, 1, 0);
     if (wbytes) CHECK_HIP(hipMalloc(&dws, wbytes));
-    if (mphip_conv3d_fwd(dx, dwp, db, dy, N, Ci, Co, D, H, W, 1, 0, dws, wbytes, stream)) {
+    if (mphip_conv3d_fwd(dx, NULL, dwp, db, dy, N, Ci, Co, D, H, W, 1, 0, dws, wbytes, stream)) {
         fprintf(stderr, "conv: %s\n", mphip_last_error());
         return 1;
     }
@@ -89,7 +89,7 @@ int main(void) {
     printf("avgpool2 max-abs error vs host reference: %.3e\n", worst);
     if (!(worst < 1e-6)) return 1;
     /* error convention: negative code, message, no crash, nothing launched */
-    int rc = mphip_conv3d_fwd(dx, dwp, db, dy, N, Ci, Co, D, H, W, 2, 0, dws, wbytes, stream);
+    int rc = mphip_conv3d_fwd(dx, NULL, dwp, db, dy, N, Ci, Co, D, H, W, 2, 0, dws, wbytes, stream);
     if (rc != MPHIP_EINVAL || strlen(mphip_last_error()) == 0) { fprintf(stderr, "expected MPHIP_EINVAL, got %d\n", rc); return 1; }
     rc = mphip_groupnorm_stats(dy, (float *)dp, N, Co, S, 4, 1e-5f, NULL, 0, stream);
     if (rc != MPHIP_EWORKSPACE) { fprintf(stderr, "expected MPHIP_EWORKSPACE, got %d (%s)\n", rc, mphip_last_error()); return 1; }

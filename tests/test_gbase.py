@@ -284,4 +284,5 @@ def test_gbase_full_size_contract_and_reenact(G):
         fast = g.reenact(xs, xd, chunk=2)
         assert maxabs(fast, img.cpu()) < 1e-4
         parts = [g.reenact(xs, xd, chunk=2, rank=r, world=2) for r in range(2)]
-        assert [p.shape[0] for p in parts] == [2, 1] and torch.equal(torch.cat(parts), fast)
+        assert [p.shape[0] for p in parts] == [2, 1]
+        assert maxabs(torch.cat(parts), fast.cpu()) < 1e-5      # (MIOpen's 2D convs are not bitwise reproducible run to run)

@@ -590,21 +590,100 @@ def test_empty_frame_shard(hot, dev):
     assert out.shape == (0, 96, 64, 64)
 
 
-def test_f16x3_range_guard(ops, dev):
-    """Activations beyond the split-f16 range are clamped (finite, wrong) — and counted, so a caller can tell."""
+def test_f16x3_accepts_any_magnitude(ops, dev):
+    """The f16x3 conv scales every operand tensor by its own power of two (range descriptors, include/mphip.h): planted
+    outliers far beyond the old fixed-scale cliff (|x| >= 4062), tiny tensors and huge tensors all stay fp32-class, and
+    nothing is clamped (saturation count 0) — like the reference's fp32 nn.Conv3d, which has no range cliff."""
     x = R.seeded_tensor((1, 96, 4, 8, 16), 831, scale=1.7)
-    pc = ops.PackedConv(R.seeded_tensor((96, 96, 3, 3, 3), 832, scale=0.02).to(dev), None)
+    w = R.seeded_tensor((96, 96, 3, 3, 3), 832, scale=0.02)
+    pc = ops.PackedConv(w.to(dev), None)
     ops.f16x3_saturation_count(reset=True)
-    ops.conv3d(x.to(dev), pc, precision=1)
-    assert ops.f16x3_saturation_count() == 0
+
+    def check(xin, label):
+        got = ops.conv3d(xin.to(dev), pc, precision=1)
+        truth = F.conv3d(xin.double(), w.double(), None, padding=1)
+        exact = ops.conv3d(xin.to(dev), pc, precision=0)
+        scale = truth.abs().max().item()
+        e1 = (got.cpu().double() - truth).abs().max().item() / scale
+        e0 = (exact.cpu().double() - truth).abs().max().item() / scale
+        assert e1 < max(2.0 * e0, 2e-6), (label, e1, e0)        # no worse than twice the exact fp32 kernel's own rounding
+        return got
+
+    check(x, "O(1)")
     big = x.clone()
-    big[0, 5, 2, 3, 7] = 5000.0
-    y = ops.conv3d(big.to(dev), pc, precision=1)
-    assert torch.isfinite(y).all()
-    assert ops.f16x3_saturation_count(reset=True) >= 1
+    big[0, 5, 2, 3, 7] = 1.0e5                                   # 25x beyond where the fixed scale used to clamp
+    check(big, "planted 1e5")
+    check(x * 1.0e-6, "tiny tensor")                             # a fixed scale would push the lo halves into f16 subnormals
+    check(x * 3.0e7, "huge tensor")
     assert ops.f16x3_saturation_count() == 0
-    want = F.conv3d(big, pc.weight.cpu(), None, padding=1)
-    assert maxabs(ops.conv3d(big.to(dev), pc, precision=0), want) < 1e-3     # the exact kernel has no such limit
+    # a stale range is never used: an in-place write bumps the tensor's version and the descriptor is re-measured
+    xd = x.to(dev)
+    ops.conv3d(xd, pc, precision=1)
+    r0 = ops.tensor_range(xd)
+    assert r0 is not None
+    xd.mul_(1.0e4)
+    assert ops.tensor_range(xd) is None
+    y = ops.conv3d(xd, pc, precision=1)
+    assert torch.isfinite(y).all() and ops.f16x3_saturation_count() == 0
+
+
+def test_f16x3_propagates_non_finite(ops, dev):
+    """Inf / NaN inputs are not clamped to finite values: they reach the output as Inf/NaN exactly where the
+    fp32 reference conv puts them, forward and backward (an overflowed gradient must stay visible to GradScaler,
+    train.py:145,318-320), and the diagnostic counter sees them."""
+    x = R.seeded_tensor((1, 96, 4, 8, 16), 833, scale=1.7)
+    w = R.seeded_tensor((96, 96, 3, 3, 3), 834, scale=0.02)
+    pc = ops.PackedConv(w.to(dev), None)
+    for bad in (float("nan"), float("inf")):
+        xb = x.clone()
+        xb[0, 7, 1, 4, 9] = bad
+        ops.f16x3_saturation_count(reset=True)
+        got = ops.conv3d(xb.to(dev), pc, precision=1).cpu()
+        want = F.conv3d(xb, w, None, padding=1)
+        assert torch.equal(torch.isfinite(got), torch.isfinite(want))          # the same voxels are poisoned, no others
+        assert (got[torch.isfinite(want)] - want[torch.isfinite(want)]).abs().max().item() < 1e-4
+        assert ops.f16x3_saturation_count(reset=True) >= 1
+        # backward: a non-finite dy poisons dx and dw instead of being clamped
+        dyb = x.clone()
+        dyb[0, 3, 2, 2, 2] = bad
+        _, scale = ops.grad_prep(dyb.to(dev), want_bias=False)
+        dw = ops.conv3d_bwd_weight(x.to(dev), dyb.to(dev), 3, dy_scale=scale, precision=1)
+        assert not torch.isfinite(dw[3]).all() and torch.isfinite(dw[4]).all()
+        pt = ops.PackedConv(w.to(dev), None, transposed=True)
+        dx = ops.conv3d_bwd_data(dyb.to(dev), pt, scale, precision=1)
+        assert not torch.isfinite(dx).all()
+
+
+def test_hot_slice_with_unnormalised_activations(dev, hot, sd, M, ops):
+    """G3d's first conv and Eapp's tail see UN-normalised activations of a trained checkpoint.  Plant 1e5
+    in `vs` (inside the 4^3 corner the reference's warp samples) and scale Eapp's input by 1e4: the f16x3 path stays within
+    the fp32 reference's own rounding of these ill-scaled problems (both measured against a float64 evaluation of the
+    oracle) and never saturates."""
+    inp = R.seeded_hot_inputs(1, INPUT_SEED)
+    inp["vs"] = inp["vs"].clone()
+    inp["vs"][0, 5, 1, 2, 3] = 1.0e5
+    ops.f16x3_saturation_count(reset=True)
+    with torch.no_grad():
+        got = hot(**{k: v.to(dev) for k, v in inp.items()}).cpu().double()
+        truth = R.hot_slice(sd={k: v.double() for k, v in sd.items()}, **{k: v.double() for k, v in inp.items()})
+        cpu32 = R.hot_slice(sd=sd, **inp).double()
+    e_hip, e_cpu = (got - truth).abs().max().item(), (cpu32 - truth).abs().max().item()
+    print(f"planted 1e5 in vs: HIP {e_hip:.3e}  fp32 CPU oracle {e_cpu:.3e} vs float64 (|out|max {truth.abs().max():.2f})")
+    assert e_hip < max(1e-3, 3.0 * e_cpu)
+    assert ops.f16x3_saturation_count() == 0
+    sd_t = R.seeded_state_dict(R.eapp_tail_shapes(), WEIGHT_SEED + 10, "appearanceEncoder.")
+    tail = M.Eapp3DTail()
+    tail.load_state_dict({k[len("appearanceEncoder."):]: v for k, v in sd_t.items()}, strict=True)
+    tail = tail.to(dev).eval()
+    feat = R.seeded_tensor((1, 1536, 16, 16), 110, scale=1.7) * 1.0e4
+    with torch.no_grad():
+        got = tail(feat.to(dev)).cpu().double()
+        truth = R.eapp_tail3d(feat.double(), {k: v.double() for k, v in sd_t.items()})
+        cpu32 = R.eapp_tail3d(feat, sd_t).double()
+    e_hip, e_cpu = (got - truth).abs().max().item(), (cpu32 - truth).abs().max().item()
+    print(f"Eapp tail on 1e4-scaled input: HIP {e_hip:.3e}  fp32 CPU oracle {e_cpu:.3e} vs float64")
+    assert e_hip < max(1e-3, 3.0 * e_cpu)
+    assert ops.f16x3_saturation_count() == 0
 
 
 def test_c_abi_from_plain_c(c_abi_exe):

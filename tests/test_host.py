@@ -35,13 +35,13 @@ def test_header_symbols_are_exported(lib):
 
 
 def test_argument_validation_needs_no_gpu(lib):
-    assert lib.mphip_warp_volume(None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None, 0, None) == -1
+    assert lib.mphip_warp_volume(None, None, None, None, None, None, None, None, None, 1, 1, 1, 1, 1, 1, 1, 1, None, 0, None) == -1
     assert b"null pointer" in lib.mphip_last_error()
-    assert lib.mphip_conv3d_fwd(None, None, None, None, 1, 1, 1, 1, 1, 1, 3, 0, None, 0, None) == -1
+    assert lib.mphip_conv3d_fwd(None, None, None, None, None, 1, 1, 1, 1, 1, 1, 3, 0, None, 0, None) == -1
     one = ctypes.c_void_p(16)
-    assert lib.mphip_conv3d_fwd(one, one, None, one, 1, 8, 8, 4, 4, 4, 5, 0, None, 0, None) == -1
+    assert lib.mphip_conv3d_fwd(one, None, one, None, one, 1, 8, 8, 4, 4, 4, 5, 0, None, 0, None) == -1
     assert b"kernel size" in lib.mphip_last_error()
-    assert lib.mphip_conv3d_fwd(one, one, None, one, 1, 8, 8, 4, 4, 4, 3, 7, None, 0, None) == -1
+    assert lib.mphip_conv3d_fwd(one, None, one, None, one, 1, 8, 8, 4, 4, 4, 3, 7, None, 0, None) == -1
     assert lib.mphip_groupnorm_stats(one, one, 1, 30, 8, 32, ctypes.c_float(1e-5), None, 0, None) == -1
     assert lib.mphip_avgpool2(one, one, 1, 3, 4, 4, None) == -1
     # pure host helpers
@@ -57,7 +57,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mphip_conv3d_supported(8, 32, 3, 16, 16, 16, 3, 0) == 1
     # split-K workspace only for small volumes
     assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3, 0) == 0
-    assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3, 1) == 0
+    assert lib.mphip_conv3d_workspace_bytes(8, 96, 96, 16, 64, 64, 3, 1) == 16   # f16x3: room for a library-computed range descriptor
     assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3, 0) > 0
     assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3, 1) > 0
     assert lib.mphip_groupnorm_workspace_bytes(2, 96, 65536, 32) == 2 * 32 * 12 * 16
