@@ -26,6 +26,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define MPHIP_RANGE_FLOATS 4100 /* floats per range descriptor: 4 + up to 4096 per-workgroup partial maxima */
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -68,7 +70,7 @@ int mphip_warp_field_compose(const float *theta, const float *em, const float *b
  * coords_out [B,D,H,W,3] float (clipped x,y,z; when given it replaces the workspace),
  * idx_out [B,D,H,W,3] int32 (floor indices; requires coords_out). */
 size_t mphip_warp_workspace_bytes(int B, int D, int H, int W);
-/* out_range (optional, 16 B): range descriptor of `out` (see "Range descriptors" below) — the gather pass folds
+/* out_range (optional, MPHIP_RANGE_FLOATS floats): range descriptor of `out` (see "Range descriptors" below) — the gather pass folds
  * max|out| in, so the conv that consumes the warped volume (G3d's first, model.py:1160) needs no extra pass. */
 int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
                       const float *lin_w, float *out, float *coords_out, int32_t *idx_out, float *out_range, int B,
@@ -98,28 +100,29 @@ int mphip_warp_volume_dsum_shared(const float *v, const float *field, const floa
  *              operand tensor is scaled by its own power of two, see "Range descriptors").  Only for
  *              k=3, Ci%16==0, Co%96==0, H%8==0, W%8==0, D%2==0: ask mphip_conv3d_supported().
  *
- * Range descriptors (precision 1).  x_range = 4 floats on the device describing the magnitude of x:
- *   [0] scale  [1] 1/scale  [2] max|x| (or a rigorous upper bound)  [3] unused
- *   [0] != 0: explicit power-of-two operand scale (mphip_grad_prep writes gradients' this way);
- *   [0] == 0: the kernel derives it from [2] — the power of two with max|x|*scale in [2^13, 2^14).
- * Producers that already stream the tensor fill one for free (mphip_warp_volume, mphip_groupnorm_apply*,
- * mphip_groupnorm_affine_table — `out_range` arguments), mphip_absmax_range() makes one for a tensor of unknown
- * origin, and x_range == NULL lets the conv do that itself (one extra read of x; 16 bytes of workspace).  With a
- * correct descriptor no finite value can leave the f16 range — the reference's fp32 conv has no range cliff, neither
- * has this; Inf/NaN inputs (and finite ones beyond a WRONG descriptor) are not clamped, they propagate as Inf/NaN and
- * are counted (mphip_f16x3_saturation_count).  precision 0 ignores x_range.
+ * Range descriptors (precision 1).  x_range = MPHIP_RANGE_FLOATS floats on the device describing the magnitude of x:
+ *   [0] scale  [1] 1/scale  [2] max|x| (or a rigorous upper bound)  [3] n (as uint32)  [4 .. 4+n) partial maxima
+ *   [0] != 0: explicit power-of-two operand scale (mphip_grad_prep writes gradients' this way; 4 floats suffice then);
+ *   [0] == 0: the kernel derives it from m = max([2], partials) — the power of two with m*scale in [2^13, 2^14).
+ * Producers that already stream the tensor fill one for free — one partial maximum per workgroup, plain stores, no
+ * atomics (mphip_warp_volume, mphip_groupnorm_apply*, mphip_groupnorm_affine_table: `out_range` arguments);
+ * mphip_absmax_range() makes one for a tensor of unknown origin, and x_range == NULL lets the conv do that itself (one
+ * extra read of x; MPHIP_RANGE_FLOATS*4 bytes of workspace).  A caller who knows a bound B can hand in {0, 0, B, 0}.
+ * With a correct descriptor no finite value can leave the f16 range — the reference's fp32 conv has no range cliff,
+ * neither has this; Inf/NaN inputs (and finite ones beyond a WRONG descriptor) are not clamped, they propagate as
+ * Inf/NaN and are counted (mphip_f16x3_saturation_count).  precision 0 ignores x_range.
  * Weights are used in a packed layout built once per weight version and per precision:
  *   precision 0: OIDHW -> [k^3][CiP][CoP] fp32 (CoP = Co up to 32, CiP = Ci up to 2, zero padded)
  *   precision 1: 16-byte header (1/scale, scale) + the LDS image of every (96-channel tile,
  *                16-channel chunk, 3-tap group) slab as f16 hi/lo planes.
- * workspace: 16 bytes for a library-computed range descriptor (precision 1) + split-K partial sums for small
- * volumes; mphip_conv3d_workspace_bytes() gives the total.                                   */
+ * workspace: MPHIP_RANGE_FLOATS*4 bytes for a library-computed range descriptor (precision 1) + split-K partial
+ * sums for small volumes; mphip_conv3d_workspace_bytes() gives the total.                     */
 int mphip_conv3d_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision);
 int mphip_pack_conv_weight(const float *w_oidhw, void *w_packed, int Co, int Ci, int k, int precision,
                            void *stream);
 size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
-int mphip_absmax_range(const float *x, size_t n, float *range, void *stream);   /* x, range 16-byte aligned */
+int mphip_absmax_range(const float *x, size_t n, float *range, void *stream);   /* x 16-byte aligned */
 int mphip_conv3d_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, int N,
                      int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                      size_t workspace_bytes, void *stream);
@@ -156,7 +159,7 @@ int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, const float
  * apply kernels that consume it sum the slabs on the fly (z ascending + bias, the same order as the
  * reduce of mphip_conv3d_fwd), so the separate reduce launch and pass disappear.
  * mphip_conv3d_splits() == 1 means the conv is not split: out is then the plain result (bias added).
- * workspace: only the 16 bytes of a library-computed range descriptor (precision 1 and x_range == NULL).  */
+ * workspace: only a library-computed range descriptor (precision 1 and x_range == NULL).                  */
 int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 int mphip_conv3d_fwd_split(const float *x, const float *x_range, const void *w_packed, const float *bias, float *out,
                            int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,

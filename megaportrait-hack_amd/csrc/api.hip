@@ -35,11 +35,10 @@ __global__ void __launch_bounds__(256) absmax_range_kernel(const float *__restri
     }
     if (blockIdx.x == 0)
         for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) m = max(m, range_bits(x[i]));
-    range_note(m, range);
+    range_note_block(m, range, blockIdx.x, gridDim.x);
 }
 
 int absmax_range_launch(const float *x, size_t n, float *range, hipStream_t s) {
-    zero_fill(range, 16, s);
     const size_t per_block = 256 * 4 * 8;  // ~8 float4 per thread
     const unsigned blocks = (unsigned)std::min<size_t>(2048, (n + per_block - 1) / per_block);
     hipLaunchKernelGGL(absmax_range_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, x, n, range);
@@ -49,6 +48,6 @@ int absmax_range_launch(const float *x, size_t n, float *range, hipStream_t s) {
 
 extern "C" int mphip_absmax_range(const float *x, size_t n, float *range, void *stream) {
     MPHIP_REQUIRE(x && range && n > 0, "absmax_range: null pointer or empty tensor");
-    MPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)range & 15) == 0, "absmax_range: pointers must be 16-byte aligned");
+    MPHIP_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)range & 3) == 0, "absmax_range: x must be 16-byte aligned");
     return mphip::absmax_range_launch(x, n, range, (hipStream_t)stream);
 }

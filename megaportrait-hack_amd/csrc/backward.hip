@@ -492,10 +492,12 @@ extern "C" int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, i
     return precision == 1 && bwd_weight_f16x3_supported(N, Ci, Co, D, H, W, k);
 }
 
+constexpr size_t BW_RANGE_BYTES = ((MPHIP_RANGE_FLOATS * sizeof(float) + 255) / 256) * 256;
+
 extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
     if (bwd_weight_direct(N, D, H, W)) return 16;  // unused
-    if (precision == 1) return 16 + bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W, k);  // 16: a library-computed range of x
+    if (precision == 1) return BW_RANGE_BYTES + bwd_weight_f16x3_ws_bytes(N, Ci, Co, D, H, W, k);  // head: a library-computed range of x
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int bxy = ((Ci + 31) / 32) * ((Co + 95) / 96) * (k == 3 ? 3 : 1);
     return (size_t)bw_splits(ntiles, bxy) * Co * Ci * k * k * k * sizeof(float);
@@ -539,7 +541,7 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *x_range, con
             if (rc0) return rc0;
             x_range = (const float *)workspace;
         }
-        return bwd_weight_f16x3_launch(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, (char *)workspace + 16, s);
+        return bwd_weight_f16x3_launch(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, (char *)workspace + BW_RANGE_BYTES, s);
     }
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;

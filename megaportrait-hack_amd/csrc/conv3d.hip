@@ -500,12 +500,12 @@ static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int
     return check_launch("pack_conv_weight");
 }
 
-constexpr size_t RANGE_BYTES = 16;
+constexpr size_t RANGE_BYTES = ((MPHIP_RANGE_FLOATS * sizeof(float) + 255) / 256) * 256;  // descriptor + padding: keeps what follows aligned
 
 extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
     int splits = precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
-    // precision 1: 16 bytes in front for the range descriptor the library computes itself when the caller passes none
+    // precision 1: room in front for the range descriptor the library computes itself when the caller passes none
     return (precision == 1 ? RANGE_BYTES : 0) + (splits > 1 ? (size_t)splits * N * Co * D * H * W * sizeof(float) : 0);
 }
 
@@ -577,14 +577,14 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     }
     float *dst = y;
     const size_t n_out = (size_t)N * Co * D * H * W;
-    // f16x3: the input's range descriptor (mphip_common.h).  None given -> one extra pass computes max|x| into the first 16
-    // bytes of the workspace (a fused input GroupNorm changes the values: its descriptor must come from
+    // f16x3: the input's range descriptor (mphip_common.h).  None given -> one extra pass computes max|x| into the head
+    // of the workspace (a fused input GroupNorm changes the values: its descriptor must come from
     // mphip_groupnorm_affine_table).
     const size_t range_bytes = precision == 1 ? RANGE_BYTES : 0;
     if (precision == 1 && !x_range) {
         MPHIP_REQUIRE(!in_affine, "conv3d_fwd: the fused input GroupNorm needs the range descriptor of mphip_groupnorm_affine_table");
         if (!workspace || workspace_bytes < range_bytes) {
-            set_error("conv3d_fwd: workspace %zu bytes < required %zu (no x_range given: 16 bytes for the input's range)", workspace_bytes, range_bytes);
+            set_error("conv3d_fwd: workspace %zu bytes < required %zu (no x_range given: the input's range descriptor goes there)", workspace_bytes, range_bytes);
             return MPHIP_EWORKSPACE;
         }
         int rc0 = absmax_range_launch(x, (size_t)N * Ci * D * H * W, (float *)workspace, s);
@@ -652,7 +652,7 @@ extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, i
 extern "C" int mphip_conv3d_fwd_split(const float *x, const float *x_range, const void *w_packed, const float *bias, float *out,
                                       int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                                       size_t workspace_bytes, void *stream) {
-    // workspace: only the 16 bytes of a library-computed range descriptor (precision 1 with x_range == NULL)
+    // workspace: only a library-computed range descriptor (precision 1 with x_range == NULL)
     return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, out, nullptr, 0, 0.0f, true, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
 }

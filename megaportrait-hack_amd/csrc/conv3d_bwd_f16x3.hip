@@ -84,7 +84,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
     const int t_end = min(ntiles, t_begin + tiles_per_split);
     const float dscale = gscale[0];
     float BF_X_SCALE, bf_x_unscale;  // the saved activation's own operand scale (its range descriptor)
-    range_scale(x_range, BF_X_SCALE, bf_x_unscale);
+    range_scale_block(x_range, BF_X_SCALE, bf_x_unscale);
     const int kd = wave / 3, kh = wave % 3;  // this wave's tap row; waves 0..2 also take row 8 (kd=kh=2), co-tile `wave`
     const bool heavy = wave < 3;
 
@@ -262,7 +262,7 @@ conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__rest
     const int t_begin = blockIdx.z * tiles_per_split, t_end = min(ntiles, t_begin + tiles_per_split);
     const float dscale = gscale[0];
     float BF_X_SCALE, bf_x_unscale;  // the saved activation's own operand scale (its range descriptor)
-    range_scale(x_range, BF_X_SCALE, bf_x_unscale);
+    range_scale_block(x_range, BF_X_SCALE, bf_x_unscale);
     f32x16 acc[3][3];
 #pragma unroll
     for (int m = 0; m < 3; ++m)

@@ -140,7 +140,7 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     // operand scale of the input tensor: from its range descriptor (activations: max|x| noted by the producing kernel or
     // mphip_absmax_range; gradients: mphip_grad_prep) — per tensor, a power of two
     float x_scale = X_SCALE, x_unscale = 1.0f / X_SCALE;
-    if (x_scale_p) range_scale(x_scale_p, x_scale, x_unscale);
+    if (x_scale_p) range_scale_block(x_scale_p, x_scale, x_unscale);  // (folds the producer's per-workgroup maxima; barriers inside)
     constexpr int TVOX = TD * TH * TW;
     constexpr int NTHR = NWAVES * 64;
     constexpr int NT = TVOX / (32 * NWAVES);          // 32-voxel column tiles per wave
@@ -371,9 +371,66 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 #endif
             PROF_ADD(2)
             const _Float16 *wsb = Ws + wb * W_BUF + a_base;
-            // Fragments are double buffered in registers by hand: the 10 ds_read_b128 of tap tg+1 are
-            // issued before the 18 MFMAs of tap tg, so LDS latency hides under 576 MFMA cycles (left to
-            // itself hipcc reloads one 28-register set and waits lgkmcnt(0) five times per tap).
+            const int gt = ((g + 1) * GS <= F16X3_NG ? GS : F16X3_NG - g * GS) * F16X3_TG;  // taps in this group
+#ifdef MPHIP_ABL_NOMFMA
+#define F16X3_MFMA(a_, b_, c_) (c_)
+#else
+#define F16X3_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#endif
+#ifndef MPHIP_F16X3_OLD_FRAGS
+            // Fragment schedule: per tap the three products run as  P1 = Wlo*Xhi,  P2 = Whi*Xhi,  P3 = Whi*Xlo  (6 MFMAs = 192
+            // MFMA cycles each).  Only the Xhi fragments are double buffered; every other fragment is loaded into the registers
+            // its predecessor vacated one or two phases earlier:
+            //   before P1(t): Whi(t), Xlo(t)  [free since P3(t-1)]  and Xhi(t+1) [other buffer]     needed at P2 / P3 / P1(t+1)
+            //   before P2(t): Wlo(t+1)        [free since P1(t)]                                     needed at P1(t+1)
+            // so every ds_read_b128 has >= 192 MFMA cycles of cover and the fragments take 48 registers instead of the 80 of two
+            // full sets (which pushed this kernel into scratch spills: 256 VGPRs + 34 spilled, r01).
+            half8 ah[MT], al[MT], bl[NT], bh[2][NT];
+#define F16X3_TOFF(tg_) ((((g * GT + (tg_)) / 9) * HH + ((g * GT + (tg_)) / 3) % 3) * HWp + (g * GT + (tg_)) % 3) * 8
+#define F16X3_WOFF(tg_) (((tg_) / F16X3_TG) * SLAB_HALFS + (((tg_) % F16X3_TG) * 2 * F16X3_COT) * 8)
+#define F16X3_LD_AH(tg_) _Pragma("unroll") for (int m = 0; m < MT; ++m) ah[m] = *reinterpret_cast<const half8 *>(wsb + F16X3_WOFF(tg_) + m * 32 * 8);
+#define F16X3_LD_AL(tg_) _Pragma("unroll") for (int m = 0; m < MT; ++m) al[m] = *reinterpret_cast<const half8 *>(wsb + F16X3_WOFF(tg_) + SLAB_HALFS / 2 + m * 32 * 8);
+#define F16X3_LD_BH(buf_, tg_) _Pragma("unroll") for (int t = 0; t < NT; ++t) bh[buf_][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t] + F16X3_TOFF(tg_));
+#define F16X3_LD_BL(tg_) _Pragma("unroll") for (int t = 0; t < NT; ++t) bl[t] = *reinterpret_cast<const half8 *>(Xs + X_PART + b_base[t] + F16X3_TOFF(tg_));
+            F16X3_LD_AL(0)
+            F16X3_LD_BH(0, 0)
+#pragma unroll
+            for (int tg = 0; tg < GT; ++tg) {
+                if (tg < gt) {
+                    const int cur = tg & 1;
+                    F16X3_LD_AH(tg)
+                    F16X3_LD_BL(tg)
+                    if (tg + 1 < gt) { F16X3_LD_BH(cur ^ 1, tg + 1) }
+                    __builtin_amdgcn_sched_barrier(0);  // the loads above stay above this tap's MFMAs
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(al[m], bh[cur][t], acc[m][t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (tg + 1 < gt) { F16X3_LD_AL(tg + 1) }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(ah[m], bh[cur][t], acc[m][t]);
+#pragma unroll
+                    for (int m = 0; m < MT; ++m)
+#pragma unroll
+                        for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(ah[m], bl[t], acc[m][t]);
+                }
+            }
+#ifdef MPHIP_ABL_NOMFMA
+            asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(bh[0][0]), "v"(bl[0]), "v"(ah[MT - 1]), "v"(al[MT - 1]), "v"(bh[1][NT - 1]),
+                         "v"(bl[NT - 1]));
+#endif
+#undef F16X3_TOFF
+#undef F16X3_WOFF
+#undef F16X3_LD_AH
+#undef F16X3_LD_AL
+#undef F16X3_LD_BH
+#undef F16X3_LD_BL
+#else
+            // (r01 schedule, kept for same-box A/B: two full fragment sets, all of tap tg+1 loaded before the MFMAs of tap tg)
             half8 ah[2][MT], al[2][MT], bh[2][NT], bl[2][NT];
 #define F16X3_LOAD_FRAGS(set, tg_)                                                                        \
     {                                                                                                     \
@@ -389,7 +446,6 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             bl[set][t] = *reinterpret_cast<const half8 *>(Xs + X_PART + b_base[t] + toff_);               \
         }                                                                                                 \
     }
-            const int gt = ((g + 1) * GS <= F16X3_NG ? GS : F16X3_NG - g * GS) * F16X3_TG;  // taps in this group
             F16X3_LOAD_FRAGS(0, 0);
 #pragma unroll
             for (int tg = 0; tg < GT; ++tg) {
@@ -397,33 +453,27 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
                 const int cur = tg & 1;
                 if (tg + 1 < gt) F16X3_LOAD_FRAGS(cur ^ 1, tg + 1);
                 __builtin_amdgcn_sched_barrier(0);  // keep the prefetch above this tap's MFMAs
-                // three passes over the 6 accumulators: consecutive MFMAs never share an accumulator
-#ifdef MPHIP_ABL_NOMFMA
-                asm volatile("" ::"v"(ah[cur][0]), "v"(al[cur][0]), "v"(bh[cur][0]), "v"(bl[cur][0]), "v"(ah[cur][MT - 1]),
-                             "v"(al[cur][MT - 1]), "v"(bh[cur][NT - 1]), "v"(bl[cur][NT - 1]));
-#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, x_, y_, z_) (c_)
-#endif
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][m], bh[cur][t], acc[m][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(al[cur][m], bh[cur][t], acc[m][t]);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][m], bl[cur][t], acc[m][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(ah[cur][m], bl[cur][t], acc[m][t]);
 #pragma unroll
                 for (int m = 0; m < MT; ++m)
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][m], bh[cur][t], acc[m][t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(ah[cur][m], bh[cur][t], acc[m][t]);
                 }
             }
-#undef F16X3_LOAD_FRAGS
 #ifdef MPHIP_ABL_NOMFMA
-#undef __builtin_amdgcn_mfma_f32_32x32x16_f16
+            asm volatile("" ::"v"(ah[0][0]), "v"(al[0][0]), "v"(bh[0][0]), "v"(bl[0][0]), "v"(ah[1][MT - 1]), "v"(al[1][MT - 1]),
+                         "v"(bh[1][NT - 1]), "v"(bl[1][NT - 1]));
 #endif
+#undef F16X3_LOAD_FRAGS
+#endif
+#undef F16X3_MFMA
             PROF_ADD(3)
             __syncthreads();  // slab (g+1) landed (DMA drained by the barrier's vmcnt(0)); slab g free
             PROF_ADD(4)

@@ -52,35 +52,52 @@ inline void zero_fill(void *p, size_t n_bytes, hipStream_t s) {
 }
 
 // ---- range descriptors: the per-tensor operand scale of the f16x3 (split-f16) kernels ------------------------------------
-// A range descriptor is 4 floats (16 B) on the device:  [0] scale  [1] 1/scale  [2] max|x| (or a rigorous upper bound)  [3] -
+// A range descriptor is MPHIP_RANGE_FLOATS floats on the device (include/mphip.h):
+//   [0] scale  [1] 1/scale  [2] max|x| (or a rigorous upper bound)  [3] n (uint)  [4 .. 4+n) per-workgroup partial maxima
 //   [0] != 0 : an explicit power-of-two scale (mphip_grad_prep writes gradients' this way);
-//   [0] == 0 : the consumer derives the scale from [2]: the power of two with max|x| * scale in [2^13, 2^14).
-// Producers (warp gather, GroupNorm apply, ...) zero the descriptor and fold max|out| into [2] with range_note();
-// mphip_absmax_range() does it for a tensor of unknown origin.  The f16x3 kernels scale every operand by it before the
-// hi/lo split, so no finite value can leave the f16 range (the reference's fp32 conv has no range cliff either) and tensors of
-// any magnitude keep fp32-class accuracy; non-finite values are passed through by the split and propagate as Inf/NaN.
+//   [0] == 0 : the consumer derives the scale from max([2], partials): the power of two with max*scale in [2^13, 2^14).
+// Producers (warp gather, GroupNorm apply, mphip_absmax_range, ...) leave ONE partial maximum per workgroup with a plain
+// store — no atomics (same-address atomics serialise in one L2 channel: measured +0.27 ms per step), no zero-fill, no
+// finalize launch; the consuming conv kernel folds the <= 4096 partials in its prologue (16 KB from L2, once per
+// workgroup).  The f16x3 kernels scale every operand by the result before the hi/lo split, so no finite value can leave
+// the f16 range (the reference's fp32 conv has no range cliff either) and tensors of any magnitude keep fp32-class
+// accuracy; non-finite values are passed through by the split and propagate as Inf/NaN.
+constexpr unsigned RANGE_MAX_PARTS = MPHIP_RANGE_FLOATS - 4;
+
 __device__ __forceinline__ unsigned range_bits(float v) { return __float_as_uint(fabsf(v)); }  // NaN sorts above Inf above finite
 
-// One wavefront folds its lanes' max (as range_bits) into range[2].  The plain (L1-cached) pre-read skips the atomic once the
-// stored maximum already covers this wave — after the first wave of workgroups almost always — so the same-address atomics
-// (which serialise in L2) stay a handful per launch.  A stale cached value only causes a redundant atomic, never a missed one.
-__device__ __forceinline__ void range_note(unsigned bits, float *__restrict__ range) {
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {
 #pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) bits = max(bits, (unsigned)__shfl_xor((int)bits, s, 64));
-    if ((threadIdx.x & 63) == 0) {
-        unsigned *slot = reinterpret_cast<unsigned *>(range) + 2;
-        if (bits > *slot) atomicMax(slot, bits);
+    for (int s = 32; s >= 1; s >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, s, 64));
+    return v;
+}
+
+// Producer side.  EVERY thread of the workgroup calls it once, at the end of the kernel (it contains a barrier), with its
+// own maximum (range_bits); `block` = linear workgroup index < nblocks <= RANGE_MAX_PARTS.
+__device__ __forceinline__ void range_note_block(unsigned bits, float *__restrict__ range, unsigned block, unsigned nblocks) {
+#ifdef MPHIP_RANGE_NOTE_OFF  /* dev: isolates the cost of noting ranges */
+    return;
+#endif
+    __shared__ unsigned range_red_[16];
+    bits = wave_umax(bits);
+    if ((threadIdx.x & 63) == 0) range_red_[threadIdx.x >> 6] = bits;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned m = 0;
+        for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) m = max(m, range_red_[w]);
+        unsigned *r = reinterpret_cast<unsigned *>(range);
+        r[4 + block] = m;
+        if (block == 0) {
+            r[0] = 0;  // derive mode
+            r[1] = 0;
+            r[2] = 0;
+            r[3] = nblocks;
+        }
     }
 }
 
-__device__ __forceinline__ void range_scale(const float *__restrict__ range, float &scale, float &inv) {
-    const float s0 = range[0];
-    if (s0 != 0.0f) {
-        scale = s0;
-        inv = range[1];
-        return;
-    }
-    const float m = range[2];
+__device__ __forceinline__ void scale_from_bits(unsigned bits, float &scale, float &inv) {
+    const float m = __uint_as_float(bits);
     scale = inv = 1.0f;  // all-zero tensor, Inf or NaN inside: unit scale (non-finite values propagate through the split)
     if (m > 0.0f && m < 3.0e38f) {
         int e;
@@ -91,7 +108,31 @@ __device__ __forceinline__ void range_scale(const float *__restrict__ range, flo
     }
 }
 
-// max|x| of a tensor of unknown origin -> descriptor (zero-fill + one streaming pass).  Defined in api.hip.
+// Consumer side.  EVERY thread of the workgroup calls it (barriers inside); the result is workgroup-uniform.
+__device__ __forceinline__ void range_scale_block(const float *__restrict__ range, float &scale, float &inv) {
+    if (range[0] != 0.0f) {  // explicit scale (uniform branch)
+        scale = range[0];
+        inv = range[1];
+        return;
+    }
+    __shared__ unsigned range_fold_[17];
+    const unsigned *r = reinterpret_cast<const unsigned *>(range);
+    const unsigned n = min(r[3], RANGE_MAX_PARTS);
+    unsigned m = r[2];
+    for (unsigned i = threadIdx.x; i < n; i += blockDim.x) m = max(m, r[4 + i]);
+    m = wave_umax(m);
+    if ((threadIdx.x & 63) == 0) range_fold_[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned t = 0;
+        for (unsigned w = 0; w < (blockDim.x + 63) / 64; ++w) t = max(t, range_fold_[w]);
+        range_fold_[16] = t;
+    }
+    __syncthreads();
+    scale_from_bits(range_fold_[16], scale, inv);
+}
+
+// max|x| of a tensor of unknown origin -> descriptor (one streaming pass, one launch).  Defined in api.hip.
 int absmax_range_launch(const float *x, size_t n, float *range, hipStream_t s);
 
 // value of a split-K tensor element: slab[0][o] + slab[1][o] + ... (z ascending, the reduce kernel's order).

@@ -182,9 +182,9 @@ __device__ __forceinline__ float gn_value(const GnParams &p, float xv, float mea
 // apply, no pooling: one thread per VW contiguous elements of one (n,c) plane.
 template <int VW>
 __global__ void __launch_bounds__(256) gn_apply_kernel(GnParams p, int S, size_t total_vec) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned mbits = 0;
-    if (t < total_vec) {
+    // grid-stride: with a range descriptor the grid is capped at the descriptor's RANGE_MAX_PARTS partial-maximum slots
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_vec; t += (size_t)gridDim.x * blockDim.x) {
         const int SV = S / VW;
         size_t plane = t / SV;  // n*C + c
         int c = (int)(plane % p.C);
@@ -204,21 +204,20 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GnParams p, int S, size_t
             out.z = gn_value(p, xv.z, mean, rstd, g, b, w2, b2, has2, rv.z, has_res);
             out.w = gn_value(p, xv.w, mean, rstd, g, b, w2, b2, has2, rv.w, has_res);
             *reinterpret_cast<float4 *>(p.y + o) = out;
-            mbits = max(max(range_bits(out.x), range_bits(out.y)), max(range_bits(out.z), range_bits(out.w)));
+            mbits = max(max(mbits, range_bits(out.x)), max(max(range_bits(out.y), range_bits(out.z)), range_bits(out.w)));
         } else {
             const float v = gn_value(p, p.x[o], mean, rstd, g, b, w2, b2, has2, has_res ? p.residual[o] : 0.0f, has_res);
             p.y[o] = v;
-            mbits = range_bits(v);
+            mbits = max(mbits, range_bits(v));
         }
     }
-    if (p.range) range_note(mbits, p.range);  // all lanes arrive (block-uniform condition)
+    if (p.range) range_note_block(mbits, p.range, blockIdx.x, gridDim.x);  // all threads arrive (uniform condition)
 }
 
 // apply + AvgPool3d(2,2): one thread per pooled output element (sum order kd,kh,kw then /8 like ATen).
 __global__ void __launch_bounds__(256) gn_apply_pool_kernel(GnParams p, int D, int H, int W, size_t total) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned mbits = 0;
-    if (t < total) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int oD = D / 2, oH = H / 2, oW = W / 2;
     int ow = (int)(t % oW);
     size_t r = t / oW;
@@ -245,9 +244,9 @@ __global__ void __launch_bounds__(256) gn_apply_pool_kernel(GnParams p, int D, i
             s += gn_value(p, xv.y, mean, rstd, g, b, w2, b2, has2, rv.y, has_res);
         }
     p.y[t] = s / 8.0f;
-    mbits = range_bits(s / 8.0f);
+    mbits = max(mbits, range_bits(s / 8.0f));
     }
-    if (p.range) range_note(mbits, p.range);
+    if (p.range) range_note_block(mbits, p.range, blockIdx.x, gridDim.x);
 }
 
 // General apply for small tensors: x and/or the residual may still be split-K slabs (value = bias[c] +
@@ -266,10 +265,9 @@ __device__ __forceinline__ float split_value(const float *__restrict__ x, int sp
 }
 
 __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, size_t total) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const GnParams &p = q.p;
     unsigned mbits = 0;
-    if (t < total) {
+    for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
     const int oD = q.pool2 ? q.D / 2 : q.D * q.uD, oH = q.pool2 ? q.H / 2 : q.H * q.uH, oW = q.pool2 ? q.W / 2 : q.W * q.uW;
     int ow = (int)(t % oW);
     size_t r = t / oW;
@@ -298,17 +296,17 @@ __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, si
                     s += gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
                 }
         p.y[t] = s / 8.0f;
-        mbits = range_bits(s / 8.0f);
+        mbits = max(mbits, range_bits(s / 8.0f));
     } else {
         size_t o = pbase + ((size_t)(od / q.uD) * q.H + oh / q.uH) * q.W + ow / q.uW;
         float xv = split_value(p.x, q.x_splits, q.slab, o, xb);
         float rv = has_res ? split_value(p.residual, q.res_splits, q.slab, o, rb) : 0.0f;
         const float v = gn_value(p, xv, mean, rstd, g, b, w2, b2, has2, rv, has_res);
         p.y[t] = v;
-        mbits = range_bits(v);
+        mbits = max(mbits, range_bits(v));
     }
     }
-    if (p.range) range_note(mbits, p.range);
+    if (p.range) range_note_block(mbits, p.range, blockIdx.x, gridDim.x);
 }
 
 // Tiny tensors (FlowField: a (sample, group) span of <= GN_FUSED_MAX floats): statistics AND apply in one
@@ -387,7 +385,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
                 for (int cc = 0; cc < q.uW; ++cc)
                     dst[((size_t)(d * q.uD + a) * oH + h * q.uH + b) * oW + w * q.uW + cc] = v;
     }
-    if (p.range) range_note(mbits, p.range);
+    if (p.range) range_note_block(mbits, p.range, blockIdx.x, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256) avgpool2_kernel(const float *__restrict__ x, float *__restrict__ y, int D,
@@ -716,6 +714,13 @@ extern "C" int mphip_groupnorm_stats(const float *x, float *stats, int N, int C,
     return groupnorm_stats_launch(x, stats, N, C, S, G, eps, workspace, (hipStream_t)stream);
 }
 
+// workgroups for `total` threads of 256; capped when a range descriptor is filled (see gn_apply_kernel)
+constexpr int RANGE_GRID_CAP = (int)RANGE_MAX_PARTS;
+static inline int range_grid(size_t total, const float *range) {
+    const int full = cdiv(total, 256);
+    return (range && full > RANGE_GRID_CAP) ? RANGE_GRID_CAP : full;
+}
+
 extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const float *gamma, const float *beta,
                                      const float *w2, const float *b2, const float *residual, float *y, float *out_range, int N,
                                      int C, int D, int H, int W, int G, int relu, int tanh_, int pool2, void *stream) {
@@ -724,18 +729,17 @@ extern "C" int mphip_groupnorm_apply(const float *x, const float *stats, const f
     MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_apply: w2/b2 must both be set or both NULL");
     GnParams p{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_, out_range};
     hipStream_t s = (hipStream_t)stream;
-    if (out_range) zero_fill(out_range, 16, s);
     const int S = D * H * W;
     if (pool2) {
         MPHIP_REQUIRE(D % 2 == 0 && H % 2 == 0 && W % 2 == 0, "groupnorm_apply: pool2 needs even D,H,W");
         size_t total = (size_t)N * C * (D / 2) * (H / 2) * (W / 2);
-        hipLaunchKernelGGL(gn_apply_pool_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, p, D, H, W, total);
+        hipLaunchKernelGGL(gn_apply_pool_kernel, dim3(range_grid(total, out_range)), dim3(256), 0, s, p, D, H, W, total);
     } else if (S % 4 == 0) {
         size_t total = (size_t)N * C * S / 4;
-        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(cdiv(total, 256)), dim3(256), 0, s, p, S, total);
+        hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(range_grid(total, out_range)), dim3(256), 0, s, p, S, total);
     } else {
         size_t total = (size_t)N * C * S;
-        hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(cdiv(total, 256)), dim3(256), 0, s, p, S, total);
+        hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(range_grid(total, out_range)), dim3(256), 0, s, p, S, total);
     }
     return check_launch("groupnorm_apply");
 }
@@ -767,7 +771,7 @@ __global__ void gn_affine_table_kernel(const float *__restrict__ stats, const fl
         table[i * 2 + 1] = shift;
         mbits = range_bits((sqrt_ng * fabsf(amp) + fabsf(off)) * 1.0001f);
     }
-    if (range) range_note(mbits, range);
+    if (range) range_note_block(mbits, range, blockIdx.x, gridDim.x);
 }
 
 extern "C" int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const float *beta, const float *w2,
@@ -777,7 +781,6 @@ extern "C" int mphip_groupnorm_affine_table(const float *stats, const float *gam
     MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_affine_table: bad dims");
     MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "groupnorm_affine_table: w2/b2 must both be set or both NULL");
     hipStream_t s = (hipStream_t)stream;
-    if (out_range) zero_fill(out_range, 16, s);
     hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, stats, gamma, beta, w2, b2, table,
                        out_range, N, C, C / G, sqrtf((float)(C / G) * (float)S));
     return check_launch("groupnorm_affine_table");
@@ -807,9 +810,8 @@ extern "C" int mphip_groupnorm_apply_split(const float *x, int x_splits, const f
     MPHIP_REQUIRE(!pool2 || (D % 2 == 0 && H % 2 == 0 && W % 2 == 0), "groupnorm_apply_split: pool2 needs even D,H,W");
     GnSplitParams q{{x, stats, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_, out_range}, x_splits, res_splits,
                     (size_t)N * C * D * H * W, x_bias, res_bias, D, H, W, pool2, uD, uH, uW};
-    if (out_range) zero_fill(out_range, 16, (hipStream_t)stream);
     size_t total = pool2 ? (size_t)N * C * (D / 2) * (H / 2) * (W / 2) : (size_t)N * C * D * uD * H * uH * W * uW;
-    hipLaunchKernelGGL(gn_apply_split_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, q, total);
+    hipLaunchKernelGGL(gn_apply_split_kernel, dim3(range_grid(total, out_range)), dim3(256), 0, (hipStream_t)stream, q, total);
     return check_launch("groupnorm_apply_split");
 }
 

@@ -375,7 +375,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
             mbits = max(max(mbits, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
         }
     }
-    if (out_range) range_note(mbits, out_range);
+    if (out_range) range_note_block(mbits, out_range, blockIdx.x, gridDim.x);
 }
 
 // K3: a workgroup owns 256 consecutive (h,w) positions of one frame and CPB channels; every thread
@@ -526,15 +526,17 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     hipStream_t s = (hipStream_t)stream;
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
-    if (out_range && W % 4 != 0) {   // (the scalar fallback kernel does not fold the maximum in)
-        rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);   // the warp is a convex combination: max|out| <= max|v|
+    const int tiles = (H * W + 1023) / 1024;
+    const size_t nblocks = (size_t)B * D * tiles;
+    if (out_range && (W % 4 != 0 || nblocks > RANGE_MAX_PARTS)) {
+        // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
+        // max|out| <= max|v|, so v's own range serves
+        rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);
         if (rc) return rc;
+        out_range = nullptr;
     }
     if (W % 4 == 0) {
-        const int tiles = (H * W + 1023) / 1024;
-        if (out_range) zero_fill(out_range, 16, s);
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)((size_t)B * D * tiles)), dim3(256), 0, s, v, coords, out, out_range,
-                           B, C, D, H, W);
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, B, C, D, H, W);
     } else {
         const int cpb = C >= 48 ? 12 : C;
         hipLaunchKernelGGL(warp_gather_scalar_kernel, dim3(cdiv((size_t)B * D * H * W, 256), cdiv(C, cpb)), dim3(256), 0, s,

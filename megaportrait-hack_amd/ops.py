@@ -40,15 +40,16 @@ def _req(t: torch.Tensor, name: str, dtype=torch.float32) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ range descriptors (f16x3 operand scales)
-# include/mphip.h "Range descriptors": 4 floats on the device per tensor; the f16x3 conv kernels scale their input by the
+# include/mphip.h "Range descriptors": a small device buffer per tensor; the f16x3 conv kernels scale their input by the
 # power of two it implies, so activations of any magnitude keep fp32-class accuracy and nothing is ever clamped.  Kernels
 # that already stream a tensor (warp gather, GroupNorm apply) fill the descriptor of their output for free; it rides on the
 # torch.Tensor object as an attribute, guarded by the tensor's version counter (an in-place write invalidates it).
+_RANGE_FLOATS = 4100  # MPHIP_RANGE_FLOATS (include/mphip.h): 4 + one partial maximum per producing workgroup
 _RANGES_ENABLED = _os.environ.get("MPHIP_FUSED_RANGES", "1") != "0"  # dev switch: 0 = every f16x3 conv measures its own input
 
 
 def new_range(device) -> torch.Tensor:
-    return torch.empty(4, dtype=torch.float32, device=device)  # zeroed / filled by the kernel call it is handed to
+    return torch.empty(_RANGE_FLOATS, dtype=torch.float32, device=device)  # filled by the kernel call it is handed to
 
 
 def tag_range(t: torch.Tensor, rng: Optional[torch.Tensor]) -> torch.Tensor:
