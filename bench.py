@@ -281,7 +281,9 @@ def train_mode(args, rank, world, dev, dist):
         graphed = training.GraphedTrainStep(hot, loss_fn, opt, inp)
         step = lambda: graphed(**inp)
     else:
-        step = lambda: training.train_step(hot, loss_fn, opt, inp)
+        # N > 1: bucketed all-reduces launched from gradient hooks, underneath backward, on in-place flat gradient buffers
+        reducer = training.OverlappedGradReducer(hot.parameters()) if world > 1 else None
+        step = lambda: training.train_step(hot, loss_fn, opt, inp, reducer=reducer)
 
     def sync_all():
         if dist is not None:

@@ -555,7 +555,14 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     p.variant = (tiles1 * cot >= 256) ? 1 : 0;
     if (force && force[0] == '0') p.variant = 0;
     if (force && force[0] == '1' && tiles1) p.variant = 1;
-    const long tiles = p.variant ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
+    // variant 2: (4,8,8) tile, FOUR waves, two workgroups per CU (81 KB of LDS each).  The two workgroups of a CU run out of
+    // phase, so one's barrier / staging / store phases overlap the other's MFMA bursts.
+    static const char *v2min_s = getenv("MPHIP_F16X3_V2_MIN");   // dev: threshold sweep
+    const long v2min = v2min_s ? atol(v2min_s) : (1L << 60);      // off by default: measured neutral end to end (same-box A/B, r02)
+    const long tiles8 = (long)N * (D / 4) * (H / 8) * (W / 8);
+    if (!force && p.td == 4 && tiles8 * cot >= v2min) p.variant = 2;
+    if (force && force[0] == '2' && p.td == 4) p.variant = 2;
+    const long tiles = p.variant == 1 ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup: each split adds a slab write + a reduce pass
     int sp = 1;
@@ -594,7 +601,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles
     const int tiles_total = (int)p.grid.x;
-    const int per_cu = (p.variant == 1 || p.td == 4) ? 1 : 2;
+    const int per_cu = p.variant == 2 ? 2 : (p.variant == 1 || p.td == 4) ? 1 : 2;
     const long others = (long)p.grid.y * p.grid.z;
     long gx = (256L * per_cu + others - 1) / others;
     if (gx < 1) gx = 1;
@@ -603,7 +610,10 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');  // dev switch for same-box A/B
     // (two-slab groups for the 512-voxel tile — 5 instead of 9 barriers per chunk, 147 KB of LDS — were tried: the
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
-    if (p.variant == 1)
+    if (p.variant == 2)
+        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+    else if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
                            D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
     else if (p.td == 4)

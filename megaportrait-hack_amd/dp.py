@@ -38,17 +38,23 @@ def run_sharded(fn: Callable[..., torch.Tensor], inputs: Dict[str, torch.Tensor]
     return fn(**local)
 
 
-def all_gather_frames(local: torch.Tensor, n_frames: int, frame_shape, group=None) -> torch.Tensor:
+def all_gather_frames(local: torch.Tensor, n_frames: int, frame_shape, group=None, device=None,
+                      dtype=torch.float32) -> torch.Tensor:
     """Ragged all-gather of per-rank frame slices back into frame order (torch.distributed; backend
-    nccl == RCCL on ROCm, gloo in the CPU tests).  Pads to the largest shard, gathers, trims."""
+    nccl == RCCL on ROCm, gloo in the CPU tests).  Pads to the largest shard, gathers, trims.
+    A rank whose shard is empty passes local=None: its pad buffer must still live where the collective runs — pass
+    `device` (and `dtype`) there; by default the current CUDA device under nccl, the CPU under gloo."""
     import torch.distributed as dist
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     counts = [shard_range(n_frames, r, world)[1] - shard_range(n_frames, r, world)[0] for r in range(world)]
     cap = max(counts)
-    ref = local if local is not None else None
-    dev = ref.device if ref is not None else torch.device("cpu")
-    dtype = ref.dtype if ref is not None else torch.float32
+    if local is not None:
+        dev, dtype = local.device, local.dtype
+    elif device is not None:
+        dev = torch.device(device)
+    else:
+        dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
     buf = torch.zeros((cap, *frame_shape), dtype=dtype, device=dev)
     if counts[rank]:
         buf[:counts[rank]] = local

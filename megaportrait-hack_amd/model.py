@@ -418,7 +418,12 @@ class _HotSliceRunner:
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
         if vs.shape[0] == 0:  # an empty frame shard (dp.shard_inputs with more ranks than frames): nothing to launch
-            return vs.new_zeros((0, vs.shape[1]) + tuple(vs.shape[3:]))
+            out = vs.new_zeros((0, vs.shape[1]) + tuple(vs.shape[3:]))
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                # training: stay connected to the parameters (zero gradients), so this rank's loss.backward() runs and it
+                # enters the gradient all-reduce with the others instead of leaving them blocked in the collective
+                out = out + sum(p.sum() for p in self.parameters() if p.requires_grad) * 0.0
+            return out
         main = torch.cuda.current_stream(vs.device)
         train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
         # training: one stream (autograd replays each op's backward on its forward stream; the overlap is an inference trick)

@@ -300,8 +300,12 @@ _weight_epoch = 0
 
 
 def invalidate_packs() -> None:
-    """Bumps the epoch that is part of every packed-weight cache key.  For writers that change parameter memory without
-    bumping the tensors' autograd version counters — a hipGraph replay of an optimizer step (training.GraphedTrainStep)."""
+    """Bumps the epoch that is part of every packed-weight cache key.  MANDATORY after any write that changes parameter
+    memory without bumping the tensors' autograd version counters: `param.data.copy_/mul_/clamp_` (EMA, weight clipping,
+    manual loads through `.data`), external graph replays — the caches key on (data_ptr, _version, epoch) and would
+    otherwise keep serving the old packed weights.  Ordinary in-place updates (optimizers, load_state_dict, `with
+    torch.no_grad(): p.copy_(...)`) bump `_version` and need nothing.  training.GraphedTrainStep calls this after
+    every replay."""
     global _weight_epoch
     _weight_epoch += 1
 

@@ -62,12 +62,108 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, bucket
     return len(works)
 
 
+class OverlappedGradReducer:
+    """Gradient averaging overlapped with backward, in place.
+
+    Every bucket owns ONE pre-allocated flat fp32 buffer and each parameter's `.grad` is a view into it, so there is no
+    `torch.cat` into a staging buffer and no copy back (allreduce_gradients does both: 2 x 264 MB of extra traffic per
+    step for the hot slice).  A post-accumulate-grad hook on every parameter counts its bucket down; a complete bucket
+    is all-reduced asynchronously right away — while backward is still producing the gradients of earlier layers
+    (buckets follow reverse registration order, the order backward produces them: G2d first, then C2D / G3d / S2C,
+    Eapp / Emtn last).  Buckets are launched strictly in index order, so every rank issues the same collectives in the
+    same order even when its graph differs (an empty frame shard, parameters unused in forward such as
+    adaptive_matrix_beta, model.py:958-963): whatever is still pending goes out in `finish()`.
+
+        reducer = OverlappedGradReducer(model.parameters())          # after the process group exists
+        reducer.prepare(); loss_fn(model, **shard).backward(); reducer.finish(); optimizer.step()
+    """
+
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, average: bool = True):
+        import torch.distributed as dist
+
+        self.group, self.average = group, average
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.buckets = gradient_buckets(params, bucket_bytes)
+        self.flats, self.views, self.bucket_of = [], {}, {}
+        for i, bucket in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in bucket), dtype=bucket[0].dtype, device=bucket[0].device)
+            off = 0
+            for p in bucket:
+                view = flat[off:off + p.numel()].view_as(p)
+                off += p.numel()
+                self.views[p] = view
+                self.bucket_of[p] = i
+                p.grad = view
+            self.flats.append(flat)
+        self.launched_during_backward = 0
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
+        self.prepare()
+
+    def prepare(self) -> None:
+        """Start of a step: zero the flat buffers in place (the `.grad` views stay) and reset the bookkeeping."""
+        for flat in self.flats:
+            flat.zero_()
+        for p, view in self.views.items():
+            if p.grad is not view:          # someone called zero_grad(set_to_none=True): re-attach the view
+                p.grad = view
+        self._pending = [len(b) for b in self.buckets]
+        self._next = 0
+        self._works = []
+        self._in_backward = True
+        self.launched_during_backward = 0
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        view = self.views[p]
+        if p.grad is not view:               # autograd installed a fresh tensor (grad was None): fold it into the bucket
+            if p.grad is not None:
+                view.copy_(p.grad)
+            p.grad = view
+        i = self.bucket_of[p]
+        self._pending[i] -= 1
+        self._launch_ready()
+
+    def _launch_ready(self, force: bool = False) -> None:
+        import torch.distributed as dist
+
+        while self._next < len(self.buckets) and (force or self._pending[self._next] <= 0):
+            if self.world > 1:
+                self._works.append(dist.all_reduce(self.flats[self._next], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self._in_backward and not force:
+                    self.launched_during_backward += 1
+            self._next += 1
+
+    def finish(self) -> int:
+        """After backward: launch what is still pending (buckets holding parameters without a gradient on this rank),
+        wait for every collective, average in place.  Returns the number of all-reduces of this step."""
+        self._in_backward = False
+        self._launch_ready(force=True)
+        for w in self._works:
+            w.wait()
+        if self.average and self.world > 1:
+            for flat in self.flats:
+                flat.div_(self.world)
+        return len(self._works)
+
+    def remove(self) -> None:
+        for h in self._handles:
+            h.remove()
+
+
 def train_step(model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
-               inputs: Dict[str, torch.Tensor], group=None) -> torch.Tensor:
+               inputs: Dict[str, torch.Tensor], group=None, reducer: Optional[OverlappedGradReducer] = None) -> torch.Tensor:
     """zero_grad -> forward -> loss -> backward -> (gradient all-reduce when distributed) -> optimizer.step().
-    `loss_fn(model, **inputs)` returns the scalar loss of this rank's shard."""
+    `loss_fn(model, **inputs)` returns the scalar loss of this rank's shard.  With `reducer` the all-reduces run
+    bucket by bucket underneath backward on pre-allocated flat gradient buffers; without, after backward
+    (allreduce_gradients)."""
     import torch.distributed as dist
 
+    if reducer is not None:
+        reducer.prepare()
+        loss = loss_fn(model, **inputs)
+        loss.backward()
+        reducer.finish()
+        optimizer.step()
+        return loss.detach()
     optimizer.zero_grad(set_to_none=True)
     loss = loss_fn(model, **inputs)
     loss.backward()
@@ -89,10 +185,20 @@ class GraphedTrainStep:
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
                  example_inputs: Dict[str, torch.Tensor], warmup: int = 3):
+        import copy
+
         from . import ops
 
+        for group in optimizer.param_groups:   # fail here with a clear message, not inside the capture
+            if "capturable" in group and not group["capturable"]:
+                raise ValueError(f"GraphedTrainStep: {type(optimizer).__name__} must be built with capturable=True to be "
+                                 "captured in a hipGraph (its step counters live on the host otherwise); SGD works as is")
         self.model, self.optimizer = model, optimizer
         self.static_in = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in example_inputs.items()}
+        # the warm-up runs REAL steps (the allocator and the packed-weight caches must see the final shapes): parameters,
+        # buffers and optimizer state are snapshotted and restored, so building the graph does not train the model
+        model_state = copy.deepcopy(model.state_dict())
+        optim_state = copy.deepcopy(optimizer.state_dict())
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -103,6 +209,10 @@ class GraphedTrainStep:
                 optimizer.step()
         cur.wait_stream(side)
         torch.cuda.synchronize()
+        with torch.no_grad():
+            model.load_state_dict(model_state)      # copies in place: parameter storage (captured below) is unchanged
+        optimizer.load_state_dict(optim_state)
+        ops.invalidate_packs()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)
         for v in self.static_in.values():

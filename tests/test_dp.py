@@ -125,3 +125,70 @@ def test_data_parallel_train_step_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _overlap_worker(rank, world, port, q):
+    """The hook path (OverlappedGradReducer: flat in-place buckets, all-reduce launched from post-accumulate-grad hooks
+    while backward is still running) must walk the parameters exactly like the post-hoc path (allreduce_gradients),
+    also when one rank's shard is EMPTY (its loss is a zero connected to the parameters) and with a parameter that
+    never gets a gradient."""
+    from megaportrait_hack_amd import training
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(11)
+
+        def make():
+            m = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 16), torch.nn.Tanh(), torch.nn.Linear(16, 2))
+            m.unused = torch.nn.Parameter(torch.ones(3))
+            return m
+
+        posthoc, hooked = make(), make()
+        hooked.load_state_dict(posthoc.state_dict())
+        g = torch.Generator().manual_seed(3)
+        x, y = torch.randn(8, 6, generator=g), torch.randn(8, 2, generator=g)
+
+        def loss_fn(m, x, y):
+            if x.shape[0] == 0:      # empty shard: zero loss that still reaches every used parameter
+                return sum(p.sum() for n, p in m.named_parameters() if n != "unused") * 0.0
+            return torch.nn.functional.mse_loss(m(x), y, reduction="sum") / 8.0
+
+        opt_p = torch.optim.SGD(posthoc.parameters(), lr=0.1, momentum=0.5)
+        opt_h = torch.optim.SGD(hooked.parameters(), lr=0.1, momentum=0.5)
+        reducer = training.OverlappedGradReducer(hooked.parameters(), bucket_bytes=600, average=False)   # several small buckets
+        assert len(reducer.buckets) >= 3
+        early = 0
+        for step in range(4):
+            if step < 2:
+                shard = dp.shard_inputs({"x": x, "y": y}, rank, world)
+            else:                    # ragged: rank 0 holds everything, rank 1 an empty shard
+                shard = {"x": x, "y": y} if rank == 0 else {"x": x[:0], "y": y[:0]}
+            training.train_step(hooked, loss_fn, opt_h, shard, reducer=reducer)
+            early += reducer.launched_during_backward
+            opt_p.zero_grad(set_to_none=True)
+            loss_fn(posthoc, **shard).backward()
+            training.allreduce_gradients(posthoc.parameters(), bucket_bytes=600, average=False)
+            opt_p.step()
+        ok = all(torch.allclose(a, b, atol=1e-6) for a, b in zip(hooked.parameters(), posthoc.parameters()))
+        ok = ok and early >= 4                        # buckets did go out from inside backward
+        ok = ok and all(p.grad is reducer.views[p] for b in reducer.buckets for p in b)   # grads still live in the flat buffers
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_allreduce_equals_posthoc_gloo():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
