@@ -116,6 +116,30 @@ __device__ __forceinline__ float gather8(const float *__restrict__ vol, const Ta
     return acc;
 }
 
+// The same 8 taps with the two x-neighbours of every (y,z) corner fetched by ONE 8-byte load (4 loads instead of 8; only
+// dword alignment is needed).  Same values, same accumulation order -> bit-identical to gather8.  At the right border
+// (dx == 0: the +x corner is outside, ATen skips it, its weight is 0) the pair is read one voxel to the left and both taps
+// take its second element, i.e. p[0] — exactly what gather8 reads there.  Needs W >= 2.
+typedef float f32x2u __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ float gather8_pairs(const float *__restrict__ vol, const Taps &t) {
+    const float *p = vol + t.base - (t.dx ? 0 : 1);
+    const f32x2u q0 = *reinterpret_cast<const f32x2u *>(p);
+    const f32x2u q1 = *reinterpret_cast<const f32x2u *>(p + t.dy);
+    const f32x2u q2 = *reinterpret_cast<const f32x2u *>(p + t.dz);
+    const f32x2u q3 = *reinterpret_cast<const f32x2u *>(p + t.dz + t.dy);
+    const bool in = t.dx != 0;
+    float acc = 0.0f;
+    acc += (in ? q0.x : q0.y) * t.w[0];
+    acc += q0.y * t.w[1];
+    acc += (in ? q1.x : q1.y) * t.w[2];
+    acc += q1.y * t.w[3];
+    acc += (in ? q2.x : q2.y) * t.w[4];
+    acc += q2.y * t.w[5];
+    acc += (in ? q3.x : q3.y) * t.w[6];
+    acc += q3.y * t.w[7];
+    return acc;
+}
+
 // ---- coordinate pass -------------------------------------------------------------------------
 // One thread per output voxel: coords[B,D,H,W,3] = clipped (x,y,z) sample coordinates (and the
 // floor indices for the tests).  12 B per voxel (0.79 MB per 512^2 frame, 3 % of K2's traffic);
@@ -299,21 +323,29 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
     return p;
 }
 
-// K2: a workgroup owns 1024 consecutive (h,w) positions of one (b,d) plane, 4 consecutive w per
-// thread (16-byte stores, a wave writes 1 KB contiguous), all C channels.
+// K2: a workgroup owns a compact 32 x 32 tile of (h,w) positions of one (b,d) plane, 4 consecutive w per thread
+// (16-byte stores, a wave writes eight 128-byte rows), all C channels.  If the tile's source box fits the LDS image with
+// >= 8 channels per pass (always, for the reference's own fields: they never leave the 4^3 low corner) it is staged and
+// gathered from LDS.  Any other tile — a field that really travels through the volume — is only MARKED here (todo[tile] = 1)
+// and done by warp_gather_direct_kernel below: keeping that path out of this kernel keeps it lean (registers: the
+// staged path lost 25 % when both lived in one kernel).
+constexpr int K2_TH = 32, K2_TW = 32;
+constexpr int K2_DIRECT_SPLIT = 4;  // channel groups (gridDim.y) of warp_gather_direct_kernel
 __global__ void __launch_bounds__(256)
 warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
-                   float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */, int B,
-                   int C, int D, int H, int W) {
+                   float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */,
+                   int *__restrict__ todo, int B, int C, int D, int H, int W) {
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
-    const int tiles = (HW + 1023) / 1024;
-    const int tile = blockIdx.x % tiles;
-    const int bd = blockIdx.x / tiles;
+    const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
+    const int tile = blockIdx.x % (tiles_w * tiles_h);
+    const int bd = blockIdx.x / (tiles_w * tiles_h);
     const int d = bd % D, b = bd / D;
-    const int p0 = tile * 1024 + threadIdx.x * 4;
-    const bool active = p0 < HW;  // W % 4 == 0 -> a thread's 4 positions share a row and validity
+    const int h = (tile / tiles_w) * K2_TH + (int)(threadIdx.x >> 3);
+    const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x & 7) * 4;
+    const bool active = h < H && w < W;  // W % 4 == 0 -> a thread's 4 positions share validity
+    const int p0 = h * W + w;
     const size_t vol = (size_t)D * HW;
 
     Taps taps[4];
@@ -342,8 +374,10 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     const float *vb = v + (size_t)b * C * vol;
     float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
     unsigned mbits = 0;
+    const bool staged = cs_max >= 8 || cs_max >= C;  // block-uniform
+    if (threadIdx.x == 0) todo[blockIdx.x] = staged ? 0 : 1;
 
-    if (cs_max >= 8 || cs_max >= C) {  // block-uniform
+    if (staged) {
         TapOff lt[4];
         if (active) {
 #pragma unroll
@@ -365,22 +399,64 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
                 }
             }
         }
-    } else if (active) {
-        for (int c = 0; c < C; ++c) {
-            const float *src = vb + (size_t)c * vol;
-            float4 r;
-            r.x = gather8(src, taps[0]); r.y = gather8(src, taps[1]);
-            r.z = gather8(src, taps[2]); r.w = gather8(src, taps[3]);
-            *reinterpret_cast<float4 *>(ob + (size_t)c * vol) = r;
-            mbits = max(max(mbits, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
-        }
     }
-    if (out_range) range_note_block(mbits, out_range, blockIdx.x, gridDim.x);
+    if (out_range) range_note_block(mbits, out_range, blockIdx.x, (1 + K2_DIRECT_SPLIT) * gridDim.x);  // (+ the direct kernel's slots)
 }
 
-// K3: a workgroup owns 256 consecutive (h,w) positions of one frame and CPB channels; every thread
-// walks the D output slices of its position accumulating the depth projection in registers
-// (d ascending, like torch.sum(dim=2) on the warped volume, which is never written).
+// The tiles warp_gather_kernel marked: one position per lane, lanes running along w, so for a smooth field every tap load of
+// a wave covers one or two contiguous row segments (the per-CU L1 serves the overlap between taps and rows) and the stores
+// are contiguous 128-byte rows; the x-neighbour taps come in pairs (gather8_pairs).  Workgroups of unmarked tiles exit.
+__global__ void __launch_bounds__(256)
+warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                          float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W) {
+    unsigned mbits = 0;
+    if (todo[blockIdx.x]) {  // block-uniform
+        const int HW = H * W;
+        const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
+        const int tile = blockIdx.x % (tiles_w * tiles_h);
+        const int bd = blockIdx.x / (tiles_w * tiles_h);
+        const int d = bd % D, b = bd / D;
+        const size_t vol = (size_t)D * HW;
+        const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x & 31);
+        const int hb = (tile / tiles_w) * K2_TH + (int)(threadIdx.x >> 5);  // rows hb, hb+8, hb+16, hb+24
+        Taps t[4];
+        bool act[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int h = hb + 8 * i;
+            act[i] = h < H && w < W;
+            if (act[i]) {
+                const float *cq = coords + (((size_t)b * D + d) * HW + h * W + w) * 3;
+                t[i] = make_taps(Coord3{cq[0], cq[1], cq[2]}, D, H, W);
+            }
+        }
+        const float *vb = v + (size_t)b * C * vol;
+        float *ob = out + (size_t)b * C * vol + (size_t)d * HW + hb * W + w;
+        // channels are split over gridDim.y workgroups: this path is latency-bound (L2-hit gathers), it needs every wave slot
+        const int cpg = (C + (int)gridDim.y - 1) / (int)gridDim.y;
+        const int c_end = min(C, ((int)blockIdx.y + 1) * cpg);
+#pragma unroll 2
+        for (int c = (int)blockIdx.y * cpg; c < c_end; ++c) {
+            const float *src = vb + (size_t)c * vol;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if (act[i]) {
+                    const float r = W >= 2 ? gather8_pairs(src, t[i]) : gather8(src, t[i]);
+                    ob[(size_t)c * vol + 8 * i * W] = r;
+                    mbits = max(mbits, range_bits(r));
+                }
+            }
+        }
+    }
+    if (out_range) range_note_block(mbits, out_range, gridDim.x * (1 + blockIdx.y) + blockIdx.x, (1 + gridDim.y) * gridDim.x);
+}
+
+// K3: a workgroup owns a compact 16 x 16 tile of (h,w) positions of one frame and CPB channels; every thread walks the D
+// output slices of its position accumulating the depth projection in registers (d ascending, like torch.sum(dim=2) on
+// the warped volume, which is never written).  If the source box of ALL D slices fits the LDS image (the reference's own
+// fields: a 4^3 corner) it is staged once, [voxel][channel] with 16-byte tap reads; otherwise the taps are gathered from
+// global memory through the L1 (lanes along w, x-neighbours in pairs).
+constexpr int K3_TH = 16, K3_TW = 16;
 template <int CPB>
 __global__ void __launch_bounds__(256)
 warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
@@ -388,14 +464,22 @@ warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ c
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
-    const int tiles = (HW + 255) / 256;
-    const int tile = blockIdx.x % tiles, b = blockIdx.x / tiles;
-    const int p = tile * 256 + threadIdx.x;
-    const bool active = p < HW;
+    const int tiles_w = (W + K3_TW - 1) / K3_TW, tiles_h = (H + K3_TH - 1) / K3_TH;
+    const int tile = blockIdx.x % (tiles_w * tiles_h), b = blockIdx.x / (tiles_w * tiles_h);
+    const int h = (tile / tiles_w) * K3_TH + (int)(threadIdx.x >> 4);
+    const int w = (tile % tiles_w) * K3_TW + (int)(threadIdx.x & 15);
+    const bool active = h < H && w < W;
+    const int p = h * W + w;
     const size_t vol = (size_t)D * HW;
     const int c0 = blockIdx.y * CPB;
     const int cs = min(CPB, C - c0);
-    const float *cp = coords + ((size_t)b * D * HW + p) * 3;
+    const int cs_pad = lds_pitch_for(cs);
+    const float *cp = coords + ((size_t)b * D * HW + (active ? p : 0)) * 3;
+    const float *vb = v + (size_t)b * v_frame_stride;
+
+    float acc[CPB];
+#pragma unroll
+    for (int c = 0; c < CPB; ++c) acc[c] = 0.0f;
 
     int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
     if (active) {
@@ -406,45 +490,43 @@ warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ c
             hx = max(hx, x); hy = max(hy, y); hz = max(hz, z);
         }
     }
-    const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
-    const int bvol = bx.ex * bx.ey * bx.ez;
-    const int cs_pad = lds_pitch_for(cs);
-    const bool staged = bvol * cs_pad <= STAGE_FLOATS;  // block-uniform
-    const float *vb = v + (size_t)b * v_frame_stride;
-    if (staged) {
-        stage_box(vb, lds, bx, c0, cs, cs_pad, H, W, vol);
+    const Box all = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
+    if (all.ex * all.ey * all.ez * cs_pad <= STAGE_FLOATS) {  // block-uniform: everything in one [voxel][channel] image
+        stage_box(vb, lds, all, c0, cs, cs_pad, H, W, vol);
         __syncthreads();
-    }
-    if (!active) return;
-
-    float acc[CPB];
+        if (active) {
+            for (int d = 0; d < D; ++d) {
+                const float *q = cp + (size_t)d * HW * 3;
+                Coord3 cc{q[0], q[1], q[2]};
+                Taps t = make_taps(cc, D, H, W);
+                const TapOff lt = rebase(t, (int)floorf(cc.x), (int)floorf(cc.y), (int)floorf(cc.z), all, cs_pad);
 #pragma unroll
-    for (int c = 0; c < CPB; ++c) acc[c] = 0.0f;
-    for (int d = 0; d < D; ++d) {
-        const float *q = cp + (size_t)d * HW * 3;
-        Coord3 cc{q[0], q[1], q[2]};
-        Taps t = make_taps(cc, D, H, W);
-        if (staged) {
-            const TapOff lt = rebase(t, (int)floorf(cc.x), (int)floorf(cc.y), (int)floorf(cc.z), bx, cs_pad);
+                for (int c = 0; c < CPB; c += 4) {
+                    if (c + 4 <= cs) {
+                        float tmp[4];
+                        gather8x4(lds + c, lt, t.w, tmp);
 #pragma unroll
-            for (int c = 0; c < CPB; c += 4) {
-                if (c + 4 <= cs) {
-                    float tmp[4];
-                    gather8x4(lds + c, lt, t.w, tmp);
+                        for (int k = 0; k < 4; ++k) acc[c + k] += tmp[k];
+                    } else {
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) acc[c + k] += tmp[k];
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (c + k < cs) acc[c + k] += gather8_lds(lds + c + k, lt, t.w);
+                        for (int k = 0; k < 4; ++k)
+                            if (c + k < cs) acc[c + k] += gather8_lds(lds + c + k, lt, t.w);
+                    }
                 }
             }
-        } else {
+        }
+    } else if (active) {
+        // a field that travels through the volume: gather from global memory; lanes run along w (coalesced row segments for
+        // a smooth field, the per-CU L1 serves the overlap between taps), x-neighbour taps in pairs
+        for (int d = 0; d < D; ++d) {
+            const float *q = cp + (size_t)d * HW * 3;
+            const Taps t = make_taps(Coord3{q[0], q[1], q[2]}, D, H, W);
 #pragma unroll
             for (int c = 0; c < CPB; ++c)
-                if (c < cs) acc[c] += gather8(vb + (size_t)(c0 + c) * vol, t);
+                if (c < cs) acc[c] += W >= 2 ? gather8_pairs(vb + (size_t)(c0 + c) * vol, t) : gather8(vb + (size_t)(c0 + c) * vol, t);
         }
     }
+    if (!active) return;
 #pragma unroll
     for (int c = 0; c < CPB; ++c)
         if (c < cs) out[((size_t)b * C + c0 + c) * HW + p] = acc[c];
@@ -490,9 +572,14 @@ static int check_warp_args(const char *name, const void *v, const void *field, c
     return MPHIP_OK;
 }
 
+static size_t k2_tiles(int B, int D, int H, int W) {
+    return (size_t)B * D * ((H + K2_TH - 1) / K2_TH) * ((W + K2_TW - 1) / K2_TW);
+}
+
+// coordinates [B,D,H,W,3] + one int per K2 tile (which of the two gather kernels takes it)
 extern "C" size_t mphip_warp_workspace_bytes(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * D * H * W * 3 * sizeof(float);
+    return (size_t)B * D * H * W * 3 * sizeof(float) + ((k2_tiles(B, D, H, W) * sizeof(int) + 15) / 16) * 16;
 }
 
 static int launch_coords(const float *field, const float *lin_d, const float *lin_h, const float *lin_w, float *coords,
@@ -514,21 +601,18 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     int rc = check_warp_args("warp_volume", v, field, lin_d, lin_h, lin_w, out, B, C, D, H, W, fD, fH, fW);
     if (rc) return rc;
     MPHIP_REQUIRE(!idx_out || coords_out, "warp_volume: idx_out requires coords_out");
-    float *coords = coords_out;
-    if (!coords) {
-        size_t need = mphip_warp_workspace_bytes(B, D, H, W);
-        if (!workspace || workspace_bytes < need) {
-            set_error("warp_volume: workspace %zu bytes < required %zu", workspace_bytes, need);
-            return MPHIP_EWORKSPACE;
-        }
-        coords = (float *)workspace;
+    const size_t need = mphip_warp_workspace_bytes(B, D, H, W), coord_bytes = (size_t)B * D * H * W * 3 * sizeof(float);
+    if (!workspace || workspace_bytes < need) {
+        set_error("warp_volume: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
     }
+    float *coords = coords_out ? coords_out : (float *)workspace;
+    int *todo = (int *)((char *)workspace + coord_bytes);
     hipStream_t s = (hipStream_t)stream;
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
-    const int tiles = (H * W + 1023) / 1024;
-    const size_t nblocks = (size_t)B * D * tiles;
-    if (out_range && (W % 4 != 0 || nblocks > RANGE_MAX_PARTS)) {
+    const size_t nblocks = k2_tiles(B, D, H, W);
+    if (out_range && (W % 4 != 0 || (1 + K2_DIRECT_SPLIT) * nblocks > RANGE_MAX_PARTS)) {
         // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
         // max|out| <= max|v|, so v's own range serves
         rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);
@@ -536,7 +620,9 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
         out_range = nullptr;
     }
     if (W % 4 == 0) {
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, B, C, D, H, W);
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W);
+        hipLaunchKernelGGL(warp_gather_direct_kernel, dim3((unsigned)nblocks, K2_DIRECT_SPLIT), dim3(256), 0, s, v, coords, out, out_range, todo, B, C,
+                           D, H, W);
     } else {
         const int cpb = C >= 48 ? 12 : C;
         hipLaunchKernelGGL(warp_gather_scalar_kernel, dim3(cdiv((size_t)B * D * H * W, 256), cdiv(C, cpb)), dim3(256), 0, s,
@@ -560,7 +646,7 @@ static int warp_volume_dsum_impl(const char *name, const float *v, size_t v_fram
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, nullptr, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
     constexpr int CPB = 16;
-    const int tiles = (H * W + 255) / 256;
+    const int tiles = ((H + K3_TH - 1) / K3_TH) * ((W + K3_TW - 1) / K3_TW);
     hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles), cdiv(C, CPB)), dim3(256), 0, s, v,
                        coords, out, B, C, D, H, W, v_frame_stride);
     return check_launch(name);

@@ -168,8 +168,8 @@ def warp_volume(v: torch.Tensor, field: torch.Tensor, return_coords: bool = Fals
         idx = torch.empty((b, d, h, w, 3), dtype=torch.int32, device=v.device)
     dev = v.device
     lib = _lib.load()
-    ws_bytes = 0 if return_coords else lib.mphip_warp_workspace_bytes(b, d, h, w)
-    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev) if ws_bytes else None
+    ws_bytes = lib.mphip_warp_workspace_bytes(b, d, h, w)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
     _lib.check(lib.mphip_warp_volume(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
                                      _ptr(linspace_table(w, dev)), _ptr(out), _ptr(coords), _ptr(idx), _ptr(rng), b, c, d, h, w,
                                      field.shape[2], field.shape[3], field.shape[4], _ptr(ws), ws_bytes, _stream()),
