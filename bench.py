@@ -234,6 +234,42 @@ def end_to_end(dev, B, steps=8, warmup=3):
                         "2D encoders/decoder on PyTorch-ROCm (MIOpen fp32), 3D tail + hot slice + G2d head on libmphip"}
 
 
+def roofline_hbm(hot, inp, B):
+    """The two HBM-bound kernels of the slice in isolation: K2 = apply_warping_field
+    (coords + gather), K3 = apply_warping_field + sum(dim=2), timed with HIP events on the launch stream for the model's own
+    ("faithful") fields of this batch and for a smooth field that travels through the whole volume ("smooth": the
+    stress case — the reference's fields only ever sample the 4^3 low corner).
+    achieved = ALGORITHMIC bytes (K2 53.5 MB, K3 29.9 MB per frame) / time; `traffic` = counter bytes per launch from the
+    committed rocprofv3 --pmc passes (profiles/r02_pmc_warps.json, B=8), `counter_GBps` = traffic / this run's time."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_warps as BW
+
+    with torch.no_grad():
+        w_s2c = hot.warp_generator_s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
+    table = {"faithful": w_s2c, "smooth": BW.fields(B)["smooth"]}
+    res = BW.measure(B, iters=20, quiet=True, field_override=table)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_warps.json")) as f:
+            pmc = json.load(f)["kernels"]
+    except Exception:
+        pmc = {}
+    out = {}
+    for key, rec in res.items():
+        kname, kind = key.split(" / ")
+        short = kname.split()[0]
+        kernels = {"K2": ["warp_coords_kernel", "warp_gather_kernel", "warp_gather_direct_kernel"],
+                   "K3": ["warp_coords_kernel", "warp_gather_dsum_kernel"]}[short]
+        traffic = None
+        if B == 8:
+            parts = [pmc.get(f"{k} / {kind} / B=8", {}).get("traffic_bytes_per_launch") for k in kernels]
+            traffic = sum(p for p in parts if p) if any(parts) else None
+        out.setdefault(short, {})[kind] = {
+            "kernels": kernels, "bound": "hbm", "launch_ms": rec["ms"], "achieved": rec["algorithmic_GBps"], "peak": 8000.0, "unit": "GB/s",
+            "frac": rec["frac_of_8TBps"], "traffic": traffic,
+            "counter_GBps": round(traffic / rec["ms"] / 1e6, 1) if traffic else None}
+    return out
+
+
 def fp32_exact(hot, inp, B, steps=10, warmup=2):
     """The same hot slice with every conv on the exact fp32 MFMA kernels (precision 0) — beside the default f16x3 line."""
     from megaportrait_hack_amd import ops
@@ -456,6 +492,7 @@ def main():
         }
         if world == 1 and not args.no_extras:
             ops.set_conv_hook(None)
+            line["roofline_hbm"] = roofline_hbm(hot, inp, B)
             if f16x3:
                 line["fp32_exact"] = fp32_exact(hot, inp, B)
             line["end_to_end"] = end_to_end(dev, B)

@@ -10,19 +10,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from megaportrait_hack_amd import ops, _lib
 
-_lib.load()
-dev = torch.device("cuda:0")
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
-B = int(args[0]) if args else 8
-iters = int(args[1]) if len(args) > 1 else 20
-out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
-only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
 C, D, H, W = 96, 16, 64, 64
 K2_BYTES = (C * D * H * W * 2 + 3 * 64 ** 3) * 4     # per frame
 K3_BYTES = (C * D * H * W + 3 * 64 ** 3 + C * H * W) * 4
 
 
-def fields():
+def fields(B):
     g = torch.Generator(device="cpu").manual_seed(7)
     lin = lambda n: torch.linspace(-1, 1, n)
     # the field is given on a 64^3 grid and resized to (D,H,W) with align_corners=True: build it at (64,64,64)
@@ -45,25 +38,41 @@ def fields():
     return {"faithful": faithful, "smooth": ident.contiguous(), "rot30": rot.contiguous(), "noise": noise}
 
 
-x = torch.randn(B, C, D, H, W, device=dev)
-res = {}
-for kind, f in fields().items():
-    if only and kind != only:
-        continue
-    f = f.to(dev)
-    for name, fn, nbytes in (("K2 warp_volume", ops.warp_volume, K2_BYTES), ("K3 warp_volume_dsum", ops.warp_volume_dsum, K3_BYTES)):
-        for _ in range(3):
-            fn(x, f)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters):
-            fn(x, f)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / iters
-        gbps = B * nbytes / ms / 1e6
-        res[f"{name} / {kind}"] = {"ms": round(ms, 4), "algorithmic_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000, 4), "B": B}
-        print(f"{name:22s} {kind:9s} B={B}: {ms * 1e3:8.1f} us  {gbps / 1e3:6.2f} TB/s algorithmic = {gbps / 80:5.1f} % of 8 TB/s")
-if out_json:
-    json.dump(res, open(out_json, "w"), indent=1)
+def measure(B, iters=20, kinds=None, quiet=False, field_override=None):
+    """-> {"K2 warp_volume / kind": {...}, "K3 warp_volume_dsum / kind": {...}}: HIP-event timing on the current stream."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    x = torch.randn(B, C, D, H, W, device=dev)
+    res = {}
+    table = fields(B) if field_override is None else field_override
+    for kind, f in table.items():
+        if kinds and kind not in kinds:
+            continue
+        f = f.to(dev)
+        for name, fn, nbytes in (("K2 warp_volume", ops.warp_volume, K2_BYTES), ("K3 warp_volume_dsum", ops.warp_volume_dsum, K3_BYTES)):
+            for _ in range(3):
+                fn(x, f)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn(x, f)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / iters
+            gbps = B * nbytes / ms / 1e6
+            res[f"{name} / {kind}"] = {"ms": round(ms, 4), "algorithmic_GBps": round(gbps, 1), "frac_of_8TBps": round(gbps / 8000, 4), "B": B}
+            if not quiet:
+                print(f"{name:22s} {kind:9s} B={B}: {ms * 1e3:8.1f} us  {gbps / 1e3:6.2f} TB/s algorithmic = {gbps / 80:5.1f} % of 8 TB/s")
+    return res
+
+
+if __name__ == "__main__":
+    _lib.load()
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B = int(args[0]) if args else 8
+    iters = int(args[1]) if len(args) > 1 else 20
+    out_json = sys.argv[sys.argv.index("--json") + 1] if "--json" in sys.argv else None
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
+    res = measure(B, iters, kinds=[only] if only else None)
+    if out_json:
+        json.dump(res, open(out_json, "w"), indent=1)
