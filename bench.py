@@ -205,7 +205,7 @@ def cpu_baseline(frames):
                       f"(ATen CPU fp32, {threads} threads), {dt:.1f} s"}
 
 
-def end_to_end(dev, B, steps=8, warmup=3):
+def end_to_end(dev, B, steps=8, warmup=3, fp16=False):
     """Gbase.forward(xs, xd) -> (image, pyramids) on synthetic 512x512 RGB pairs (xs, xd ~ U[0,1)): the
     full generator — Eapp / Emtn / G2d bodies on PyTorch-ROCm (MIOpen), the 3D tail, the hot slice and G2d's head on
     the HIP kernels.  Random-init weights (gbase.Gbase builds offline).  Side measurement: the hot slice is ~10 % of
@@ -217,7 +217,7 @@ def end_to_end(dev, B, steps=8, warmup=3):
     gen = torch.Generator(device="cpu").manual_seed(20240501)
     xs = torch.rand(B, 3, 512, 512, generator=gen).to(dev)
     xd = torch.rand(B, 3, 512, 512, generator=gen).to(dev)
-    with torch.no_grad():
+    with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16, enabled=fp16):
         for _ in range(warmup):
             img, pyr = g(xs, xd)
         torch.cuda.synchronize()
@@ -226,12 +226,14 @@ def end_to_end(dev, B, steps=8, warmup=3):
             img, pyr = g(xs, xd)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-    assert img.shape == (B, 3, 512, 512) and torch.isfinite(img).all()
+    assert img.shape == (B, 3, 512, 512) and torch.isfinite(img.float()).all()
     del g
     torch.cuda.empty_cache()
+    prec = ("torch.autocast(float16) around the generator like the reference's training loop (train.py:188): MIOpen fp16 2D convs; "
+            "the HIP kernels stay fp32 / f16x3") if fp16 else "MIOpen fp32 2D convs"
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "batch": B, "steps": steps,
             "workload": "gbase.Gbase.forward(xs, xd) -> (image [B,3,512,512], pyramids), xs/xd ~ U[0,1), random init; "
-                        "2D encoders/decoder on PyTorch-ROCm (MIOpen fp32), 3D tail + hot slice + G2d head on libmphip"}
+                        "2D encoders/decoder on PyTorch-ROCm, 3D tail + hot slice + G2d head on libmphip", "precision_2d": prec}
 
 
 def roofline_hbm(hot, inp, B):
@@ -496,6 +498,7 @@ def main():
             if f16x3:
                 line["fp32_exact"] = fp32_exact(hot, inp, B)
             line["end_to_end"] = end_to_end(dev, B)
+            line["end_to_end_autocast_fp16"] = end_to_end(dev, B, fp16=True)
         if world == 1 and args.torch_gpu_baseline:
             line["torch_rocm_baseline"] = torch_rocm_baseline(dev, B)
         if world == 1 and not args.no_cpu_baseline:

@@ -61,23 +61,29 @@ class Gbase(M._HotSliceRunner, nn.Module):
         return xhat_base, self.image_pyramid(xhat_base)
 
     @torch.no_grad()
-    def reenact(self, xs, xd, chunk: int = 16, rank: int = 0, world: int = 1):
+    def reenact(self, xs, xd, chunk: int = 16, rank: int = 0, world: int = 1, fp16: bool = False):
         """BASELINE config 5: ONE source image x N driver frames -> images [n_local,3,H,W] of this rank's driver shard.
         The source-side half (Eapp, Emtn(xs), S2C field, warp #1, G3d: model.py:1141-1160) runs once; per driver chunk
         only Emtn(xd), the C2D field, the fused warp + depth sum and G2d run (model.py:1145,1163-1174).  Results equal
-        calling forward() on every (source, driver) pair."""
+        calling forward() on every (source, driver) pair.
+
+        fp16 (config 5's "fp16"): the reference's own reduced-precision policy is `torch.cuda.amp.autocast()` around the
+        generator (train.py:188).  Here that region covers the PyTorch-ROCm 2D modules (Emtn and G2d's body are the whole
+        per-driver cost: G3d runs once per SOURCE); the HIP kernels keep computing in fp32 / f16x3 — their inputs are
+        cast back to fp32 at the boundary (model._f32), which is never less precise than what autocast would run."""
         from . import dp, ops
 
         if xs.shape[0] != 1:
             raise ValueError("reenact expects a single source image [1,3,H,W]")
-        vs, es = self.appearanceEncoder(xs)
-        Rs, ts, zs = self.motionEncoder(xs)
-        vc2d = self.G3d(M.apply_warping_field(vs, self.warp_generator_s2c(Rs, ts, zs, es)))
-        b, e = dp.shard_range(xd.shape[0], rank, world)
-        outs = []
-        for i in range(b, e, chunk):
-            j = min(e, i + chunk)
-            Rd, td, zd = self.motionEncoder(xd[i:j])
-            w_c2d = self.warp_generator_c2d(Rd, td, zd, es.expand(j - i, -1).contiguous())
-            outs.append(self.G2d(ops.warp_volume_dsum(vc2d, w_c2d)))
+        with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=bool(fp16)):
+            vs, es = self.appearanceEncoder(xs)
+            Rs, ts, zs = self.motionEncoder(xs)
+            vc2d = self.G3d(M.apply_warping_field(vs, self.warp_generator_s2c(Rs, ts, zs, es)))
+            b, e = dp.shard_range(xd.shape[0], rank, world)
+            outs = []
+            for i in range(b, e, chunk):
+                j = min(e, i + chunk)
+                Rd, td, zd = self.motionEncoder(xd[i:j])
+                w_c2d = self.warp_generator_c2d(Rd, td, zd, es.float().expand(j - i, -1).contiguous())
+                outs.append(self.G2d(ops.warp_volume_dsum(vc2d, w_c2d)).float())
         return torch.cat(outs, dim=0) if outs else xs.new_zeros((0,) + tuple(xs.shape[1:]))

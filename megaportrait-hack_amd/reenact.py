@@ -39,6 +39,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--unit-range", action="store_true",
                     help="write image*255 (G2d ends in a sigmoid) instead of the reference's (x+1)/2*255 (inference.py:40)")
+    ap.add_argument("--fp16", action="store_true",
+                    help="run the PyTorch-ROCm 2D modules under torch.autocast(float16) (the reference's policy, train.py:188); "
+                         "the HIP hot path stays fp32-class")
     ap.add_argument("--any-size", action="store_true", help="skip the reference's 512x512-only assert (model.py:1157)")
     ap.add_argument("--random-init", action="store_true", help="no checkpoint: random weights (plumbing tests)")
     ap.add_argument("--dry-run", action="store_true", help="resolve inputs and the launch plan, print them as JSON, exit")
@@ -144,7 +147,7 @@ def run(job: dict, args, rank: int, world: int) -> List[str]:
     if not args.any_size and tuple(xs.shape[2:]) != (512, 512):
         raise SystemExit(f"reenact: the reference's Gbase only runs 512x512 frames (model.py:1157); got {tuple(xs.shape[2:])} "
                          "(pass --any-size to run other sizes)")
-    frames = g.reenact(xs.to(dev), xd.to(dev), chunk=args.chunk)          # this rank's shard; no collective
+    frames = g.reenact(xs.to(dev), xd.to(dev), chunk=args.chunk, fp16=args.fp16)   # this rank's shard; no collective
     written = []
     if job["output_tensor"]:
         path = job["output_tensor"] if world == 1 else f"{job['output_tensor']}.rank{rank}"

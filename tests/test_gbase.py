@@ -283,6 +283,12 @@ def test_gbase_full_size_contract_and_reenact(G):
             g(xs[:, :, :256, :256].contiguous(), xd[:1, :, :256, :256].contiguous())
         fast = g.reenact(xs, xd, chunk=2)
         assert maxabs(fast, img.cpu()) < 1e-4
+        # config 5's "fp16": autocast on the PyTorch-ROCm 2D modules (the reference's policy, train.py:188), HIP path unchanged
+        half = g.reenact(xs, xd, chunk=2, fp16=True)
+        assert half.dtype == torch.float32 and half.shape == fast.shape
+        err16 = maxabs(half, fast.cpu())
+        print(f"config 5 fp16 (autocast on the 2D modules) vs fp32: max-abs {err16:.3e} on images in (0,1)")
+        assert err16 < 3e-2
         parts = [g.reenact(xs, xd, chunk=2, rank=r, world=2) for r in range(2)]
         assert [p.shape[0] for p in parts] == [2, 1]
         assert maxabs(torch.cat(parts), fast.cpu()) < 1e-5      # (MIOpen's 2D convs are not bitwise reproducible run to run)
