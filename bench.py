@@ -138,11 +138,10 @@ class DominantKernelTimer:
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            table = json.load(f)
-        for name, rec in table.items():
-            if name.startswith(kernel_prefix):
-                return rec["traffic_bytes_per_launch"]
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_conv.json")) as f:
+            rec = json.load(f)
+        if rec["kernel"].startswith(kernel_prefix):
+            return rec["derived"]["traffic_bytes_per_launch"]
     except Exception:
         pass
     return None
