@@ -461,6 +461,7 @@ extern "C" size_t mphip_packed_weight_bytes(int Co, int Ci, int k, int precision
     if (Co <= 0 || Ci <= 0 || (k != 1 && k != 3)) return 0;
     if (precision == 0) return packed_elems_f32(Co, Ci, k) * sizeof(float);
     if (precision == 1 && k == 3 && Ci % 16 == 0 && Co % 96 == 0) return f16x3_packed_bytes(Co, Ci);
+    if (precision == 1 && k == 1 && Ci % 16 == 0 && Co % 96 == 0) return f16x3_packed_bytes_k1(Co, Ci);
     return 0;
 }
 
@@ -491,7 +492,7 @@ static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int
     MPHIP_REQUIRE(Co > 0 && Ci > 0 && (k == 1 || k == 3), "pack_conv_weight: bad dims");
     MPHIP_REQUIRE(mphip_packed_weight_bytes(Co, Ci, k, precision) > 0,
                   "pack_conv_weight: precision %d not available for Co=%d Ci=%d k=%d", precision, Co, Ci, k);
-    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, transposed, header_from, (hipStream_t)stream);
+    if (precision == 1) return f16x3_pack(w, wp, Co, Ci, k, transposed, header_from, (hipStream_t)stream);
     size_t n = packed_elems_f32(Co, Ci, k);
     int blocks = (int)((n + 255) / 256);
     if (blocks > 4096) blocks = 4096;
@@ -504,7 +505,7 @@ constexpr size_t RANGE_BYTES = ((MPHIP_RANGE_FLOATS * sizeof(float) + 255) / 256
 
 extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
-    int splits = precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
+    int splits = precision == 1 ? (k == 1 ? 1 : f16x3_plan(N, Ci, Co, D, H, W).splits) : plan_conv(N, Ci, Co, D, H, W, k).splits;
     // precision 1: room in front for the range descriptor the library computes itself when the caller passes none
     return (precision == 1 ? RANGE_BYTES : 0) + (splits > 1 ? (size_t)splits * N * Co * D * H * W * sizeof(float) : 0);
 }
@@ -568,7 +569,10 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     ConvPlan p{};
     F16x3Plan fp{};
     int splits;
-    if (precision == 1) {
+    if (precision == 1 && k == 1) {
+        MPHIP_REQUIRE(!in_affine, "conv3d_fwd: the fused input GroupNorm is for the 3x3x3 f16x3 kernel");
+        splits = 1;   // the k=1 GEMM kernel (conv3d_f16x3.hip): no split-K
+    } else if (precision == 1) {
         fp = f16x3_plan(N, Ci, Co, D, H, W);
         splits = fp.splits;
     } else {
@@ -609,7 +613,9 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     }
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
-    if (precision == 1) {
+    if (precision == 1 && k == 1) {
+        rc = f16x3_launch_k1(x, w_packed, bias, dst, N, Ci, Co, D * H * W, x_range, s);
+    } else if (precision == 1) {
         rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s);
     } else {
         const float *wf = (const float *)w_packed;
@@ -646,6 +652,7 @@ extern "C" int mphip_conv3d_fwd(const float *x, const float *x_range, const void
 
 extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    if (precision == 1 && k == 1) return 1;
     return precision == 1 ? f16x3_plan(N, Ci, Co, D, H, W).splits : plan_conv(N, Ci, Co, D, H, W, k).splits;
 }
 

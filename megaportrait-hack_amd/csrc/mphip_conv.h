@@ -23,8 +23,11 @@ struct F16x3Plan {
 
 bool f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
 size_t f16x3_packed_bytes(int Co, int Ci);
+size_t f16x3_packed_bytes_k1(int Co, int Ci);
+int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci, int Co, int DHW,
+                    const float *x_range, hipStream_t s);
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W);
-int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int transposed, const void *header_from, hipStream_t s);
+int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int k, int transposed, const void *header_from, hipStream_t s);
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s);
 

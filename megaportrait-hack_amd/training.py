@@ -198,7 +198,8 @@ class GraphedTrainStep:
         # the warm-up runs REAL steps (the allocator and the packed-weight caches must see the final shapes): parameters,
         # buffers and optimizer state are snapshotted and restored, so building the graph does not train the model
         model_state = copy.deepcopy(model.state_dict())
-        optim_state = copy.deepcopy(optimizer.state_dict())
+        had_state = len(optimizer.state) > 0
+        optim_state = copy.deepcopy(optimizer.state_dict()) if had_state else None
         cur = torch.cuda.current_stream()
         side = torch.cuda.Stream()
         side.wait_stream(cur)
@@ -211,7 +212,16 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         with torch.no_grad():
             model.load_state_dict(model_state)      # copies in place: parameter storage (captured below) is unchanged
-        optimizer.load_state_dict(optim_state)
+            if had_state:
+                optimizer.load_state_dict(optim_state)
+            else:
+                # a fresh optimizer: keep the state tensors the warm-up allocated (the capture below must record the steady-state
+                # update, not the first-step "create the buffer" branch) but reset their VALUES — zero momentum / moments / step
+                # counts are what a fresh SGD(momentum, dampening=0) or Adam(capturable=True) starts from
+                for st in optimizer.state.values():
+                    for v in st.values():
+                        if isinstance(v, torch.Tensor):
+                            v.zero_()
         ops.invalidate_packs()
         self.graph = torch.cuda.CUDAGraph()
         optimizer.zero_grad(set_to_none=True)

@@ -387,9 +387,11 @@ def test_graphed_train_step_matches_eager(dev, M):
     eager, graphed = make(), make()
     opt_e = torch.optim.SGD(eager.parameters(), lr=1e-2, momentum=0.9)
     opt_g = torch.optim.SGD(graphed.parameters(), lr=1e-2, momentum=0.9)
-    step = training.GraphedTrainStep(graphed, loss_fn, opt_g, {"x": x}, warmup=2)   # 2 warm-up + 1 capture-free = 2 updates
-    for _ in range(2):
-        training.train_step(eager, loss_fn, opt_e, {"x": x})
+    before = {n: p.detach().clone() for n, p in graphed.named_parameters()}
+    step = training.GraphedTrainStep(graphed, loss_fn, opt_g, {"x": x}, warmup=2)
+    # building the graph runs real warm-up steps but must not train the model: parameters and momentum are restored
+    assert all(torch.equal(p, before[n]) for n, p in graphed.named_parameters())
+    assert all(float(st["momentum_buffer"].abs().max()) == 0.0 for st in opt_g.state.values())
     losses = []
     for _ in range(3):
         le = training.train_step(eager, loss_fn, opt_e, {"x": x})

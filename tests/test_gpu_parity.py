@@ -591,6 +591,31 @@ def test_empty_frame_shard(hot, dev):
     assert out.shape == (0, 96, 64, 64)
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 192, 8, 32, 32), (1, 768, 384, 2, 8, 8), (3, 192, 96, 4, 16, 16)])
+def test_conv3d_k1_f16x3(ops, dev, shape):
+    """The 1x1x1 shortcut convs of G3d (model.py:510) on the split-f16 GEMM kernel (conv3d_k1_f16x3_kernel): forward and
+    bwd-data vs float64, no worse than twice the exact fp32 kernel's own rounding; bias; a planted outlier."""
+    n, ci, co, d, h, w = shape
+    x = R.seeded_tensor((n, ci, d, h, w), 841, scale=1.7)
+    x[0, 3, 0, 1, 2] = 3.0e4
+    wt = R.seeded_tensor((co, ci, 1, 1, 1), 842, scale=1.0 / ci ** 0.5)
+    b = R.seeded_tensor((co,), 843, scale=0.3)
+    pc = ops.PackedConv(wt.to(dev), b.to(dev))
+    assert ops._lib.load().mphip_conv3d_supported(n, ci, co, d, h, w, 1, 1) == 1
+    truth = F.conv3d(x.double(), wt.double(), b.double())
+    got = ops.conv3d(x.to(dev), pc, precision=1)
+    exact = ops.conv3d(x.to(dev), pc, precision=0)
+    scale = truth.abs().max().item()
+    e1 = (got.cpu().double() - truth).abs().max().item() / scale
+    e0 = (exact.cpu().double() - truth).abs().max().item() / scale
+    assert e1 < max(2.0 * e0, 2e-6), (e1, e0)
+    dy = R.seeded_tensor((n, co, d, h, w), 844, scale=1e-3)
+    _, gs = ops.grad_prep(dy.to(dev), want_bias=False)
+    dx = ops.conv3d_bwd_data(dy.to(dev), ops.PackedConv(wt.to(dev), None, transposed=True), gs, precision=1)
+    want = torch.nn.grad.conv3d_input(x.shape, wt.double(), dy.double())
+    assert (dx.cpu().double() - want).abs().max().item() / want.abs().max().item() < 2e-6
+
+
 def test_f16x3_accepts_any_magnitude(ops, dev):
     """The f16x3 conv scales every operand tensor by its own power of two (range descriptors, include/mphip.h): planted
     outliers far beyond the old fixed-scale cliff (|x| >= 4062), tiny tensors and huge tensors all stay fp32-class, and
