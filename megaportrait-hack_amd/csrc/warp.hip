@@ -339,9 +339,12 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     __shared__ int red[24];
     const int HW = H * W;
     const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
-    const int tile = blockIdx.x % (tiles_w * tiles_h);
-    const int bd = blockIdx.x / (tiles_w * tiles_h);
-    const int d = bd % D, b = bd / D;
+    // XCD-aware order: consecutive logical ids (d fastest, then tile, then frame) run on the same XCD, so the source planes two
+    // neighbouring output slices share meet in that XCD's L2
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int d = (int)(bid % (unsigned)D);
+    const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
+    const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
     const int h = (tile / tiles_w) * K2_TH + (int)(threadIdx.x >> 3);
     const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x & 7) * 4;
     const bool active = h < H && w < W;  // W % 4 == 0 -> a thread's 4 positions share validity
@@ -375,7 +378,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
     unsigned mbits = 0;
     const bool staged = cs_max >= 8 || cs_max >= C;  // block-uniform
-    if (threadIdx.x == 0) todo[blockIdx.x] = staged ? 0 : 1;
+    if (threadIdx.x == 0) todo[bid] = staged ? 0 : 1;
 
     if (staged) {
         TapOff lt[4];
@@ -410,12 +413,13 @@ __global__ void __launch_bounds__(256)
 warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                           float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W) {
     unsigned mbits = 0;
-    if (todo[blockIdx.x]) {  // block-uniform
+    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);  // same logical order as warp_gather_kernel
+    if (todo[bid]) {  // block-uniform
         const int HW = H * W;
         const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
-        const int tile = blockIdx.x % (tiles_w * tiles_h);
-        const int bd = blockIdx.x / (tiles_w * tiles_h);
-        const int d = bd % D, b = bd / D;
+        const int d = (int)(bid % (unsigned)D);
+        const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
+        const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
         const size_t vol = (size_t)D * HW;
         const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x & 31);
         const int hb = (tile / tiles_w) * K2_TH + (int)(threadIdx.x >> 5);  // rows hb, hb+8, hb+16, hb+24
