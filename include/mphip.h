@@ -212,6 +212,11 @@ int mphip_avgpool2(const float *x, float *y, int NC, int D, int H, int W, void *
 int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D, int H, int W, void *stream);
 int mphip_upsample_nearest(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW,
                            void *stream);
+/* F.interpolate(x, scale_factor=(sD,sH,sW), 'trilinear', align_corners=False), integer factors: the `upsample=True` branch of
+ * ResBlock3D / ResBlock3D_Adaptive (model.py:404-405, 525-526), and its adjoint (dx [NC,D,H,W], 16-byte aligned; fp32 atomics). */
+int mphip_upsample_trilinear(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW, void *stream);
+int mphip_upsample_trilinear_bwd(const float *dout, float *dx, int NC, int D, int H, int W, int sD, int sH, int sW,
+                                 void *stream);
 
 /* ------------------------------------------------------------------ K8  small head ops
  * mphip_add_matmul: out[b,n] = sum_k (a[b,k]+a2[b,k]) * m[k,n]   — (z+e) @ Gamma, model.py:945-957

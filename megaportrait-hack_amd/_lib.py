@@ -51,6 +51,8 @@ SIGNATURES = {
     "mphip_avgpool2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_nearest": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_upsample_trilinear": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_upsample_trilinear_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _i, _p]),
     "mphip_add_matmul": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mphip_grad_prep_workspace_bytes": (_sz, [_i, _i, _i]),
     "mphip_grad_prep": (_i, [_p, _p, _p, _i, _i, _i, _p, _sz, _p]),

@@ -124,6 +124,22 @@ class UpsampleTrilinear2Fn(torch.autograd.Function):
         return ops.upsample_trilinear2_bwd(dout.contiguous())
 
 
+class UpsampleTrilinearFn(torch.autograd.Function):
+    """F.interpolate(scale_factor=(sD,sH,sW), 'trilinear', align_corners=False): the residual blocks' `upsample=True` branch."""
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, x, scale):
+        ctx.scale = tuple(scale)
+        return ops.upsample_trilinear(x.contiguous(), ctx.scale)
+
+    @staticmethod
+    @once_differentiable
+    @_bwd
+    def backward(ctx, dout):
+        return ops.upsample_trilinear_bwd(dout.contiguous(), ctx.scale), None
+
+
 def conv3d(x, conv, fwd_pack):
     return Conv3dFn.apply(x, conv.weight, conv.bias, conv, fwd_pack)
 

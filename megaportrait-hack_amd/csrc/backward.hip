@@ -619,6 +619,48 @@ extern "C" int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int N
     return check_launch("upsample_trilinear2_bwd");
 }
 
+// adjoint of mphip_upsample_trilinear: every output gradient scatters to its 8 source voxels with the forward's weights
+// (hardware fp32 atomics, like ATen's upsample_trilinear3d backward on the GPU)
+__global__ void __launch_bounds__(256) upsample_trilinear_scaled_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx,
+                                                                            int D, int H, int W, int sD, int sH, int sW, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int oD = D * sD, oH = H * sH, oW = W * sW;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    const SrcIdx sd = src_index<false>(od, D, oD), sh = src_index<false>(oh, H, oH), sw = src_index<false>(ow, W, oW);
+    const float g = dout[t];
+    float *p = dx + plane * D * H * W;
+    const int di[2] = {sd.i0, sd.i1}, hi[2] = {sh.i0, sh.i1}, wi[2] = {sw.i0, sw.i1};
+    const float dl[2] = {sd.l0, sd.l1}, hl[2] = {sh.l0, sh.l1}, wl[2] = {sw.l0, sw.l1};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const float wgt = dl[a] * hl[b] * wl[c];
+                if (wgt != 0.0f) atomicAdd(p + ((size_t)di[a] * H + hi[b]) * W + wi[c], g * wgt);
+            }
+}
+
+extern "C" int mphip_upsample_trilinear_bwd(const float *dout, float *dx, int NC, int D, int H, int W, int sD, int sH, int sW,
+                                            void *stream) {
+    MPHIP_REQUIRE(dout && dx, "upsample_trilinear_bwd: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && sD > 0 && sH > 0 && sW > 0, "upsample_trilinear_bwd: bad dims");
+    MPHIP_REQUIRE(((size_t)NC * D * H * W * sizeof(float)) % 16 == 0 && ((uintptr_t)dx & 15) == 0,
+                  "upsample_trilinear_bwd: dx must be 16-byte aligned and a multiple of 16 bytes");
+    const size_t total = (size_t)NC * D * H * W * sD * sH * sW;
+    zero_fill(dx, (size_t)NC * D * H * W * sizeof(float), (hipStream_t)stream);
+    hipLaunchKernelGGL(upsample_trilinear_scaled_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, D,
+                       H, W, sD, sH, sW, total);
+    return check_launch("upsample_trilinear_bwd");
+}
+
 extern "C" int mphip_upsample_nearest_bwd(const float *dout, float *dx, int NC, int D, int H, int W, int sD, int sH, int sW,
                                           void *stream) {
     MPHIP_REQUIRE(dout && dx, "upsample_nearest_bwd: null pointer");

@@ -519,6 +519,23 @@ __global__ void __launch_bounds__(256) upsample_trilinear2_scalar_kernel(const f
     y[t] = trilerp(x + plane * D * H * W, H, W, sd, sh, sw);
 }
 
+// F.interpolate(x, scale_factor=(sD,sH,sW), mode='trilinear', align_corners=False) for integer scale factors — the
+// `upsample=True` branch of ResBlock3D / ResBlock3D_Adaptive (model.py:404-405, 525-526; no module of Gbase sets it).
+__global__ void __launch_bounds__(256) upsample_trilinear_scaled_kernel(const float *__restrict__ x, float *__restrict__ y, int D,
+                                                                        int H, int W, int sD, int sH, int sW, size_t total) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int oD = D * sD, oH = H * sH, oW = W * sW;
+    int ow = (int)(t % oW);
+    size_t r = t / oW;
+    int oh = (int)(r % oH);
+    r /= oH;
+    int od = (int)(r % oD);
+    size_t plane = r / oD;
+    SrcIdx sd = src_index<false>(od, D, oD), sh = src_index<false>(oh, H, oH), sw = src_index<false>(ow, W, oW);
+    y[t] = trilerp(x + plane * D * H * W, H, W, sd, sh, sw);
+}
+
 __global__ void __launch_bounds__(256) upsample_nearest_kernel(const float *__restrict__ x, float *__restrict__ y,
                                                                int D, int H, int W, int sD, int sH, int sW,
                                                                size_t total) {
@@ -858,6 +875,16 @@ extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D
                            D, H, W, total);
     }
     return check_launch("upsample_trilinear2");
+}
+
+extern "C" int mphip_upsample_trilinear(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW,
+                                        void *stream) {
+    MPHIP_REQUIRE(x && y, "upsample_trilinear: null pointer");
+    MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0 && sD > 0 && sH > 0 && sW > 0, "upsample_trilinear: bad dims");
+    size_t total = (size_t)NC * D * H * W * sD * sH * sW;
+    hipLaunchKernelGGL(upsample_trilinear_scaled_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W,
+                       sD, sH, sW, total);
+    return check_launch("upsample_trilinear");
 }
 
 extern "C" int mphip_upsample_nearest(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW,

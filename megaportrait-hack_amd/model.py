@@ -76,6 +76,15 @@ def apply_warping_field(v, warp_field):
     return ops.warp_volume(v, warp_field)
 
 
+def _upsample_trilinear(x, scale_factors):
+    """F.interpolate(x, scale_factor=scale_factors, mode='trilinear', align_corners=False) on the HIP kernels."""
+    if tuple(float(v) for v in scale_factors) == (1.0, 1.0, 1.0):
+        return x
+    if torch.is_grad_enabled() and x.requires_grad:
+        return ag.UpsampleTrilinearFn.apply(x, tuple(scale_factors))
+    return ops.upsample_trilinear(x, scale_factors)
+
+
 class AdaptiveGroupNorm(nn.Module):
     """model.py:304-316."""
 
@@ -101,8 +110,6 @@ class ResBlock3D_Adaptive(nn.Module):
 
     def __init__(self, in_channels, out_channels, upsample=False, scale_factors=(1, 1, 1)):
         super().__init__()
-        if upsample:
-            raise NotImplementedError("ResBlock3D_Adaptive(upsample=True) is not used by Gbase's hot path")
         self.upsample = upsample
         self.scale_factors = scale_factors
         self.conv1 = nn.Conv3d(in_channels, out_channels, 3, padding=1)
@@ -116,6 +123,12 @@ class ResBlock3D_Adaptive(nn.Module):
 
     def forward(self, x, _up=(1, 1, 1)):
         """`_up`: nearest-upsample factors fused into the block's last elementwise pass (FlowField's nn.Upsample)."""
+        out = self._forward(x, _up)
+        if self.upsample:   # model.py:404-405 (no module of Gbase sets the flag): trilinear, align_corners=False
+            out = _upsample_trilinear(out, self.scale_factors)
+        return out
+
+    def _forward(self, x, _up=(1, 1, 1)):
         x = _f32(x)
         if ag.needs_grad(self, x):  # differentiable path: the same ops, unfused, as autograd Functions (autograd.py)
             y = ag.conv3d(x, self.conv1, _packs.get(self.conv1))
@@ -253,8 +266,6 @@ class ResBlock3D(nn.Module):
 
     def __init__(self, in_channels, out_channels, upsample=False, scale_factors=(1, 1, 1)):
         super().__init__()
-        if upsample:
-            raise NotImplementedError("ResBlock3D(upsample=True) is not used by G3d")
         self.upsample = upsample
         self.scale_factors = scale_factors
         self.conv1 = nn.Conv3d(in_channels, out_channels, kernel_size=3, padding=1)
@@ -275,6 +286,12 @@ class ResBlock3D(nn.Module):
     def forward(self, x, _pool_after: bool = False, _after_conv1=None):
         """`_after_conv1`: host-side hook called right after conv1 has been launched (GbaseHotSlice issues the side-stream
         generator there, once the GPU has a long kernel queued)."""
+        out = self._forward(x, _pool_after, _after_conv1)
+        if self.upsample:   # model.py:525-526 (G3d never sets the flag): trilinear, align_corners=False
+            out = _upsample_trilinear(out, self.scale_factors)
+        return out
+
+    def _forward(self, x, _pool_after: bool = False, _after_conv1=None):
         x = _f32(x)
         if ag.needs_grad(self, x):
             y = self._forward_train(x)

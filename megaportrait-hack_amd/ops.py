@@ -601,6 +601,35 @@ def upsample_trilinear2(x: torch.Tensor) -> torch.Tensor:
     return tag_range(y, tensor_range(x))  # convex combinations of x: max|y| <= max|x|
 
 
+def _int_scale(scale) -> Tuple[int, int, int]:
+    out = tuple(int(round(float(v))) for v in scale)
+    if len(out) != 3 or any(o < 1 or abs(float(v) - o) > 1e-9 for o, v in zip(out, scale)):
+        raise ValueError(f"upsample_trilinear: integer scale factors (sD,sH,sW) >= 1 expected, got {tuple(scale)}")
+    return out
+
+
+def upsample_trilinear(x: torch.Tensor, scale) -> torch.Tensor:
+    """F.interpolate(x, scale_factor=scale, mode='trilinear', align_corners=False) (model.py:404-405, 525-526)."""
+    x = _req(x, "x")
+    n, c, d, h, w = x.shape
+    sd, sh, sw = _int_scale(scale)
+    y = torch.empty((n, c, d * sd, h * sh, w * sw), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mphip_upsample_trilinear(_ptr(x), _ptr(y), n * c, d, h, w, sd, sh, sw, _stream()), "mphip_upsample_trilinear")
+    return tag_range(y, tensor_range(x))  # convex combinations of x
+
+
+def upsample_trilinear_bwd(dout: torch.Tensor, scale) -> torch.Tensor:
+    dout = _req(dout, "dout")
+    n, c, d, h, w = dout.shape
+    sd, sh, sw = _int_scale(scale)
+    dx = torch.empty((n, c, d // sd, h // sh, w // sw), dtype=torch.float32, device=dout.device)
+    if dx.numel() % 4:
+        raise RuntimeError("upsample_trilinear_bwd: gradient tensor size must be a multiple of 4 elements")
+    _lib.check(_lib.load().mphip_upsample_trilinear_bwd(_ptr(dout), _ptr(dx), n * c, d // sd, h // sh, w // sw, sd, sh, sw, _stream()),
+               "mphip_upsample_trilinear_bwd")
+    return dx
+
+
 def upsample_nearest(x: torch.Tensor, scale: Tuple[int, int, int]) -> torch.Tensor:
     x = _req(x, "x")
     n, c, d, h, w = x.shape

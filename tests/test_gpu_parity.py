@@ -616,6 +616,28 @@ def test_conv3d_k1_f16x3(ops, dev, shape):
     assert (dx.cpu().double() - want).abs().max().item() / want.abs().max().item() < 2e-6
 
 
+def test_resblock_upsample_branch(ops, M, dev):
+    """`upsample=True` of ResBlock3D / ResBlock3D_Adaptive (model.py:404-405, 525-526: F.interpolate(scale_factor, 'trilinear',
+    align_corners=False)) — no module of Gbase sets it; covered for constructor parity.  Forward vs the block without the flag
+    + ATen's interpolate on the CPU, and the gradient through it vs CPU autograd."""
+    x = R.seeded_tensor((1, 96, 4, 8, 8), 851, scale=1.7)
+    for cls, sf in ((M.ResBlock3D, (2, 2, 2)), (M.ResBlock3D_Adaptive, (1, 2, 3))):
+        plain, up = cls(96, 96), cls(96, 96, upsample=True, scale_factors=sf)
+        up.load_state_dict(plain.state_dict())
+        plain, up = plain.to(dev).eval(), up.to(dev).eval()
+        with torch.no_grad():
+            base = plain(x.to(dev))
+            got = up(x.to(dev))
+        want = F.interpolate(base.cpu(), scale_factor=sf, mode="trilinear", align_corners=False)
+        assert got.shape == want.shape and maxabs(got, want) < 1e-6
+    y = R.seeded_tensor((2, 8, 3, 4, 6), 852).requires_grad_(True)
+    dy = R.seeded_tensor((2, 8, 6, 8, 18), 853)
+    F.interpolate(y, scale_factor=(2, 2, 3), mode="trilinear", align_corners=False).backward(dy)
+    assert maxabs(ops.upsample_trilinear_bwd(dy.to(dev), (2, 2, 3)), y.grad) < 1e-5
+    with pytest.raises(ValueError):
+        ops.upsample_trilinear(x.to(dev), (1.5, 2, 2))
+
+
 def test_f16x3_accepts_any_magnitude(ops, dev):
     """The f16x3 conv scales every operand tensor by its own power of two (range descriptors, include/mphip.h): planted
     outliers far beyond the old fixed-scale cliff (|x| >= 4062), tiny tensors and huge tensors all stay fp32-class, and

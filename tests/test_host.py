@@ -52,7 +52,8 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mphip_packed_weight_bytes(96, 96, 3, 1) == 16 + 27 * 96 * 96 * 2 * 2   # f16 hi + lo planes + header
     assert lib.mphip_packed_weight_bytes(3, 32, 3, 1) == 0                     # f16x3 needs Co%96, Ci%16
     assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 3, 1) == 1
-    assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 1, 1) == 0
+    assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 1, 1) == 1     # r02: the k=1 split-f16 GEMM kernel
+    assert lib.mphip_conv3d_supported(8, 96, 96, 1, 5, 5, 1, 1) == 0        # ... needs whole 64-voxel wave tiles per sample
     assert lib.mphip_conv3d_supported(8, 32, 3, 16, 16, 16, 3, 1) == 0
     assert lib.mphip_conv3d_supported(8, 32, 3, 16, 16, 16, 3, 0) == 1
     # split-K workspace only for small volumes
