@@ -370,6 +370,25 @@ def test_conv3d_bwd_weight_full_resolution(dev, precision):
     assert rel_err(got, want) < 2e-5
 
 
+def test_compute_rt_warp_is_differentiable(dev, M):
+    """integration.patch_functions installs model.compute_rt_warp over the reference's differentiable function
+    (model.py:777-809); un-swapped reference code calling it under autograd must get gradients for rotation / translation,
+    not a detached tensor."""
+    rot = R.seeded_tensor((3, 3), 71, scale=30.0)
+    tr = R.seeded_tensor((3, 3), 72, scale=0.17)
+    dw = R.seeded_tensor((3, 3, 64, 64, 64), 73)
+    for invert in (False, True):
+        rc, tc = rot.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        R.compute_rt_warp(rc, tc, invert=invert, grid_size=64).backward(dw)
+        rg, tg = rot.clone().to(dev).requires_grad_(True), tr.clone().to(dev).requires_grad_(True)
+        out = M.compute_rt_warp(rg, tg, invert=invert, grid_size=64)
+        assert out.requires_grad
+        out.backward(dw.to(dev))
+        assert rel_err(rg.grad, rc.grad) < 1e-3 and rel_err(tg.grad, tc.grad) < 1e-3
+    with torch.no_grad():
+        assert not M.compute_rt_warp(rot.to(dev), tr.to(dev)).requires_grad
+
+
 def test_graphed_train_step_matches_eager(dev, M):
     """training.GraphedTrainStep (forward + backward + SGD replayed as one hipGraph, weights re-packed inside the
     graph) walks the parameters exactly like the eager step."""
