@@ -131,11 +131,11 @@ __global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restr
 // GS = packed slabs (of 3 taps) streamed per barrier interval: 3 -> 4 barriers per chunk and 110 KB of
 // weight buffers (one workgroup per CU), 1 -> 10 barriers per chunk and 37 KB.
 template <int TD, int TH, int TW, int NWAVES, int GS>
-__global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // 256 registers: two waves per SIMD
-conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
-                       const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
-                       int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware) {
+__device__ __forceinline__ void
+conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
+                     const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
+                     int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
+                     const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware) {
     constexpr int MT = 3, KC = F16X3_KC;
     // operand scale of the input tensor: from its range descriptor (activations: max|x| noted by the producing kernel or
     // mphip_absmax_range; gradients: mphip_grad_prep) — per tensor, a power of two
@@ -533,6 +533,29 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     PROF_FLUSH
 }
 
+template <int TD, int TH, int TW, int NWAVES, int GS>
+__global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // 256 registers: two waves per SIMD
+conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
+                       const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
+                       int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
+                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware) {
+    conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
+                                                 in_relu, x_scale_p, tiles_total, xcd_aware);
+}
+
+// One wave per SIMD with up to 512 registers: a wave owns 96 output channels x 128 voxels (12 accumulator tiles), so every
+// weight fragment read from LDS feeds four MFMAs instead of two (LDS reads per MFMA 0.56 -> 0.39) and half as many waves meet at
+// every barrier.  The kernel is power-bound: fewer joules per tile is what can make it faster.
+template <int TD, int TH, int TW, int NWAVES, int GS>
+__global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
+conv3d_k3_f16x3_wide_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
+                            const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
+                            int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
+                            const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware) {
+    conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
+                                                 in_relu, x_scale_p, tiles_total, xcd_aware);
+}
+
 // ---- k = 1: the 1x1x1 shortcut convs of G3d (model.py:510) on the same split-f16 arithmetic ---------------------------------
 // Y[co][vox] = sum_ci W[co][ci] * X[ci][vox] is a plain GEMM that streams X once: HBM-bound.  No LDS, no barriers: a wave owns
 // 64 voxels x 96 output channels (3 x 2 MFMA tiles, 96 accumulator registers); per 16-channel chunk a lane fetches its 8
@@ -690,7 +713,8 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     const long tiles8 = (long)N * (D / 4) * (H / 8) * (W / 8);
     if (!force && p.td == 4 && tiles8 * cot >= v2min) p.variant = 2;
     if (force && force[0] == '2' && p.td == 4) p.variant = 2;
-    const long tiles = p.variant == 1 ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
+    if (force && force[0] == '3' && tiles1) p.variant = 3;   // the 512-voxel tile on FOUR wide waves (dev: same-box A/B)
+    const long tiles = (p.variant == 1 || p.variant == 3) ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup: each split adds a slab write + a reduce pass
     int sp = 1;
@@ -744,7 +768,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles
     const int tiles_total = (int)p.grid.x;
-    const int per_cu = p.variant == 2 ? 2 : (p.variant == 1 || p.td == 4) ? 1 : 2;
+    const int per_cu = p.variant == 2 ? 2 : (p.variant == 1 || p.variant == 3 || p.td == 4) ? 1 : 2;
     const long others = (long)p.grid.y * p.grid.z;
     long gx = (256L * per_cu + others - 1) / others;
     if (gx < 1) gx = 1;
@@ -753,7 +777,10 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');  // dev switch for same-box A/B
     // (two-slab groups for the 512-voxel tile — 5 instead of 9 barriers per chunk, 147 KB of LDS — were tried: the
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
-    if (p.variant == 2)
+    if (p.variant == 3)
+        hipLaunchKernelGGL((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+    else if (p.variant == 2)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
                            H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
     else if (p.variant == 1)
