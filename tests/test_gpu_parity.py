@@ -675,6 +675,46 @@ def test_f16x3_accepts_any_magnitude(ops, dev):
     assert torch.isfinite(y).all() and ops.f16x3_saturation_count() == 0
 
 
+def test_range_descriptors_are_correct_bounds(ops, dev):
+    """What the producers leave in a range descriptor: max over [2] and the partial maxima must equal max|tensor| (K2's fused
+    note, GroupNorm apply, mphip_absmax_range) or bound it (K2 with more workgroups than partial slots falls back to the
+    SOURCE volume's maximum — a warp is a convex combination; the affine-table bound of a folded GroupNorm)."""
+    def desc_max(r):
+        r = r.cpu()
+        n = int(r[3:4].view(torch.int32).item())
+        assert 0 <= n <= 4096
+        return max(r[2].item(), r[4:4 + n].max().item() if n else 0.0)
+
+    x = R.seeded_tensor((2, 96, 4, 8, 16), 861, scale=3.0).to(dev)
+    assert desc_max(ops.absmax_range(x)) == x.abs().max().item()
+    field = (R.seeded_tensor((2, 3, 64, 64, 64), 862, scale=1.3) + 0.4).to(dev)
+    v = R.seeded_tensor((2, 8, 16, 64, 64), 863, scale=2.0).to(dev)
+    out = ops.warp_volume(v, field)
+    assert desc_max(ops.tensor_range(out)) == out.abs().max().item()          # fused into the gather kernels
+    vb = R.seeded_tensor((14, 8, 16, 64, 64), 864, scale=2.0).to(dev)           # 14*16*4 tiles x 5 > 4096 partial slots
+    fb = (R.seeded_tensor((14, 3, 64, 64, 64), 865, scale=1.3) + 0.4).to(dev)
+    ob = ops.warp_volume(vb, fb)
+    m = desc_max(ops.tensor_range(ob))
+    assert ob.abs().max().item() <= m == vb.abs().max().item()                 # the source's maximum bounds the warp
+    st = ops.groupnorm_stats(x, 32)
+    g, b = R.seeded_tensor((96,), 866, scale=0.5, shift=1.0).to(dev), R.seeded_tensor((96,), 867, scale=0.5).to(dev)
+    for kw in (dict(relu=True), dict(relu=True, pool2=True), dict(residual=x, relu=False)):
+        y = ops.groupnorm_apply(x, st, g, b, 32, **kw)
+        assert desc_max(ops.tensor_range(y)) == y.abs().max().item(), kw
+    up = ops.upsample_trilinear2(y)
+    assert ops.tensor_range(up) is ops.tensor_range(y) and up.abs().max().item() <= desc_max(ops.tensor_range(y)) + 1e-6
+    # the folded GroupNorm's data-independent bound really bounds the normalised tensor
+    pc = ops.PackedConv(R.seeded_tensor((96, 96, 3, 3, 3), 868, scale=0.02).to(dev), None)
+    lib = ops._lib.load()
+    table = torch.empty((2, 96, 2), device=dev)
+    rng = ops.new_range(dev)
+    ops._lib.check(lib.mphip_groupnorm_affine_table(ops._ptr(st), ops._ptr(g), ops._ptr(b), None, None, ops._ptr(table), ops._ptr(rng), 2, 96,
+                                                    4 * 8 * 16, 32, ops._stream()), "affine_table")
+    normed = ops.groupnorm_apply(x, st, g, b, 32, relu=False)
+    assert normed.abs().max().item() <= desc_max(rng) and desc_max(rng) < 1e3
+    del pc
+
+
 def test_f16x3_propagates_non_finite(ops, dev):
     """Inf / NaN inputs are not clamped to finite values: they reach the output as Inf/NaN exactly where the
     fp32 reference conv puts them, forward and backward (an overflowed gradient must stay visible to GradScaler,
