@@ -488,7 +488,9 @@ def main():
                          "note": ("algorithmic (fp32-equivalent) FLOPs; the kernel issues 3x that on the f16 pipe: "
                                   f"{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the f16 peak; "
                                   f"vs the fp32-MFMA peak ({PEAK_F32_MFMA_TFLOPS}) the algorithmic rate is "
-                                  f"{round(achieved / PEAK_F32_MFMA_TFLOPS, 2)}x") if f16x3 else
+                                  f"{round(achieved / PEAK_F32_MFMA_TFLOPS, 2)}x.  The kernel is power-bound: the package sits at its "
+                                  "1400 W limit with the clock throttled to ~1.7-2.0 GHz while it runs (profiles/r02_power_probe.txt); the "
+                                  "2500 TFLOP/s peak assumes 2.4 GHz") if f16x3 else
                                  "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         }
         if world == 1 and not args.no_extras:
