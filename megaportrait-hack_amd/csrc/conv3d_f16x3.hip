@@ -679,8 +679,10 @@ conv3d_k1_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
 }
 
 bool f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k) {
-    if (k == 1)   // the k=1 GEMM kernel: whole 64-voxel wave tiles inside one sample
-        return Ci % F16X3_KC == 0 && Co % F16X3_COT == 0 && ((long)D * H * W) % 64 == 0 && (size_t)N * Ci * D * H * W * 4 < 0x80000000ull;
+    if (k == 1)   // the k=1 GEMM kernel: whole 64-voxel wave tiles inside one sample, and enough of them to beat the split-K
+                  // fp32 gather kernel (measured: 1024 voxels 29 vs 32 us at B=8, but slower below — B=1 went 1.93 -> 2.11 ms)
+        return Ci % F16X3_KC == 0 && Co % F16X3_COT == 0 && ((long)D * H * W) % 64 == 0 && (long)N * D * H * W >= 2048 &&
+               (size_t)N * Ci * D * H * W * 4 < 0x80000000ull;
     return k == 3 && Ci % F16X3_KC == 0 && Co % F16X3_COT == 0 && H % 8 == 0 && W % 8 == 0 && D % 2 == 0 &&
            (size_t)N * Ci * D * H * W * 4 < 0x80000000ull;
 }
