@@ -13,7 +13,7 @@ Nothing here touches the GPU kernels: it is plain state-dict plumbing (torch.sav
 from __future__ import annotations
 
 import os
-from typing import Dict, Iterable, Optional, Tuple
+from typing import Dict, Optional, Tuple
 
 import torch
 

@@ -21,7 +21,7 @@ import argparse
 import json
 import os
 import sys
-from typing import List, Optional
+from typing import List
 
 
 def parse(argv=None):
