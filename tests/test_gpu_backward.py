@@ -370,6 +370,35 @@ def test_conv3d_bwd_weight_full_resolution(dev, precision):
     assert rel_err(got, want) < 2e-5
 
 
+def test_overlapped_reducer_on_the_hip_modules(dev, M):
+    """training.OverlappedGradReducer with the HIP autograd Functions (world size 1: no collective, but the whole in-place
+    machinery runs): gradients land in the flat bucket buffers (views), equal the plain backward's, the optimizer steps on
+    them, and a parameter without a gradient (adaptive_matrix_beta, model.py:958-963) stays zero."""
+    from megaportrait_hack_amd import training
+
+    sd = R.seeded_gbase_hot_state_dict(7)
+    plain, hooked = M.GbaseHotSlice(), M.GbaseHotSlice()
+    M.load_hot_state_dict(plain, sd)
+    M.load_hot_state_dict(hooked, sd)
+    plain, hooked = plain.to(dev).train(), hooked.to(dev).train()
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 45, D=8, H=16, W=16).items()}
+    loss_fn = lambda m, **kw: m.forward_any_size(**kw).square().mean()
+    loss_fn(plain, **inp).backward()
+    reducer = training.OverlappedGradReducer(hooked.parameters(), bucket_bytes=8 << 20)
+    assert len(reducer.buckets) >= 4
+    opt = torch.optim.SGD(hooked.parameters(), lr=1e-3)
+    before = hooked.G3d.final_conv.weight.detach().clone()
+    training.train_step(hooked, loss_fn, opt, inp, reducer=reducer)
+    ref = {n: (None if p.grad is None else p.grad.cpu()) for n, p in plain.named_parameters()}
+    for n, p in hooked.named_parameters():
+        assert p.grad is reducer.views[p], n
+        if ref[n] is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+    _check_param_grads(hooked.named_parameters(), lambda n: ref[n], 1e-4)   # (the warp scatter uses fp32 atomics: not bitwise)
+    assert not torch.equal(hooked.G3d.final_conv.weight, before)
+    reducer.remove()
+
+
 def test_compute_rt_warp_is_differentiable(dev, M):
     """integration.patch_functions installs model.compute_rt_warp over the reference's differentiable function
     (model.py:777-809); un-swapped reference code calling it under autograd must get gradients for rotation / translation,
