@@ -688,10 +688,12 @@ namespace mphip {
 // (wild field) falls back to direct global atomics for that tile.
 constexpr int WB_CH = 8;
 constexpr int WB_LDS = 16384;  // floats: 64 KB of accumulation image
+constexpr int FBOX_INTS = 8;   // per-frame sample box (warp_frame_box_kernel): ox, oy, oz, ex, ey, ez, dense, -
 template <bool DSUM>
 __global__ void __launch_bounds__(256)
 warp_bwd_tiled_kernel(const float *__restrict__ v, const float *__restrict__ coords, const float *__restrict__ dout,
-                      float *__restrict__ dv, float *__restrict__ dcoords, int B, int C, int D, int H, int W) {
+                      float *__restrict__ dv_all, float *__restrict__ dcoords, const int *__restrict__ fbox, int B, int C, int D,
+                      int H, int W) {
     __shared__ float img[WB_LDS];
     __shared__ int red[24];
     const int HW = H * W;
@@ -704,6 +706,9 @@ warp_bwd_tiled_kernel(const float *__restrict__ v, const float *__restrict__ coo
     const int b = bid / tiles_d;
     const int ox = tw * 16 + (threadIdx.x & 15), oy = th * 16 + (threadIdx.x >> 4);
     const int c0 = blockIdx.y * WB_CH, cs = min(WB_CH, C - c0);
+    // a frame whose samples all fall into one tiny box has its dv computed by warp_bwd_dense_dv_kernel (block-uniform)
+    float *const dv = (fbox && fbox[b * FBOX_INTS + 6]) ? nullptr : dv_all;
+    if (!dv && !dcoords) return;
 
     bool ok[4];
     int base[4], dxyz[4];
@@ -808,6 +813,246 @@ warp_bwd_tiled_kernel(const float *__restrict__ v, const float *__restrict__ coo
             o[2] = (czs[k] > 0.0f && czs[k] < (float)(D - 1)) ? gz[k] : 0.0f;
         }
     }
+}
+
+// ---- the reference's own fields: every sample of a frame inside one small box ------------------------------------------
+// apply_warping_field hands grid_sample coordinates of size ~[-2, 3] as if they were voxel indices, so
+// after the border clip EVERY output voxel of a frame samples the low corner of the volume: floor indices in {0, 1(, 2, 3)}.
+// dv is then non-zero in E^3 voxels per channel (E = 3..5) and each of them receives a contribution from all D*H*W outputs: in the
+// tiled scatter above that is ~1000 same-address LDS atomics per box element and tile, fully serialised (1.18 ms per warp at
+// B=4, 15 % of a training step).  For such frames dv is a plain reduction over the outputs,
+//     dv[c][cell] = sum_o dout[c][o] * Wt[o][cell],      Wt[o][cell] = fz(cell.z - z0(o)) * fy(..) * fx(..)
+// i.e. a [C x outputs] x [outputs x E^3] GEMM with exact fp32 products: it runs on v_mfma_f32_32x32x2_f32 (M = 32 channels,
+// N = 32 box cells, K = 2 outputs).  A lane supplies dout of its channel (one 16-byte load per four k-steps) and computes the
+// trilinear weight of ITS cell for the k-step's output (zero unless the cell is one of the output's 8 corners) — no atomics, no
+// LDS traffic in the loop.  Every wave reduces its own range of outputs; a workgroup folds its 4 waves in LDS and writes one
+// partial [C][cells]; warp_bwd_dense_fold_kernel sums the partials of a frame in a fixed order (deterministic, unlike the scatter)
+// and stores the box into the zero-filled dv.  The per-frame box comes from a one-workgroup-per-frame pass over the coordinates
+// (fbox[6] = the smallest E in 3..5 that holds the frame, 0 = none): frames that do not qualify keep the tiled scatter.
+constexpr int DENSE_E_MIN = 3, DENSE_E_MAX = 5;
+constexpr int DENSE_SEGS = 64;       // workgroups (partials) per frame and 96-channel block
+constexpr int DENSE_MT = 3;          // 32-channel MFMA row tiles per workgroup
+constexpr int DENSE_COLS = 128;      // column stride of a partial (>= 5^3)
+__host__ __device__ constexpr int dense_ntiles(int E) { return E == 3 ? 1 : E == 4 ? 2 : 4; }  // 32-cell MFMA column tiles
+
+__global__ void __launch_bounds__(1024)
+warp_frame_box_kernel(const float *__restrict__ coords, int *__restrict__ fbox, int D, int H, int W) {
+    __shared__ int red[16 * 6];
+    const int b = blockIdx.x;
+    const size_t vol = (size_t)D * H * W;
+    const float *cb = coords + (size_t)b * vol * 3;
+    int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
+    for (size_t t = threadIdx.x; t < vol; t += 1024) {
+        const int x0 = (int)floorf(cb[t * 3]), y0 = (int)floorf(cb[t * 3 + 1]), z0 = (int)floorf(cb[t * 3 + 2]);
+        lx = min(lx, x0); ly = min(ly, y0); lz = min(lz, z0);
+        hx = max(hx, x0); hy = max(hy, y0); hz = max(hz, z0);
+    }
+    lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
+    hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave * 6 + 0] = lx; red[wave * 6 + 1] = ly; red[wave * 6 + 2] = lz;
+        red[wave * 6 + 3] = hx; red[wave * 6 + 4] = hy; red[wave * 6 + 5] = hz;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) {
+            lx = min(lx, red[w * 6 + 0]); ly = min(ly, red[w * 6 + 1]); lz = min(lz, red[w * 6 + 2]);
+            hx = max(hx, red[w * 6 + 3]); hy = max(hy, red[w * 6 + 4]); hz = max(hz, red[w * 6 + 5]);
+        }
+        const int ex = min(hx + 1, W - 1) - lx + 1, ey = min(hy + 1, H - 1) - ly + 1, ez = min(hz + 1, D - 1) - lz + 1;
+        const int e = max(max(ex, ey), max(ez, DENSE_E_MIN));
+        // (the GEMM walks the outputs in aligned groups of 4: 16-byte loads of dout)
+        const bool shape_ok = (H * W) % 4 == 0 && vol >= 32;
+        int *o = fbox + b * FBOX_INTS;
+        o[0] = lx; o[1] = ly; o[2] = lz; o[3] = ex; o[4] = ey; o[5] = ez;
+        o[6] = (e <= DENSE_E_MAX && shape_ok) ? e : 0;
+        o[7] = 0;
+    }
+}
+
+template <bool DSUM, int E>
+__global__ void __launch_bounds__(256)
+warp_bwd_dense_dv_kernel(const float *__restrict__ coords, const float *__restrict__ dout, float *__restrict__ partial,
+                         const int *__restrict__ fbox, int C, int D, int H, int W) {
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int NT = dense_ntiles(E), MT = DENSE_MT;
+    const int b = blockIdx.z;
+    const int *fb = fbox + b * FBOX_INTS;
+    if (fb[6] != E) return;  // block-uniform: another instantiation (or the tiled scatter) owns this frame
+    const int ox = fb[0], oy = fb[1], oz = fb[2];
+    const int HW = H * W;
+    const size_t vol = (size_t)D * HW;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int cblk = blockIdx.y * (MT * 32);
+    // this wave's outputs: [t0, t1), walked 32 at a time: lane half h takes outputs +16h .. +16h+15, one per k-step (the order of
+    // the k index is free).  One iteration = 16 k-steps x MT x NT MFMAs (1.5-6 us of matrix time), with the next iteration's
+    // loads (4 x 16 B of dout per lane and row tile, one coordinate triple per lane) in flight underneath.
+    const size_t per_wave = (vol / 32 + DENSE_SEGS * 4 - 1) / (DENSE_SEGS * 4) * 32;
+    const size_t t0 = min(vol, ((size_t)blockIdx.x * 4 + wave) * per_wave), t1 = min(vol, t0 + per_wave);
+    // LDS table of the current 32 outputs: per output the dense per-axis weight vectors fx[0..E), fy[0..E), fz[0..E) (a slot of
+    // zeros at [15]); the weight of (output, cell) is one product of three table reads, no select chains in the k loop
+    __shared__ __attribute__((aligned(16))) float tab_all[4][32][16];
+    float (*tab)[16] = tab_all[wave];
+    int offx[NT], offy[NT], offz[NT];  // table slots of this lane's column (box cell x, y, z) in every column tile
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        const int cell = n * 32 + col;
+        offx[n] = cell % E; offy[n] = 5 + (cell / E) % E;
+        offz[n] = cell < E * E * E ? 10 + cell / (E * E) : 15;  // padding columns read the zero slot
+    }
+    const float *gp[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) gp[m] = dout + ((size_t)b * C + min(cblk + m * 32 + col, C - 1)) * (DSUM ? (size_t)HW : vol);
+    const float *cb = coords + (size_t)b * vol * 3;
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.0f;
+
+    float4 gv[MT][4], gv_n[MT][4];
+    float cx_l, cy_l, cz_l, cx_n, cy_n, cz_n;  // the coordinates of output t + lane % 32 (lanes 32..63 mirror 0..31)
+    // branch-free and without selects on the loaded values (a conditional load is waited for at the end of its block, a select
+    // right after the load — in both cases before the MFMAs the load should hide under): addresses are clamped into the frame;
+    // outputs past the end of the range get an all-zero table row below, i.e. weight 0 (rows of channels >= C are never read back)
+    auto load = [&](size_t t, float4 (*g)[4], float &lx_, float &ly_, float &lz_) {
+        const size_t o = t + 16 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t oq = min(o + 4 * q, vol - 4);
+            const size_t gi = DSUM ? oq % (size_t)HW : oq;  // (H*W % 4 == 0: a group of 4 never leaves its plane)
+#pragma unroll
+            for (int m = 0; m < MT; ++m) g[m][q] = *reinterpret_cast<const float4 *>(gp[m] + gi);
+        }
+        const size_t oc = min(t + (size_t)col, vol - 1);
+        lx_ = cb[oc * 3]; ly_ = cb[oc * 3 + 1]; lz_ = cb[oc * 3 + 2];
+    };
+    if (t0 < t1) load(t0, gv, cx_l, cy_l, cz_l);
+    for (size_t t = t0; t < t1; t += 32) {
+        load(min(t + 32, vol - 32), gv_n, cx_n, cy_n, cz_n);  // (the last iteration's prefetch is a discarded re-read)
+        {   // this lane's output (t + col): the same weights as the tiled kernel — (x0+1) - cx on the floor corner, cx - x0 on
+            // the +1 corner unless it is outside the volume
+            const int x0 = (int)floorf(cx_l), y0 = (int)floorf(cy_l), z0 = (int)floorf(cz_l);
+            const float ax = (float)(x0 + 1) - cx_l, ay = (float)(y0 + 1) - cy_l, az = (float)(z0 + 1) - cz_l;
+            const float bx1 = x0 + 1 < W ? cx_l - (float)x0 : 0.0f, by1 = y0 + 1 < H ? cy_l - (float)y0 : 0.0f,
+                        bz1 = z0 + 1 < D ? cz_l - (float)z0 : 0.0f;
+            const int ix = x0 - ox, iy = y0 - oy;
+            const int iz = t + col < t1 ? z0 - oz : -2;  // past the end of this wave's range: no z slot matches, weight 0
+            float f[16];
+#pragma unroll
+            for (int e = 0; e < 5; ++e) {
+                f[e] = e == ix ? ax : e == ix + 1 ? bx1 : 0.0f;
+                f[5 + e] = e == iy ? ay : e == iy + 1 ? by1 : 0.0f;
+                f[10 + e] = e == iz ? az : e == iz + 1 ? bz1 : 0.0f;
+            }
+            f[15] = 0.0f;
+            __builtin_amdgcn_wave_barrier();  // (every lane is past its reads of the previous table: one wave, program order)
+            if (half == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) *reinterpret_cast<float4 *>(&tab[col][4 * q]) = make_float4(f[4 * q], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3]);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float *row = tab[16 * half + i];
+            float w[NT];
+#pragma unroll
+#ifndef MPHIP_DENSE_ABL_NOTAB
+            for (int n = 0; n < NT; ++n) w[n] = row[offz[n]] * row[offy[n]] * row[offx[n]];
+#else
+            for (int n = 0; n < NT; ++n) w[n] = cx_l + (float)(n + i);
+#endif
+#pragma unroll
+            for (int m = 0; m < MT; ++m) {
+                const float4 q4 = gv[m][i >> 2];
+                const float gmi = (i & 3) == 0 ? q4.x : (i & 3) == 1 ? q4.y : (i & 3) == 2 ? q4.z : q4.w;
+#pragma unroll
+#ifndef MPHIP_DENSE_ABL_NOMFMA
+                for (int n = 0; n < NT; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(gmi, w[n], acc[m][n], 0, 0, 0);
+#else
+                for (int n = 0; n < NT; ++n) acc[m][n][(i + n) & 15] += gmi * w[n];
+#endif
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gv[m][q] = gv_n[m][q];
+        cx_l = cx_n; cy_l = cy_n; cz_l = cz_n;
+    }
+    // fold the 4 waves pairwise through LDS with plain stores / loads, [value][lane] (conflict-free) — ds_add_f32 costs ~4 cycles
+    // per LANE: 192 of them per lane were 75 % of this kernel's time — then wave 0 writes the workgroup's partial [MT*32][DENSE_COLS]
+    __shared__ float xch[2][MT * NT * 16][64];
+#pragma unroll
+    for (int step = 0; step < 2; ++step) {
+        const int senders_from = step == 0 ? 2 : 1, nsend = step == 0 ? 2 : 1;  // waves 2,3 -> 0,1 ; then wave 1 -> 0
+        if (wave >= senders_from && wave < senders_from + nsend) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) xch[wave - senders_from][(m * NT + n) * 16 + r][lane] = acc[m][n][r];
+        }
+        __syncthreads();
+        if (wave < nsend) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] += xch[wave][(m * NT + n) * 16 + r][lane];
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float *pw = partial + (((size_t)b * gridDim.y + blockIdx.y) * DENSE_SEGS + blockIdx.x) * (MT * 32 * DENSE_COLS);
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;  // D layout: row (channel), column = lane & 31 (cell)
+                    pw[row * DENSE_COLS + n * 32 + col] = acc[m][n][r];
+                }
+    }
+}
+
+// dv[b][c][box cell] = sum over the frame's DENSE_SEGS partials, in index order (dv is zero-filled: only the box is written)
+__global__ void __launch_bounds__(256)
+warp_bwd_dense_fold_kernel(const float *__restrict__ partial, float *__restrict__ dv, const int *__restrict__ fbox, int C, int D,
+                           int H, int W, int cblocks) {
+    const int b = blockIdx.y;
+    const int *fb = fbox + b * FBOX_INTS;
+    const int E = fb[6];
+    if (!E) return;
+    const int cells = E * E * E;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= C * cells) return;
+    const int c = t / cells, cell = t % cells;
+    const int x = cell % E, y = (cell / E) % E, z = cell / (E * E);
+    if (x >= fb[3] || y >= fb[4] || z >= fb[5]) return;  // outside the (border-clamped) box: its weights are all zero
+    const float *p = partial + ((size_t)b * cblocks + c / (DENSE_MT * 32)) * DENSE_SEGS * (DENSE_MT * 32 * DENSE_COLS) +
+                     (size_t)(c % (DENSE_MT * 32)) * DENSE_COLS + cell;
+    float a = 0.0f;
+    for (int sgm = 0; sgm < DENSE_SEGS; ++sgm) a += p[(size_t)sgm * (DENSE_MT * 32 * DENSE_COLS)];
+    const int HW = H * W;
+    dv[((size_t)b * C + c) * D * HW + (size_t)(fb[2] + z) * HW + (fb[1] + y) * W + fb[0] + x] = a;
+}
+
+template <bool DSUM, int E>
+static void launch_dense_dv(const float *coords, const float *dout, float *partial, const int *fbox, int B, int C, int D, int H,
+                            int W, hipStream_t s) {
+    hipLaunchKernelGGL((warp_bwd_dense_dv_kernel<DSUM, E>), dim3(DENSE_SEGS, cdiv(C, DENSE_MT * 32), B), dim3(256), 0, s, coords,
+                       dout, partial, fbox, C, D, H, W);
 }
 
 template <bool ALIGN>
@@ -1043,7 +1288,9 @@ extern "C" int mphip_warp_coords(const float *field, const float *lin_d, const f
 extern "C" size_t mphip_warp_volume_bwd_workspace_bytes(int B, int C, int D, int H, int W) {
     if (B <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
     const size_t groups = (size_t)cdiv(C, WARP_BWD_CPB);
-    return (size_t)B * D * H * W * 3 * sizeof(float) * (1 + groups);
+    const size_t dense = (size_t)B * cdiv(C, DENSE_MT * 32) * DENSE_SEGS * (DENSE_MT * 32 * DENSE_COLS) * sizeof(float) +
+                         (size_t)B * FBOX_INTS * sizeof(int);  // partials of the dense dv path + per-frame sample boxes
+    return (size_t)B * D * H * W * 3 * sizeof(float) * (1 + groups) + dense;
 }
 
 extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const float *lin_d, const float *lin_h,
@@ -1069,13 +1316,31 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
         zero_fill(dv, bytes, s);  // the scatter pass accumulates with atomics
     }
     const int groups = cdiv(C, WARP_BWD_CPB);
+    int *fbox = nullptr;
+    if (dv) {  // frames whose samples all sit in one small box (the reference's own fields): dv as a GEMM over the outputs
+        float *partial = dcoords + nvox * 3 * groups;
+        const int cblocks = cdiv(C, DENSE_MT * 32);
+        fbox = (int *)(partial + (size_t)B * cblocks * DENSE_SEGS * (DENSE_MT * 32 * DENSE_COLS));
+        hipLaunchKernelGGL(warp_frame_box_kernel, dim3(B), dim3(1024), 0, s, (const float *)coords, fbox, D, H, W);
+        if (dsum) {
+            launch_dense_dv<true, 3>(coords, dout, partial, fbox, B, C, D, H, W, s);
+            launch_dense_dv<true, 4>(coords, dout, partial, fbox, B, C, D, H, W, s);
+            launch_dense_dv<true, 5>(coords, dout, partial, fbox, B, C, D, H, W, s);
+        } else {
+            launch_dense_dv<false, 3>(coords, dout, partial, fbox, B, C, D, H, W, s);
+            launch_dense_dv<false, 4>(coords, dout, partial, fbox, B, C, D, H, W, s);
+            launch_dense_dv<false, 5>(coords, dout, partial, fbox, B, C, D, H, W, s);
+        }
+        hipLaunchKernelGGL(warp_bwd_dense_fold_kernel, dim3(cdiv(C * 125, 256), B), dim3(256), 0, s, (const float *)partial, dv,
+                           (const int *)fbox, C, D, H, W, cblocks);
+    }
     dim3 grid((unsigned)((size_t)B * cdiv(D, 4) * cdiv(H, 16) * cdiv(W, 16)), groups);
     if (dsum)
         hipLaunchKernelGGL(warp_bwd_tiled_kernel<true>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
-                           dfield ? dcoords : nullptr, B, C, D, H, W);
+                           dfield ? dcoords : nullptr, (const int *)fbox, B, C, D, H, W);
     else
         hipLaunchKernelGGL(warp_bwd_tiled_kernel<false>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
-                           dfield ? dcoords : nullptr, B, C, D, H, W);
+                           dfield ? dcoords : nullptr, (const int *)fbox, B, C, D, H, W);
     if (dfield) {
         const size_t nf = (size_t)B * 3 * fD * fH * fW;
         hipLaunchKernelGGL(resize_trilinear_adjoint_kernel<true>, dim3(cdiv(nf, 256)), dim3(256), 0, s, (const float *)dcoords,

@@ -205,14 +205,23 @@ def _ag():
 
 
 @pytest.mark.parametrize("dsum", [False, True])
-@pytest.mark.parametrize("kind", ["faithful", "wide", "small"])
+@pytest.mark.parametrize("kind", ["faithful", "wide", "small", "mixed", "edge", "e5"])
 def test_warp_volume_backward(dev, kind, dsum):
     """grid_sample backward (input: atomicAdd scatter; grid: ATen's clip rule) + the align_corners=True field resize
-    (+ the depth sum), vs CPU autograd of the oracle's apply_warping_field."""
+    (+ the depth sum), vs CPU autograd of the oracle's apply_warping_field.  "faithful" frames (every sample in the low
+    corner, like the reference's own fields: a 3-wide box of source voxels) take the dense-reduction dv kernel, "wide" ones
+    the tiled scatter; "mixed" has one frame of each in a batch; "edge" has a 4-wide box in one frame and a box in the HIGH
+    corner (the +1 corner clipped away at the border) in the other; "e5" a 5-wide and a 4-wide box."""
+    faithful = R.seeded_tensor((2, 3, 64, 64, 64), 301, scale=1.3) + 0.4
+    wide = (R.seeded_tensor((2, 3, 64, 64, 64), 302) + 1.0) * torch.tensor([20.0, 20.0, 6.0]).view(1, 3, 1, 1, 1) - 2.0
+    high = R.seeded_tensor((1, 3, 64, 64, 64), 304, scale=0.9) + torch.tensor([22.6, 14.6, 6.6]).view(1, 3, 1, 1, 1)
     fields = {
-        "faithful": R.seeded_tensor((2, 3, 64, 64, 64), 301, scale=1.3) + 0.4,
-        "wide": (R.seeded_tensor((2, 3, 64, 64, 64), 302) + 1.0) * torch.tensor([20.0, 20.0, 6.0]).view(1, 3, 1, 1, 1) - 2.0,
+        "faithful": faithful,
+        "wide": wide,
         "small": R.seeded_tensor((2, 3, 5, 7, 9), 303, scale=6.0) + 4.0,
+        "mixed": torch.cat([faithful[:1], wide[1:]], dim=0),
+        "edge": torch.cat([faithful[:1] * 1.6, high], dim=0),
+        "e5": torch.cat([faithful[:1] * 2.3, faithful[1:] * 1.6], dim=0),
     }
     C, D, H, W = (12, 8, 16, 24) if kind != "small" else (5, 6, 10, 14)
     v = R.seeded_tensor((2, C, D, H, W), 310, scale=1.7).requires_grad_(True)
