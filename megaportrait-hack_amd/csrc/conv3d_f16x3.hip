@@ -74,18 +74,28 @@ __device__ unsigned long long g_f16x3_prof[8];
 
 // ---- weight packing ----------------------------------------------------------------------------
 // header (16 B): [0] inv_scale (float)  [1] scale (float)  [2] max|w| bits (uint)  [3] unused
-__global__ void f16x3_absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ hdr) {
+__global__ void __launch_bounds__(256) f16x3_absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ hdr) {
     float m = 0.0f;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    const size_t n4 = ((uintptr_t)w & 15) == 0 ? n / 4 : 0;  // 16-byte loads when the tensor is aligned (torch allocations are)
+    const float4 *w4 = reinterpret_cast<const float4 *>(w);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 q = w4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
         m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
     __shared__ float red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    // one atomic per workgroup (same-address atomics serialise in L2: they, not the read, set this kernel's time)
-    if (threadIdx.x == 0)
-        atomicMax(hdr + 2, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));  // non-negative floats order like uints
+    // Same-address atomics serialise in L2 (with one per workgroup they, not the read, set this kernel's time — which is why the
+    // grid used to be capped at 256 workgroups, i.e. 1/8 of the read bandwidth): a workgroup only issues its atomicMax when its
+    // maximum beats what the header already holds (a device-scope load), so after the first few workgroups almost none do.
+    if (threadIdx.x == 0) {
+        const unsigned mine = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));  // non-negative floats order like uints
+        if (mine > __hip_atomic_load(hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(hdr + 2, mine);
+    }
 }
 
 __device__ __forceinline__ float weight_scale(unsigned maxbits) {
@@ -96,30 +106,56 @@ __device__ __forceinline__ float weight_scale(unsigned maxbits) {
     return ldexpf(1.0f, 15 - e);  // m*scale < 2^15 = 32768
 }
 
-// OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*NG + g][part][tap][kg][co][8] f16 (after the header)
-__global__ void f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in,
-                                  float *__restrict__ hdr_out, int Co, int Ci, int transposed) {
+// OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*NG + g][part][tap][kg][co][8] f16 (after the header).
+// A training step re-packs every weight twice (forward and bwd-data direction: 2 x 194 MB read, 2 x 194 MB written for G3d), so
+// this is a bandwidth kernel: a workgroup owns (32 output channels, one 16-channel chunk), loads that tile with 16-byte loads
+// of contiguous runs (forward: 32 runs of 16 ci x 27 taps; transposed: 16 runs of 32 co x 27 taps), transposes it in LDS (odd
+// pitches: conflict-free both ways) and writes every (slab, part, tap, kg) piece as 32 contiguous 16-byte fragments.
+constexpr int PK_CO = 32;
+constexpr int PK_LDS_FLOATS = PK_CO * (F16X3_KC * 27 + 1);   // forward: 32 rows of 433; transposed: 16 rows of 865 (fewer floats)
+static_assert(PK_LDS_FLOATS >= F16X3_KC * (PK_CO * 27 + 1), "pack tile");
+__global__ void __launch_bounds__(256)
+f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in, float *__restrict__ hdr_out, int Co,
+                  int Ci, int transposed) {
+    __shared__ __attribute__((aligned(16))) float tile[PK_LDS_FLOATS];
     const float scale = weight_scale(hdr_in[2]);
-    const int nchunks = Ci / F16X3_KC;
-    const size_t n = (size_t)(Co / F16X3_COT) * nchunks * F16X3_NG * (SLAB_HALFS / 2);  // one thread per (hi,lo) pair
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        size_t r = i;
-        const int e = (int)(r % 8); r /= 8;
-        const int co = (int)(r % F16X3_COT); r /= F16X3_COT;
-        const int kg = (int)(r % 2); r /= 2;
-        const int tg = (int)(r % F16X3_TG); r /= F16X3_TG;
-        const int g = (int)(r % F16X3_NG); r /= F16X3_NG;
-        const int chunk = (int)(r % nchunks);
-        const int cot = (int)(r / nchunks);
-        const int ci = chunk * F16X3_KC + kg * 8 + e, tap = g * F16X3_TG + tg, cog = cot * F16X3_COT + co;
-        _Float16 hi, lo;
-        // transposed: w is the original conv's [Ci][Co][27] weight, this pack its bwd-data conv (taps reversed)
-        const size_t src = transposed ? ((size_t)ci * Co + cog) * 27 + (26 - tap) : ((size_t)cog * Ci + ci) * 27 + tap;
-        split_f16(w[src] * scale, hi, lo);
+    const int nchunks = Ci / F16X3_KC, subs = F16X3_COT / PK_CO;
+    int bid = blockIdx.x;
+    const int sub = bid % subs; bid /= subs;
+    const int chunk = bid % nchunks;
+    const int cot = bid / nchunks;
+    const int cog0 = cot * F16X3_COT + sub * PK_CO, ci0 = chunk * F16X3_KC;
+    // transposed: w is the original conv's [Ci][Co][27] weight, this pack its bwd-data conv (taps reversed)
+    const int rows = transposed ? F16X3_KC : PK_CO, run = transposed ? PK_CO * 27 : F16X3_KC * 27, pitch = run + 1;
+    for (int i = threadIdx.x; i < rows * (run / 4); i += 256) {
+        const int r = i / (run / 4), q = i % (run / 4);
+        const size_t src = transposed ? ((size_t)(ci0 + r) * Co + cog0) * 27 : ((size_t)(cog0 + r) * Ci + ci0) * 27;
+        const float4 v = *reinterpret_cast<const float4 *>(w + src + 4 * q);
+        float *d = tile + r * pitch + 4 * q;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    // one item = (slab g, tap tg, kg, co): 8 consecutive ci -> one 16-byte fragment of hi and one of lo
+    for (int i = threadIdx.x; i < F16X3_NG * F16X3_TG * 2 * PK_CO; i += 256) {
+        const int co = i % PK_CO;
+        int r = i / PK_CO;
+        const int kg = r % 2; r /= 2;
+        const int tg = r % F16X3_TG;
+        const int g = r / F16X3_TG;
+        const int tap = g * F16X3_TG + tg;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = kg * 8 + e;
+            const float v = transposed ? tile[ci * pitch + co * 27 + (26 - tap)] : tile[co * pitch + ci * 27 + tap];
+            _Float16 h, l;
+            split_f16(v * scale, h, l);
+            hi[e] = h; lo[e] = l;
+        }
         const size_t slab = ((size_t)cot * nchunks + chunk) * F16X3_NG + g;
-        const size_t inner = (((size_t)tg * 2 + kg) * F16X3_COT + co) * 8 + e;
-        out[slab * SLAB_HALFS + inner] = hi;
-        out[slab * SLAB_HALFS + SLAB_HALFS / 2 + inner] = lo;
+        const size_t inner = (((size_t)tg * 2 + kg) * F16X3_COT + sub * PK_CO + co) * 8;
+        *reinterpret_cast<half8 *>(out + slab * SLAB_HALFS + inner) = hi;
+        *reinterpret_cast<half8 *>(out + slab * SLAB_HALFS + SLAB_HALFS / 2 + inner) = lo;
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr_out[0] = 1.0f / scale;
@@ -735,15 +771,15 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed,
     } else {
         zero_fill(out, 16, s);  // header: the absmax kernel accumulates with atomicMax
         const size_t n = (size_t)Co * Ci * (k == 3 ? 27 : 1);
-        hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(256, (n + 8191) / 8192)), dim3(256), 0, s, w, n,
+        hipLaunchKernelGGL(f16x3_absmax_kernel, dim3((unsigned)std::min<size_t>(2048, (n + 4095) / 4096)), dim3(256), 0, s, w, n,
                            (unsigned *)out);
     }
     if (k == 1)
         hipLaunchKernelGGL(f16x3_pack_k1_kernel, dim3(256), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), hdr, (float *)out, Co,
                            Ci, transposed);
     else
-        hipLaunchKernelGGL(f16x3_pack_kernel, dim3(2048), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), hdr, (float *)out, Co, Ci,
-                           transposed);
+        hipLaunchKernelGGL(f16x3_pack_kernel, dim3((unsigned)((Co / PK_CO) * (Ci / F16X3_KC))), dim3(256), 0, s, w,
+                           (_Float16 *)((char *)out + 16), hdr, (float *)out, Co, Ci, transposed);
     return check_launch("pack_conv_weight(f16x3)");
 }
 
