@@ -706,9 +706,9 @@ warp_bwd_tiled_kernel(const float *__restrict__ v, const float *__restrict__ coo
     const int b = bid / tiles_d;
     const int ox = tw * 16 + (threadIdx.x & 15), oy = th * 16 + (threadIdx.x >> 4);
     const int c0 = blockIdx.y * WB_CH, cs = min(WB_CH, C - c0);
-    // a frame whose samples all fall into one tiny box has its dv computed by warp_bwd_dense_dv_kernel (block-uniform)
-    float *const dv = (fbox && fbox[b * FBOX_INTS + 6]) ? nullptr : dv_all;
-    if (!dv && !dcoords) return;
+    // a frame whose samples all fall into one small box belongs to the warp_bwd_dense_* kernels (block-uniform)
+    if (fbox && fbox[b * FBOX_INTS + 6]) return;
+    float *const dv = dv_all;
 
     bool ok[4];
     int base[4], dxyz[4];
@@ -1048,6 +1048,101 @@ warp_bwd_dense_fold_kernel(const float *__restrict__ partial, float *__restrict_
     dv[((size_t)b * C + c) * D * HW + (size_t)(fb[2] + z) * HW + (fb[1] + y) * W + fb[0] + x] = a;
 }
 
+// Coordinate gradient of the same frames.  d out / d coord is linear in the 8 corner values, so per output voxel
+//     S_k = sum_c dout[c][o] * v[c][corner_k(o)]       (8 FMAs per channel, the corners read from an LDS copy of the box)
+// and the trilinear derivative formulas are applied ONCE to the eight S_k instead of once per channel.  One slab of gradients
+// (the tiled kernel writes one per 8-channel slice for the resize adjoint to sum), no re-read of v from HBM.
+constexpr int DENSE_DC_CH = 96;   // channels per LDS box image (48 KB at E = 5)
+template <bool DSUM>
+__global__ void __launch_bounds__(256)
+warp_bwd_dense_dcoords_kernel(const float *__restrict__ v, const float *__restrict__ coords, const float *__restrict__ dout,
+                              float *__restrict__ dcoords, const int *__restrict__ fbox, int C, int D, int H, int W) {
+    __shared__ float vbox[DENSE_DC_CH * DENSE_E_MAX * DENSE_E_MAX * DENSE_E_MAX];
+    const int b = blockIdx.y;
+    const int *fb = fbox + b * FBOX_INTS;
+    const int E = fb[6];
+    if (!E) return;  // block-uniform: the tiled kernel owns this frame
+    const int ox = fb[0], oy = fb[1], oz = fb[2], ex = fb[3], ey = fb[4], ez = fb[5];
+    const int cells = E * E * E;
+    const int HW = H * W;
+    const size_t vol = (size_t)D * HW;
+    const size_t seg_len = ((vol + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const size_t t_begin = blockIdx.x * seg_len;
+    constexpr int OPT = 4;  // outputs per thread
+    float S[OPT][8];
+#pragma unroll
+    for (int i = 0; i < OPT; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) S[i][k] = 0.0f;
+    int cbase[OPT], dx[OPT], dy[OPT], dz[OPT];
+    size_t gi[OPT];
+    bool ok[OPT];
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        const size_t t = t_begin + (size_t)i * 256 + threadIdx.x;
+        ok[i] = t < min(vol, t_begin + seg_len);
+        const size_t tc = ok[i] ? t : 0;
+        const float *cp = coords + ((size_t)b * vol + tc) * 3;
+        const int x0 = (int)floorf(cp[0]), y0 = (int)floorf(cp[1]), z0 = (int)floorf(cp[2]);
+        dx[i] = x0 + 1 < W ? 1 : 0;
+        dy[i] = y0 + 1 < H ? E : 0;
+        dz[i] = z0 + 1 < D ? E * E : 0;
+        cbase[i] = ((z0 - oz) * E + (y0 - oy)) * E + (x0 - ox);
+        gi[i] = DSUM ? tc % (size_t)HW : tc;
+    }
+    for (int c0 = 0; c0 < C; c0 += DENSE_DC_CH) {
+        const int cs = min(DENSE_DC_CH, C - c0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < cs * cells; i += 256) {
+            const int c = i / cells, cell = i - c * cells;
+            const int x = cell % E, y = (cell / E) % E, z = cell / (E * E);
+            vbox[i] = (x < ex && y < ey && z < ez)
+                          ? v[((size_t)b * C + c0 + c) * vol + (size_t)(oz + z) * HW + (oy + y) * W + ox + x] : 0.0f;
+        }
+        __syncthreads();
+        const float *gp = dout + ((size_t)b * C + c0) * (DSUM ? (size_t)HW : vol);
+#pragma unroll 4
+        for (int c = 0; c < cs; ++c) {
+            const float *vb = vbox + c * cells;
+#pragma unroll
+            for (int i = 0; i < OPT; ++i) {
+                const float g = ok[i] ? gp[(size_t)c * (DSUM ? (size_t)HW : vol) + gi[i]] : 0.0f;
+                const float *q = vb + cbase[i];
+                S[i][0] = fmaf(g, q[0], S[i][0]);
+                S[i][1] = fmaf(g, q[dx[i]], S[i][1]);
+                S[i][2] = fmaf(g, q[dy[i]], S[i][2]);
+                S[i][3] = fmaf(g, q[dy[i] + dx[i]], S[i][3]);
+                S[i][4] = fmaf(g, q[dz[i]], S[i][4]);
+                S[i][5] = fmaf(g, q[dz[i] + dx[i]], S[i][5]);
+                S[i][6] = fmaf(g, q[dz[i] + dy[i]], S[i][6]);
+                S[i][7] = fmaf(g, q[dz[i] + dy[i] + dx[i]], S[i][7]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < OPT; ++i) {
+        if (!ok[i]) continue;
+        const size_t t = t_begin + (size_t)i * 256 + threadIdx.x;
+        const float *cp = coords + ((size_t)b * vol + t) * 3;
+        const float cx = cp[0], cy = cp[1], cz = cp[2];
+        const int x0 = (int)floorf(cx), y0 = (int)floorf(cy), z0 = (int)floorf(cz);
+        const bool vx = dx[i] != 0, vy = dy[i] != 0, vz = dz[i] != 0;
+        // corners outside the volume: ATen skips them (value 0, weight 0) — the same rule as the tiled kernel
+        const float ax = (float)(x0 + 1) - cx, ay = (float)(y0 + 1) - cy, az = (float)(z0 + 1) - cz;
+        const float bx1 = vx ? cx - (float)x0 : 0.0f, by1 = vy ? cy - (float)y0 : 0.0f, bz1 = vz ? cz - (float)z0 : 0.0f;
+        const float v000 = S[i][0], v100 = vx ? S[i][1] : 0.0f, v010 = vy ? S[i][2] : 0.0f, v110 = (vx && vy) ? S[i][3] : 0.0f;
+        const float v001 = vz ? S[i][4] : 0.0f, v101 = (vz && vx) ? S[i][5] : 0.0f, v011 = (vz && vy) ? S[i][6] : 0.0f,
+                    v111 = (vz && vy && vx) ? S[i][7] : 0.0f;
+        const float gx = ((v100 - v000) * ay + (v110 - v010) * by1) * az + ((v101 - v001) * ay + (v111 - v011) * by1) * bz1;
+        const float gy = ((v010 - v000) * ax + (v110 - v100) * bx1) * az + ((v011 - v001) * ax + (v111 - v101) * bx1) * bz1;
+        const float gz = ((v001 - v000) * ax + (v101 - v100) * bx1) * ay + ((v011 - v010) * ax + (v111 - v110) * bx1) * by1;
+        float *o = dcoords + ((size_t)b * vol + t) * 3;  // slab 0
+        o[0] = (cx > 0.0f && cx < (float)(W - 1)) ? gx : 0.0f;
+        o[1] = (cy > 0.0f && cy < (float)(H - 1)) ? gy : 0.0f;
+        o[2] = (cz > 0.0f && cz < (float)(D - 1)) ? gz : 0.0f;
+    }
+}
+
 template <bool DSUM, int E>
 static void launch_dense_dv(const float *coords, const float *dout, float *partial, const int *fbox, int B, int C, int D, int H,
                             int W, hipStream_t s) {
@@ -1088,7 +1183,7 @@ __device__ __forceinline__ float adj_w(int o, int i, int in, int out) {
 template <bool ALIGN>
 __global__ void __launch_bounds__(256)
 resize_trilinear_adjoint_kernel(const float *__restrict__ gout, float *__restrict__ gin, int B, int C, int iD, int iH, int iW,
-                                int oD, int oH, int oW, int slabs, int interleaved) {
+                                int oD, int oH, int oW, int slabs_all, int interleaved, const int *__restrict__ fbox) {
     const size_t ivol = (size_t)iD * iH * iW, ovol = (size_t)oD * oH * oW;
     const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)B * C * ivol) return;
@@ -1099,6 +1194,7 @@ resize_trilinear_adjoint_kernel(const float *__restrict__ gout, float *__restric
     const int id = (int)(r % iD);
     r /= iD;
     const int ch = (int)(r % C), b = (int)(r / C);
+    const int slabs = (fbox && fbox[b * FBOX_INTS + 6]) ? 1 : slabs_all;  // a dense frame's coordinate gradient is one slab
     int dlo, dhi, hlo, hhi, wlo, whi;
     adj_bounds<ALIGN>(id, iD, oD, dlo, dhi);
     adj_bounds<ALIGN>(ih, iH, oH, hlo, hhi);
@@ -1316,12 +1412,13 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
         zero_fill(dv, bytes, s);  // the scatter pass accumulates with atomics
     }
     const int groups = cdiv(C, WARP_BWD_CPB);
-    int *fbox = nullptr;
-    if (dv) {  // frames whose samples all sit in one small box (the reference's own fields): dv as a GEMM over the outputs
-        float *partial = dcoords + nvox * 3 * groups;
-        const int cblocks = cdiv(C, DENSE_MT * 32);
-        fbox = (int *)(partial + (size_t)B * cblocks * DENSE_SEGS * (DENSE_MT * 32 * DENSE_COLS));
-        hipLaunchKernelGGL(warp_frame_box_kernel, dim3(B), dim3(1024), 0, s, (const float *)coords, fbox, D, H, W);
+    // frames whose samples all sit in one small box (the reference's own fields) take the dense kernels: dv as a GEMM over the
+    // outputs, the coordinate gradient from an LDS image of the box; every other frame the tiled scatter below
+    float *partial = dcoords + nvox * 3 * groups;
+    const int cblocks = cdiv(C, DENSE_MT * 32);
+    int *fbox = (int *)(partial + (size_t)B * cblocks * DENSE_SEGS * (DENSE_MT * 32 * DENSE_COLS));
+    hipLaunchKernelGGL(warp_frame_box_kernel, dim3(B), dim3(1024), 0, s, (const float *)coords, fbox, D, H, W);
+    if (dv) {
         if (dsum) {
             launch_dense_dv<true, 3>(coords, dout, partial, fbox, B, C, D, H, W, s);
             launch_dense_dv<true, 4>(coords, dout, partial, fbox, B, C, D, H, W, s);
@@ -1334,6 +1431,15 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
         hipLaunchKernelGGL(warp_bwd_dense_fold_kernel, dim3(cdiv(C * 125, 256), B), dim3(256), 0, s, (const float *)partial, dv,
                            (const int *)fbox, C, D, H, W, cblocks);
     }
+    if (dfield) {
+        const dim3 dgrid((unsigned)cdiv((size_t)D * H * W, 1024), B);  // 4 outputs per thread
+        if (dsum)
+            hipLaunchKernelGGL(warp_bwd_dense_dcoords_kernel<true>, dgrid, dim3(256), 0, s, v, (const float *)coords, dout, dcoords,
+                               (const int *)fbox, C, D, H, W);
+        else
+            hipLaunchKernelGGL(warp_bwd_dense_dcoords_kernel<false>, dgrid, dim3(256), 0, s, v, (const float *)coords, dout, dcoords,
+                               (const int *)fbox, C, D, H, W);
+    }
     dim3 grid((unsigned)((size_t)B * cdiv(D, 4) * cdiv(H, 16) * cdiv(W, 16)), groups);
     if (dsum)
         hipLaunchKernelGGL(warp_bwd_tiled_kernel<true>, grid, dim3(256), 0, s, v, (const float *)coords, dout, dv,
@@ -1344,7 +1450,7 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
     if (dfield) {
         const size_t nf = (size_t)B * 3 * fD * fH * fW;
         hipLaunchKernelGGL(resize_trilinear_adjoint_kernel<true>, dim3(cdiv(nf, 256)), dim3(256), 0, s, (const float *)dcoords,
-                           dfield, B, 3, fD, fH, fW, D, H, W, groups, 1);
+                           dfield, B, 3, fD, fH, fW, D, H, W, groups, 1, (const int *)fbox);
     }
     return check_launch("warp_volume_bwd");
 }
