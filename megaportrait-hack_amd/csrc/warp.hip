@@ -460,7 +460,10 @@ warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__
 // the warped volume, which is never written).  If the source box of ALL D slices fits the LDS image (the reference's own
 // fields: a 4^3 corner) it is staged once, [voxel][channel] with 16-byte tap reads; otherwise the taps are gathered from
 // global memory through the L1 (lanes along w, x-neighbours in pairs).
-constexpr int K3_TH = 16, K3_TW = 16;
+#ifndef MPHIP_K3_TH
+#define MPHIP_K3_TH 16
+#endif
+constexpr int K3_TH = MPHIP_K3_TH, K3_TW = 256 / MPHIP_K3_TH;
 template <int CPB>
 __global__ void __launch_bounds__(256)
 warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
@@ -468,14 +471,22 @@ warp_gather_dsum_kernel(const float *__restrict__ v, const float *__restrict__ c
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
-    const int tiles_w = (W + K3_TW - 1) / K3_TW, tiles_h = (H + K3_TH - 1) / K3_TH;
-    const int tile = blockIdx.x % (tiles_w * tiles_h), b = blockIdx.x / (tiles_w * tiles_h);
-    const int h = (tile / tiles_w) * K3_TH + (int)(threadIdx.x >> 4);
-    const int w = (tile % tiles_w) * K3_TW + (int)(threadIdx.x & 15);
+    const int tiles_w = (W + K3_TW - 1) / K3_TW, tiles_h = (H + K3_TH - 1) / K3_TH, ntile = tiles_w * tiles_h;
+    // XCD-aware order: the tiles of one (frame, channel slice) are consecutive logical ids, i.e. they run on ONE XCD at about the
+    // same time — w-neighbours share every 128-byte line of a source row, h-neighbours the halo rows, and with the hardware's
+    // round-robin (tile t -> XCD t % 8) each of those lines was fetched into up to four different L2s (travelling fields: 5x the
+    // algorithmic bytes crossed the fabric, at 6.9 TB/s — the kernel's limit)
+    unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = (int)(bid % ntile); bid /= ntile;
+    const int slices = (C + CPB - 1) / CPB;
+    const int slice = (int)(bid % slices), b = (int)(bid / slices);
+    static_assert(K3_TH * K3_TW == 256, "one thread per position of the tile");
+    const int h = (tile / tiles_w) * K3_TH + (int)(threadIdx.x / K3_TW);
+    const int w = (tile % tiles_w) * K3_TW + (int)(threadIdx.x % K3_TW);
     const bool active = h < H && w < W;
     const int p = h * W + w;
     const size_t vol = (size_t)D * HW;
-    const int c0 = blockIdx.y * CPB;
+    const int c0 = slice * CPB;
     const int cs = min(CPB, C - c0);
     const int cs_pad = lds_pitch_for(cs);
     const float *cp = coords + ((size_t)b * D * HW + (active ? p : 0)) * 3;
@@ -651,7 +662,7 @@ static int warp_volume_dsum_impl(const char *name, const float *v, size_t v_fram
     if (rc) return rc;
     constexpr int CPB = 16;
     const int tiles = ((H + K3_TH - 1) / K3_TH) * ((W + K3_TW - 1) / K3_TW);
-    hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles), cdiv(C, CPB)), dim3(256), 0, s, v,
+    hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles * cdiv(C, CPB))), dim3(256), 0, s, v,
                        coords, out, B, C, D, H, W, v_frame_stride);
     return check_launch(name);
 }
