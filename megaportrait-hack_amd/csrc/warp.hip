@@ -847,7 +847,7 @@ constexpr int DENSE_COLS = 128;      // column stride of a partial (>= 5^3)
 __host__ __device__ constexpr int dense_ntiles(int E) { return E == 3 ? 1 : E == 4 ? 2 : 4; }  // 32-cell MFMA column tiles
 
 __global__ void __launch_bounds__(1024)
-warp_frame_box_kernel(const float *__restrict__ coords, int *__restrict__ fbox, int D, int H, int W) {
+warp_frame_box_kernel(const float *__restrict__ coords, int *__restrict__ fbox, int D, int H, int W, int allow_dense) {
     __shared__ int red[16 * 6];
     const int b = blockIdx.x;
     const size_t vol = (size_t)D * H * W;
@@ -877,7 +877,7 @@ warp_frame_box_kernel(const float *__restrict__ coords, int *__restrict__ fbox, 
         const bool shape_ok = (H * W) % 4 == 0 && vol >= 32;
         int *o = fbox + b * FBOX_INTS;
         o[0] = lx; o[1] = ly; o[2] = lz; o[3] = ex; o[4] = ey; o[5] = ez;
-        o[6] = (e <= DENSE_E_MAX && shape_ok) ? e : 0;
+        o[6] = (e <= DENSE_E_MAX && shape_ok && allow_dense) ? e : 0;
         o[7] = 0;
     }
 }
@@ -1428,7 +1428,9 @@ extern "C" int mphip_warp_volume_bwd(const float *v, const float *field, const f
     float *partial = dcoords + nvox * 3 * groups;
     const int cblocks = cdiv(C, DENSE_MT * 32);
     int *fbox = (int *)(partial + (size_t)B * cblocks * DENSE_SEGS * (DENSE_MT * 32 * DENSE_COLS));
-    hipLaunchKernelGGL(warp_frame_box_kernel, dim3(B), dim3(1024), 0, s, (const float *)coords, fbox, D, H, W);
+    const char *no_dense = getenv("MPHIP_WARP_BWD_DENSE");  // "0": every frame through the tiled scatter (tests: dense == tiled)
+    hipLaunchKernelGGL(warp_frame_box_kernel, dim3(B), dim3(1024), 0, s, (const float *)coords, fbox, D, H, W,
+                       (no_dense && no_dense[0] == '0') ? 0 : 1);
     if (dv) {
         if (dsum) {
             launch_dense_dv<true, 3>(coords, dout, partial, fbox, B, C, D, H, W, s);

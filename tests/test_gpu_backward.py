@@ -239,6 +239,27 @@ def test_warp_volume_backward(dev, kind, dsum):
     assert rel_err(fg.grad, f.grad) < 1e-4
 
 
+@pytest.mark.parametrize("dsum", [False, True])
+def test_warp_volume_backward_dense_equals_tiled_at_full_size(dev, ops, dsum, monkeypatch):
+    """Property at BASELINE's size (96x16x64x64, where the CPU oracle takes minutes): on a field like the reference's own — every
+    sample in the low corner, boxes of 4 and 5 source voxels — the dense path (fp32-MFMA GEMM for dv, LDS box image for the
+    coordinate gradient) and the tiled atomic scatter (MPHIP_WARP_BWD_DENSE=0) are two implementations of the same sums; the
+    small-shape tests above pin both to the oracle.  The dense path is deterministic: two runs are bitwise equal."""
+    torch.manual_seed(5)
+    v = torch.randn(2, 96, 16, 64, 64, device=dev)
+    f = torch.rand(2, 3, 64, 64, 64, device=dev) * torch.tensor([1.9, 2.9], device=dev).view(2, 1, 1, 1, 1) - 0.3   # + linspace(-1, 1): floors up to 2 / 3
+    dout = torch.randn((2, 96, 64, 64) if dsum else (2, 96, 16, 64, 64), device=dev)
+    dv, df = ops.warp_volume_bwd(v, f, dout, dsum)
+    dv2, df2 = ops.warp_volume_bwd(v, f, dout, dsum)
+    assert torch.equal(dv, dv2) and torch.equal(df, df2)
+    monkeypatch.setenv("MPHIP_WARP_BWD_DENSE", "0")
+    dv_t, df_t = ops.warp_volume_bwd(v, f, dout, dsum)
+    monkeypatch.delenv("MPHIP_WARP_BWD_DENSE")
+    assert int((dv != 0).sum()) <= 2 * 96 * 5 ** 3     # the gradient lives in the sampled corner only
+    assert rel_err(dv, dv_t.cpu()) < 2e-5                # 65536-term sums in different orders
+    assert rel_err(df, df_t.cpu()) < 2e-5
+
+
 def test_warp_field_compose_backward(dev):
     theta = R.seeded_tensor((3, 3, 4), 201).requires_grad_(True)
     em = ((R.seeded_tensor((3, 3, 16, 16, 16), 202) + 1.0) * 0.5).requires_grad_(True)
