@@ -358,6 +358,30 @@ def test_hot_slice_backward(dev, M):
     _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3)
 
 
+def test_hot_slice_backward_is_bitwise_reproducible(dev, M):
+    """With the reference's kind of fields (small source boxes: the dense warp backward, no atomics) every gradient of the hot
+    slice is bitwise identical from run to run — the tiled scatter of r01 (fp32 atomics) was the only unordered sum on the path."""
+    sd = R.seeded_gbase_hot_state_dict(7)
+    hot = M.GbaseHotSlice()
+    M.load_hot_state_dict(hot, sd)
+    hot = hot.to(dev).train()
+    inp = R.seeded_hot_inputs(2, 44, D=16, H=32, W=32)
+    dout = None
+    runs = []
+    for _ in range(2):
+        hot.zero_grad(set_to_none=True)
+        gpu_in = {k: v.to(dev).requires_grad_(True) for k, v in inp.items()}
+        out = hot.forward_any_size(**gpu_in)
+        dout = R.seeded_tensor(tuple(out.shape), 93).to(dev) if dout is None else dout
+        out.backward(dout)
+        runs.append(({k: t.grad.clone() for k, t in gpu_in.items()},
+                     {n: p.grad.clone() for n, p in hot.named_parameters() if p.grad is not None}))
+    for k in runs[0][0]:
+        assert torch.equal(runs[0][0][k], runs[1][0][k]), k
+    for n in runs[0][1]:
+        assert torch.equal(runs[0][1][n], runs[1][1][n]), n
+
+
 def test_config3_train_step_full_size(dev, M):
     """BASELINE config 3's per-GPU shard at its own size: B=4 frames of the 512^2 volume (96x16x64x64) through the
     whole hot slice under autograd — the full-resolution bwd-weight split/slab-reduce plan, warp_volume_bwd at
