@@ -204,7 +204,7 @@ def cpu_baseline(frames):
                       f"(ATen CPU fp32, {threads} threads), {dt:.1f} s"}
 
 
-def end_to_end(dev, B, steps=8, warmup=3, fp16=False):
+def end_to_end(dev, B, steps=8, warmup=3, fp16=False, channels_last=False):
     """Gbase.forward(xs, xd) -> (image, pyramids) on synthetic 512x512 RGB pairs (xs, xd ~ U[0,1)): the
     full generator — Eapp / Emtn / G2d bodies on PyTorch-ROCm (MIOpen), the 3D tail, the hot slice and G2d's head on
     the HIP kernels.  Random-init weights (gbase.Gbase builds offline).  Side measurement: the hot slice is ~10 % of
@@ -213,6 +213,8 @@ def end_to_end(dev, B, steps=8, warmup=3, fp16=False):
 
     torch.manual_seed(20240501)
     g = gbase.Gbase().to(dev).eval()
+    if channels_last:
+        g.channels_last_2d()
     gen = torch.Generator(device="cpu").manual_seed(20240501)
     xs = torch.rand(B, 3, 512, 512, generator=gen).to(dev)
     xd = torch.rand(B, 3, 512, 512, generator=gen).to(dev)
@@ -230,6 +232,8 @@ def end_to_end(dev, B, steps=8, warmup=3, fp16=False):
     torch.cuda.empty_cache()
     prec = ("torch.autocast(float16) around the generator like the reference's training loop (train.py:188): MIOpen fp16 2D convs; "
             "the HIP kernels stay fp32 / f16x3") if fp16 else "MIOpen fp32 2D convs"
+    if channels_last:
+        prec += "; motionEncoder and G2d in torch.channels_last (Gbase.channels_last_2d)"
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "batch": B, "steps": steps,
             "workload": "gbase.Gbase.forward(xs, xd) -> (image [B,3,512,512], pyramids), xs/xd ~ U[0,1), random init; "
                         "2D encoders/decoder on PyTorch-ROCm, 3D tail + hot slice + G2d head on libmphip", "precision_2d": prec}
@@ -500,6 +504,7 @@ def main():
                 line["fp32_exact"] = fp32_exact(hot, inp, B)
             line["end_to_end"] = end_to_end(dev, B)
             line["end_to_end_autocast_fp16"] = end_to_end(dev, B, fp16=True)
+            line["end_to_end_autocast_fp16_nhwc"] = end_to_end(dev, B, fp16=True, channels_last=True)
         if world == 1 and args.torch_gpu_baseline:
             line["torch_rocm_baseline"] = torch_rocm_baseline(dev, B)
         if world == 1 and not args.no_cpu_baseline:

@@ -225,6 +225,16 @@ def test_gbase_forward_end_to_end_small(G):
     assert maxabs(img, want_img) < 1e-3
     for k in pyr:
         assert maxabs(pyr[k], want_pyr[k]) < 1e-3
+    # the NHWC option is a layout choice: same keys, same image (up to MIOpen's kernel selection), forward and reenact
+    keys = list(g.state_dict())
+    with torch.no_grad():
+        g.channels_last_2d()
+        img_cl, _ = g.forward_any_size(xs.to(dev), xd.to(dev))
+        ree = g.reenact(xs[:1].to(dev), xd.to(dev))
+        g.channels_last_2d(False)
+    assert list(g.state_dict()) == keys
+    assert maxabs(img_cl, want_img) < 1e-3
+    assert ree.shape == (2, 3, 64, 64) and ree.is_contiguous() and torch.isfinite(ree).all()
 
 
 @pytest.mark.gpu
