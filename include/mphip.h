@@ -272,7 +272,10 @@ int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, c
                               const float *gamma, const float *w2, const float *ab, float *dx, float *dres, int N,
                               int C, int S, int G, int act, void *stream);
 int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
-int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
+size_t mphip_upsample_trilinear2_bwd_workspace_bytes(int NC, int D, int H, int W);
+/* workspace: three separable bandwidth passes (D, H, W); NULL: one gather pass that needs no scratch (slower on large tensors) */
+int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *workspace,
+                                  size_t workspace_bytes, void *stream);
 int mphip_upsample_nearest_bwd(const float *dout, float *dx, int NC, int D, int H, int W, int sD, int sH, int sW,
                                void *stream);
 int mphip_small_gemm(const float *a, const float *a2, const float *b, const float *bias, float *out, int M, int N,

@@ -75,7 +75,8 @@ SIGNATURES = {
     "mphip_rt_theta_bwd": (_i, [_p] * 5 + [_i, _i, _p]),
     "mphip_f16x3_saturation_count": (_i, [_p, _i]),
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
-    "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mphip_upsample_trilinear2_bwd_workspace_bytes": (_sz, [_i] * 4),
+    "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _sz, _p]),
 }
 
 _lib = None

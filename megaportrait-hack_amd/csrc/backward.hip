@@ -339,6 +339,54 @@ upsample_trilinear2_bwd_kernel(const float *__restrict__ dout, float *__restrict
     dx[t] = acc;
 }
 
+// One axis of the same adjoint (the trilinear resize is separable): gin[outer][i][inner] = sum_o w(o -> i) * gout[outer][o][inner],
+// out_len = 2 * in_len.  Three of these (D, then H, then W: the pass over the full-size gradient is the fully coalesced one)
+// read 1 + 1/2 + 1/4 and write 1/2 + 1/4 + 1/8 of the gradient tensor, with <= 5 taps per element — the one-pass gather above
+// reads ~90 candidates per input voxel through L1/L2 (212 us on the full-resolution gradient at B=4; this: 3 bandwidth passes).
+template <int V>  // V consecutive inner elements per thread (V = 4: 16-byte loads / stores; needs inner % 4 == 0)
+__global__ void __launch_bounds__(256)
+upsample2_adjoint_axis_kernel(const float *__restrict__ gout, float *__restrict__ gin, size_t outer, int in_len, size_t inner,
+                              float scale) {
+    const size_t inner_v = inner / V;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= outer * in_len * inner_v) return;
+    const size_t q = (t % inner_v) * V;
+    const int i = (int)((t / inner_v) % in_len);
+    const size_t o_ = t / (inner_v * in_len);
+    const AdjTaps tp = adj_taps(i, in_len, scale, 2 * in_len);
+    const float *p = gout + (o_ * (size_t)(2 * in_len) + tp.lo) * inner + q;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        if (tp.w[k] == 0.0f) continue;
+        if (V == 4) {
+            const float4 g = *reinterpret_cast<const float4 *>(p + (size_t)k * inner);
+            acc[0] += tp.w[k] * g.x; acc[1] += tp.w[k] * g.y; acc[2] += tp.w[k] * g.z; acc[3] += tp.w[k] * g.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += tp.w[k] * p[(size_t)k * inner + e];
+        }
+    }
+    float *o = gin + (o_ * (size_t)in_len + i) * inner + q;
+    if (V == 4) {
+        *reinterpret_cast<float4 *>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = acc[e];
+    }
+}
+
+static void launch_adjoint_axis(const float *gout, float *gin, size_t outer, int in_len, size_t inner, float scale, hipStream_t s) {
+    const bool v4 = inner % 4 == 0 && ((uintptr_t)gout & 15) == 0 && ((uintptr_t)gin & 15) == 0;
+    const size_t n = outer * in_len * (v4 ? inner / 4 : inner);
+    if (v4)
+        hipLaunchKernelGGL(upsample2_adjoint_axis_kernel<4>, dim3(cdiv(n, 256)), dim3(256), 0, s, gout, gin, outer, in_len, inner, scale);
+    else
+        hipLaunchKernelGGL(upsample2_adjoint_axis_kernel<1>, dim3(cdiv(n, 256)), dim3(256), 0, s, gout, gin, outer, in_len, inner, scale);
+}
+
 // nn.Upsample(scale_factor=(sD,sH,sW)) nearest backward: dx[i] = sum of the sD*sH*sW replicated outputs (model.py:427-433)
 __global__ void __launch_bounds__(256)
 upsample_nearest_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, int sD, int sH, int sW,
@@ -607,15 +655,33 @@ extern "C" int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, i
     return check_launch("avgpool2_bwd");
 }
 
-extern "C" int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream) {
+extern "C" size_t mphip_upsample_trilinear2_bwd_workspace_bytes(int NC, int D, int H, int W) {
+    if (NC <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
+    return (size_t)NC * D * H * W * (4 + 2) * sizeof(float);  // [NC,D,2H,2W] and [NC,D,H,2W]
+}
+
+extern "C" int mphip_upsample_trilinear2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *workspace,
+                                             size_t workspace_bytes, void *stream) {
     MPHIP_REQUIRE(dout && dx, "upsample_trilinear2_bwd: null pointer");
     MPHIP_REQUIRE(NC > 0 && D > 0 && H > 0 && W > 0, "upsample_trilinear2_bwd: bad dims");
     const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
     const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
     const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
     const size_t total = (size_t)NC * D * H * W;
-    hipLaunchKernelGGL(upsample_trilinear2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, dout, dx, D, H,
-                       W, sD, sH, sW, total);
+    hipStream_t s = (hipStream_t)stream;
+    if (!workspace) {  // no scratch: the one-pass gather
+        hipLaunchKernelGGL(upsample_trilinear2_bwd_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, dout, dx, D, H, W, sD, sH, sW, total);
+        return check_launch("upsample_trilinear2_bwd");
+    }
+    const size_t need = mphip_upsample_trilinear2_bwd_workspace_bytes(NC, D, H, W);
+    if (workspace_bytes < need) {
+        set_error("upsample_trilinear2_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    float *t1 = (float *)workspace, *t2 = t1 + total * 4;
+    launch_adjoint_axis(dout, t1, (size_t)NC, D, (size_t)4 * H * W, sD, s);
+    launch_adjoint_axis(t1, t2, (size_t)NC * D, H, (size_t)2 * W, sH, s);
+    launch_adjoint_axis(t2, dx, (size_t)NC * D * H, W, (size_t)1, sW, s);
     return check_launch("upsample_trilinear2_bwd");
 }
 

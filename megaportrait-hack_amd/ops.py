@@ -762,7 +762,10 @@ def upsample_trilinear2_bwd(dout: torch.Tensor) -> torch.Tensor:
     if d % 2 or h % 2 or w % 2:
         raise RuntimeError("upsample_trilinear2_bwd: gradient dims must be even")
     dx = torch.empty((n, c, d // 2, h // 2, w // 2), dtype=torch.float32, device=dout.device)
-    _lib.check(_lib.load().mphip_upsample_trilinear2_bwd(_ptr(dout), _ptr(dx), n * c, d // 2, h // 2, w // 2, _stream()),
+    lib = _lib.load()
+    ws_bytes = lib.mphip_upsample_trilinear2_bwd_workspace_bytes(n * c, d // 2, h // 2, w // 2)
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dout.device)
+    _lib.check(lib.mphip_upsample_trilinear2_bwd(_ptr(dout), _ptr(dx), n * c, d // 2, h // 2, w // 2, _ptr(ws), ws_bytes, _stream()),
                "mphip_upsample_trilinear2_bwd")
     return dx
 
