@@ -40,8 +40,9 @@ class Gbase(M._HotSliceRunner, nn.Module):
     def channels_last_2d(self, enable: bool = True) -> "Gbase":
         """Memory format of the PyTorch-ROCm 2D modules on the driver-side path: `motionEncoder` and `G2d` in
         torch.channels_last (MIOpen's NHWC kernels: 73 -> 62 ms per 8 frames under autocast-fp16, 147 -> 142 ms in fp32 on
-        MI355X; Eapp's trunk measures slower in NHWC and is left alone).  A layout choice only: same parameters, same
-        state-dict keys, results equal up to MIOpen's kernel selection."""
+        MI355X — with MIOpen's find mode, `torch.backends.cudnn.benchmark = True`; in immediate mode NHWC measures SLOWER
+        (101 vs 110 frames/s), so set that flag with it.  Eapp's trunk measures slower in NHWC and is left alone).  A layout
+        choice only: same parameters, same state-dict keys, results equal up to MIOpen's kernel selection."""
         self._cl2d = bool(enable)
         fmt = torch.channels_last if enable else torch.contiguous_format
         for m in (self.motionEncoder, self.G2d):

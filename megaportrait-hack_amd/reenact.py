@@ -140,6 +140,7 @@ def run(job: dict, args, rank: int, world: int) -> List[str]:
             print(f"reenact: checkpoint loaded with {len(missing)} missing / {len(unexpected)} unexpected keys", file=sys.stderr)
     g = g.to(dev).eval()
     if args.channels_last:
+        torch.backends.cudnn.benchmark = True   # MIOpen find mode: the NHWC kernels only pay off with it (gbase.channels_last_2d)
         g.channels_last_2d()
     xs = _load_tensor(job["source_tensor"]) if job["source_tensor"] else _load_image(job["source"])
     n = _load_tensor(job["drivers_tensor"]).shape[0] if job["drivers_tensor"] else len(job["drivers"])
