@@ -284,9 +284,12 @@ int mphip_small_gemm(const float *a, const float *a2, const float *b, const floa
 /* ------------------------------------------------------------------ K10  backward of K0-K3 (training, row f2)
  * warp_coords:            the coordinate pass of K2/K3 alone: coords[B,D,H,W,3] (clipped x,y,z sample positions).
  * warp_volume_bwd:        backward of mphip_warp_volume (dsum=0) / mphip_warp_volume_dsum (dsum=1; dout is [B,C,H,W]):
- *                         dv [B,C,D,H,W] (scatter with hardware fp32 atomics, like the reference's grid_sample
- *                         backward) and dfield [B,3,fD,fH,fW] (ATen rule: clipped coordinates pass no gradient;
+ *                         dv [B,C,D,H,W] and dfield [B,3,fD,fH,fW] (ATen rule: clipped coordinates pass no gradient;
  *                         then the adjoint of the align_corners=True resize, model.py:1036).  Either may be NULL.
+ *                         Per frame: if every sample of the frame falls into a box of <= 5^3 source voxels (the
+ *                         reference's own fields) dv is a deterministic fp32-MFMA reduction over the outputs and the
+ *                         coordinate gradient comes from an LDS image of the box; otherwise dv is a scatter with
+ *                         hardware fp32 atomics (like the reference's grid_sample backward on a GPU).
  * warp_field_compose_bwd: dtheta [B,3,4] (F.affine_grid backward) and dem [B,3,eD,eH,eW] (adjoint of the
  *                         align_corners=False resize, model.py:971-973) from dw [B,3,G,G,G].  Either may be NULL.
  * rt_theta_bwd:           (drot [B,3] in degrees, dtr [B,3]) from dtheta through the rotation composition and,
