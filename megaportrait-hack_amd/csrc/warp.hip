@@ -327,14 +327,15 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
 // (16-byte stores, a wave writes eight 128-byte rows), all C channels.  If the tile's source box fits the LDS image with
 // >= 8 channels per pass (always, for the reference's own fields: they never leave the 4^3 low corner) it is staged and
 // gathered from LDS.  Any other tile — a field that really travels through the volume — is only MARKED here (todo[tile] = 1)
-// and done by warp_gather_direct_kernel below: keeping that path out of this kernel keeps it lean (registers: the
+// and done by warp_gather_columns_kernel / warp_gather_direct_kernel below: keeping that path out of this kernel keeps it lean (registers: the
 // staged path lost 25 % when both lived in one kernel).
 constexpr int K2_TH = 32, K2_TW = 32;
-constexpr int K2_DIRECT_SPLIT = 4;  // channel groups (gridDim.y) of warp_gather_direct_kernel
+constexpr int K2_DIRECT_SPLIT = 4;  // channel groups of the direct gather (warp_gather_direct_body)
+constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a 32 x 32 tile up to which the column walk is used
 __global__ void __launch_bounds__(256)
 warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                    float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */,
-                   int *__restrict__ todo, int B, int C, int D, int H, int W) {
+                   int *__restrict__ todo, int B, int C, int D, int H, int W, unsigned range_slots) {
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
@@ -378,7 +379,9 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
     unsigned mbits = 0;
     const bool staged = cs_max >= 8 || cs_max >= C;  // block-uniform
-    if (threadIdx.x == 0) todo[bid] = staged ? 0 : 1;
+    // 0: done here; 1: a box of moderate size = a smooth field that travels -> warp_gather_columns_body (plane reuse down the
+    // slices); 2: no locality to exploit (a box like the whole volume) -> warp_gather_direct_body (most loads in flight)
+    if (threadIdx.x == 0) todo[bid] = staged ? 0 : (bvol <= K2_COLUMNS_MAX_BOX ? 1 : 2);
 
     if (staged) {
         TapOff lt[4];
@@ -403,18 +406,19 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
             }
         }
     }
-    if (out_range) range_note_block(mbits, out_range, blockIdx.x, (1 + K2_DIRECT_SPLIT) * gridDim.x);  // (+ the direct kernel's slots)
+    if (out_range) range_note_block(mbits, out_range, blockIdx.x, range_slots);  // (+ the direct kernel's slots)
 }
 
 // The tiles warp_gather_kernel marked: one position per lane, lanes running along w, so for a smooth field every tap load of
 // a wave covers one or two contiguous row segments (the per-CU L1 serves the overlap between taps and rows) and the stores
 // are contiguous 128-byte rows; the x-neighbour taps come in pairs (gather8_pairs).  Workgroups of unmarked tiles exit.
-__global__ void __launch_bounds__(256)
-warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
-                          float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W) {
+__device__ __forceinline__ void
+warp_gather_direct_body(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                        float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
+                        unsigned range_slots, unsigned blk_x, unsigned grid_x, unsigned blk_y, unsigned grid_y) {
     unsigned mbits = 0;
-    const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);  // same logical order as warp_gather_kernel
-    if (todo[bid]) {  // block-uniform
+    const unsigned bid = xcd_remap(blk_x, grid_x);  // same logical order as warp_gather_kernel
+    if (todo[bid] == 2) {  // block-uniform
         const int HW = H * W;
         const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
         const int d = (int)(bid % (unsigned)D);
@@ -436,11 +440,11 @@ warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__
         }
         const float *vb = v + (size_t)b * C * vol;
         float *ob = out + (size_t)b * C * vol + (size_t)d * HW + hb * W + w;
-        // channels are split over gridDim.y workgroups: this path is latency-bound (L2-hit gathers), it needs every wave slot
-        const int cpg = (C + (int)gridDim.y - 1) / (int)gridDim.y;
-        const int c_end = min(C, ((int)blockIdx.y + 1) * cpg);
+        // channels are split over grid_y workgroups: this path is latency-bound (L2-hit gathers), it needs every wave slot
+        const int cpg = (C + (int)grid_y - 1) / (int)grid_y;
+        const int c_end = min(C, ((int)blk_y + 1) * cpg);
 #pragma unroll 2
-        for (int c = (int)blockIdx.y * cpg; c < c_end; ++c) {
+        for (int c = (int)blk_y * cpg; c < c_end; ++c) {
             const float *src = vb + (size_t)c * vol;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -452,7 +456,76 @@ warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__
             }
         }
     }
-    if (out_range) range_note_block(mbits, out_range, gridDim.x * (1 + blockIdx.y) + blockIdx.x, (1 + gridDim.y) * gridDim.x);
+    if (out_range) range_note_block(mbits, out_range, grid_x * (1 + blk_y) + blk_x, range_slots);
+}
+
+// The same marked tiles, walked like K3 walks them: a workgroup owns a 16 x 16 tile of (h,w) positions, ALL D output slices and
+// K2C_CPB channels; every thread runs down the slices of its position (taps once per slice, channels innermost).  Consecutive
+// output slices of a smooth field sample neighbouring source planes, so the plane a slice fetched is still in the L1 / L2 when
+// the next slice needs it — the direct gather, one workgroup per (tile, slice), re-fetches it from another CU.
+#ifndef MPHIP_K2C_CPB
+#define MPHIP_K2C_CPB 16
+#endif
+constexpr int K2C_CPB = MPHIP_K2C_CPB;
+__device__ __forceinline__ void
+warp_gather_columns_body(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                         float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
+                         unsigned range_slot0, unsigned range_slots, unsigned blk, unsigned nblk) {
+    const int HW = H * W;
+    const int tiles_w = (W + 15) / 16, tiles_h = (H + 15) / 16, ntile = tiles_w * tiles_h;
+    const int tiles32_w = (W + K2_TW - 1) / K2_TW, ntile32 = tiles32_w * ((H + K2_TH - 1) / K2_TH);
+    unsigned bid = xcd_remap(blk, nblk);  // the tiles of one (frame, channel slice) under one L2 (as K3)
+    const int tile = (int)(bid % ntile); bid /= ntile;
+    const int slices = (C + K2C_CPB - 1) / K2C_CPB;
+    const int slice = (int)(bid % slices), b = (int)(bid / slices);
+    const int h = (tile / tiles_w) * 16 + (int)(threadIdx.x >> 4);
+    const int w = (tile % tiles_w) * 16 + (int)(threadIdx.x & 15);
+    const bool active = h < H && w < W;
+    const int p = h * W + w;
+    const size_t vol = (size_t)D * HW;
+    const int c0 = slice * K2C_CPB, cs = min(K2C_CPB, C - c0);
+    // the 16 x 16 tile lies inside one 32 x 32 tile of warp_gather_kernel: its marks, one per slice (block-uniform)
+    const int t32 = ((tile / tiles_w) * 16 / K2_TH) * tiles32_w + (tile % tiles_w) * 16 / K2_TW;
+    const int *marks = todo + ((size_t)b * ntile32 + t32) * D;
+    const float *vb = v + ((size_t)b * C + c0) * vol;
+    float *ob = out + ((size_t)b * C + c0) * vol + p;
+    unsigned mbits = 0;
+    // nothing marked for this column (every launch on the reference's own fields): leave after ONE round of loads
+    int mine = 0;
+    for (int d = threadIdx.x; d < D; d += 256) mine |= marks[d] == 1;
+    if (!__syncthreads_or(mine)) {
+        if (out_range) range_note_block(0u, out_range, range_slot0 + blk, range_slots);
+        return;
+    }
+    for (int d = 0; d < D; ++d) {
+        if (marks[d] != 1 || !active) continue;
+        const float *q = coords + (((size_t)b * D + d) * HW + p) * 3;
+        const Taps t = make_taps(Coord3{q[0], q[1], q[2]}, D, H, W);
+#pragma unroll
+        for (int c = 0; c < K2C_CPB; ++c)
+            if (c < cs) {
+                const float r = gather8_pairs(vb + (size_t)c * vol, t);
+                ob[(size_t)c * vol + (size_t)d * HW] = r;
+                mbits = max(mbits, range_bits(r));
+            }
+    }
+    if (out_range) range_note_block(mbits, out_range, range_slot0 + blk, range_slots);
+}
+
+// Two launches, not one kernel with two roles: merged, the column walk inherits the direct gather's 223 registers (two waves
+// per SIMD) and loses what it gained (smooth field 223 -> 325 us); the second, mostly idle launch costs the reference-field path ~4 us.
+__global__ void __launch_bounds__(256)
+warp_gather_columns_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                           float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
+                           unsigned nblocks, unsigned range_slots) {
+    warp_gather_columns_body(v, coords, out, out_range, todo, B, C, D, H, W, nblocks * (1 + K2_DIRECT_SPLIT), range_slots, blockIdx.x,
+                             gridDim.x);
+}
+__global__ void __launch_bounds__(256)
+warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
+                          float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
+                          unsigned range_slots) {
+    warp_gather_direct_body(v, coords, out, out_range, todo, B, C, D, H, W, range_slots, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
 }
 
 // K3: a workgroup owns a compact 16 x 16 tile of (h,w) positions of one frame and CPB channels; every thread walks the D
@@ -627,7 +700,8 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
     const size_t nblocks = k2_tiles(B, D, H, W);
-    if (out_range && (W % 4 != 0 || (1 + K2_DIRECT_SPLIT) * nblocks > RANGE_MAX_PARTS)) {
+    const size_t ncol_all = (size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * cdiv(C, K2C_CPB);
+    if (out_range && (W % 4 != 0 || (1 + K2_DIRECT_SPLIT) * nblocks + ncol_all > RANGE_MAX_PARTS)) {
         // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
         // max|out| <= max|v|, so v's own range serves
         rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);
@@ -635,9 +709,16 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
         out_range = nullptr;
     }
     if (W % 4 == 0) {
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W);
-        hipLaunchKernelGGL(warp_gather_direct_kernel, dim3((unsigned)nblocks, K2_DIRECT_SPLIT), dim3(256), 0, s, v, coords, out, out_range, todo, B, C,
-                           D, H, W);
+        const unsigned ncol = (unsigned)((size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * cdiv(C, K2C_CPB));
+        const unsigned slots = (unsigned)nblocks * (1 + K2_DIRECT_SPLIT) + ncol;
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W,
+                           slots);
+        // the tiles it marked: smooth travelling fields -> column walk, incoherent ones -> direct gather (workgroups of the other
+        // kind, and all of them on the reference's own fields, exit after one load)
+        hipLaunchKernelGGL(warp_gather_columns_kernel, dim3(ncol), dim3(256), 0, s, v, (const float *)coords, out, out_range,
+                           (const int *)todo, B, C, D, H, W, (unsigned)nblocks, slots);
+        hipLaunchKernelGGL(warp_gather_direct_kernel, dim3((unsigned)nblocks, K2_DIRECT_SPLIT), dim3(256), 0, s, v, (const float *)coords,
+                           out, out_range, (const int *)todo, B, C, D, H, W, slots);
     } else {
         const int cpb = C >= 48 ? 12 : C;
         hipLaunchKernelGGL(warp_gather_scalar_kernel, dim3(cdiv((size_t)B * D * H * W, 256), cdiv(C, cpb)), dim3(256), 0, s,

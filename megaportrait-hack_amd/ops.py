@@ -48,7 +48,12 @@ _RANGE_FLOATS = 4100  # MPHIP_RANGE_FLOATS (include/mphip.h): 4 + one partial ma
 _RANGES_ENABLED = _os.environ.get("MPHIP_FUSED_RANGES", "1") != "0"  # dev switch: 0 = every f16x3 conv measures its own input
 
 
+_POISON_RANGES = _os.environ.get("MPHIP_POISON_RANGES", "0") == "1"  # tests: a slot nobody wrote shows up as a 1e30 maximum
+
+
 def new_range(device) -> torch.Tensor:
+    if _POISON_RANGES:
+        return torch.full((_RANGE_FLOATS,), 1.0e30, dtype=torch.float32, device=device)
     return torch.empty(_RANGE_FLOATS, dtype=torch.float32, device=device)  # filled by the kernel call it is handed to
 
 

@@ -621,6 +621,7 @@ def test_resblock_upsample_branch(ops, M, dev):
     align_corners=False)) — no module of Gbase sets it; covered for constructor parity.  Forward vs the block without the flag
     + ATen's interpolate on the CPU, and the gradient through it vs CPU autograd."""
     x = R.seeded_tensor((1, 96, 4, 8, 8), 851, scale=1.7)
+    torch.manual_seed(851)   # (the blocks' default init is random: unseeded, the 1e-6 bar below met |y| > 16 once in ~20 runs)
     for cls, sf in ((M.ResBlock3D, (2, 2, 2)), (M.ResBlock3D_Adaptive, (1, 2, 3))):
         plain, up = cls(96, 96), cls(96, 96, upsample=True, scale_factors=sf)
         up.load_state_dict(plain.state_dict())
@@ -629,7 +630,7 @@ def test_resblock_upsample_branch(ops, M, dev):
             base = plain(x.to(dev))
             got = up(x.to(dev))
         want = F.interpolate(base.cpu(), scale_factor=sf, mode="trilinear", align_corners=False)
-        assert got.shape == want.shape and maxabs(got, want) < 1e-6
+        assert got.shape == want.shape and maxabs(got, want) < 1e-6 + 2.4e-7 * want.abs().max().item()   # <= 2 ulp of the largest value
     y = R.seeded_tensor((2, 8, 3, 4, 6), 852).requires_grad_(True)
     dy = R.seeded_tensor((2, 8, 6, 8, 18), 853)
     F.interpolate(y, scale_factor=(2, 2, 3), mode="trilinear", align_corners=False).backward(dy)
