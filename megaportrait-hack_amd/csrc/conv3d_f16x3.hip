@@ -126,13 +126,23 @@ f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const
     const int cot = bid / nchunks;
     const int cog0 = cot * F16X3_COT + sub * PK_CO, ci0 = chunk * F16X3_KC;
     // transposed: w is the original conv's [Ci][Co][27] weight, this pack its bwd-data conv (taps reversed)
-    const int rows = transposed ? F16X3_KC : PK_CO, run = transposed ? PK_CO * 27 : F16X3_KC * 27, pitch = run + 1;
-    for (int i = threadIdx.x; i < rows * (run / 4); i += 256) {
+    const int run = transposed ? PK_CO * 27 : F16X3_KC * 27, pitch = run + 1;  // forward: 32 rows of 16 ci x 27; transposed: 16 rows of 32 co x 27
+    constexpr int NQ = PK_CO * F16X3_KC * 27 / 4, NIT = (NQ + 255) / 256;  // 16-byte pieces of the tile; all loads issued up front
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + threadIdx.x;
         const int r = i / (run / 4), q = i % (run / 4);
         const size_t src = transposed ? ((size_t)(ci0 + r) * Co + cog0) * 27 : ((size_t)(cog0 + r) * Ci + ci0) * 27;
-        const float4 v = *reinterpret_cast<const float4 *>(w + src + 4 * q);
-        float *d = tile + r * pitch + 4 * q;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        if (i < NQ) v[it] = *reinterpret_cast<const float4 *>(w + src + 4 * q);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int i = it * 256 + threadIdx.x;
+        if (i < NQ) {
+            float *d = tile + (i / (run / 4)) * pitch + 4 * (i % (run / 4));
+            d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+        }
     }
     __syncthreads();
     // one item = (slab g, tap tg, kg, co): 8 consecutive ci -> one 16-byte fragment of hi and one of lo
