@@ -934,10 +934,20 @@ warp_frame_box_kernel(const float *__restrict__ coords, int *__restrict__ fbox, 
     const size_t vol = (size_t)D * H * W;
     const float *cb = coords + (size_t)b * vol * 3;
     int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
-    for (size_t t = threadIdx.x; t < vol; t += 1024) {
-        const int x0 = (int)floorf(cb[t * 3]), y0 = (int)floorf(cb[t * 3 + 1]), z0 = (int)floorf(cb[t * 3 + 2]);
-        lx = min(lx, x0); ly = min(ly, y0); lz = min(lz, z0);
-        hx = max(hx, x0); hy = max(hy, y0); hz = max(hz, z0);
+    // (eight voxels' loads in flight per thread: with one at a time this one-workgroup-per-frame pass took 15 us of pure latency)
+    for (size_t t0 = threadIdx.x; t0 < vol; t0 += 8 * 1024) {
+        float c[8][3];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const size_t t = min(t0 + (size_t)u * 1024, vol - 1);  // (a clamped duplicate changes no minimum / maximum)
+            c[u][0] = cb[t * 3]; c[u][1] = cb[t * 3 + 1]; c[u][2] = cb[t * 3 + 2];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int x0 = (int)floorf(c[u][0]), y0 = (int)floorf(c[u][1]), z0 = (int)floorf(c[u][2]);
+            lx = min(lx, x0); ly = min(ly, y0); lz = min(lz, z0);
+            hx = max(hx, x0); hy = max(hy, y0); hz = max(hz, z0);
+        }
     }
     lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
     hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
@@ -1185,11 +1195,20 @@ warp_bwd_dense_dcoords_kernel(const float *__restrict__ v, const float *__restri
     for (int c0 = 0; c0 < C; c0 += DENSE_DC_CH) {
         const int cs = min(DENSE_DC_CH, C - c0);
         __syncthreads();
-        for (int i = threadIdx.x; i < cs * cells; i += 256) {
-            const int c = i / cells, cell = i - c * cells;
-            const int x = cell % E, y = (cell / E) % E, z = cell / (E * E);
-            vbox[i] = (x < ex && y < ey && z < ez)
-                          ? v[((size_t)b * C + c0 + c) * vol + (size_t)(oz + z) * HW + (oy + y) * W + ox + x] : 0.0f;
+        for (int i0 = threadIdx.x; i0 < cs * cells; i0 += 8 * 256) {  // eight loads in flight per thread (47 dependent ones otherwise)
+            float val[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u * 256, cs * cells - 1);
+                const int c = i / cells, cell = i - c * cells;
+                const int x = cell % E, y = (cell / E) % E, z = cell / (E * E);
+                const bool in = x < ex && y < ey && z < ez;
+                const float got = v[((size_t)b * C + c0 + c) * vol + (size_t)(oz + min(z, ez - 1)) * HW + (oy + min(y, ey - 1)) * W + ox + min(x, ex - 1)];
+                val[u] = in ? got : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (i0 + u * 256 < cs * cells) vbox[i0 + u * 256] = val[u];
         }
         __syncthreads();
         const float *gp = dout + ((size_t)b * C + c0) * (DSUM ? (size_t)HW : vol);
