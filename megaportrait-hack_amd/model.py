@@ -422,6 +422,10 @@ class _HotSliceRunner:
     # The C2D generator depends only on (Rd, td, zd, es): its ~25 small, latency-bound launches run on
     # a second HIP stream underneath G3d's MFMA-bound kernels instead of in front of the last warp.
     overlap_generators = True
+    # Frames per pass of the slice: the conv kernels address their input through one 2 GiB buffer resource (a [B,96,16,64,64]
+    # volume is 25 MB per frame: 85 frames); larger batches run as consecutive passes of this many frames (frames are
+    # independent: same results).  Under autograd the batch is not split (a training batch of that size does not fit anyway).
+    max_frames_per_pass = 64
 
     def _side_stream(self, main):
         """One helper stream per caller stream (callers may keep several batches in flight on their own streams)."""
@@ -441,8 +445,12 @@ class _HotSliceRunner:
                 # enters the gradient all-reduce with the others instead of leaving them blocked in the collective
                 out = out + sum(p.sum() for p in self.parameters() if p.requires_grad) * 0.0
             return out
-        main = torch.cuda.current_stream(vs.device)
         train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
+        if not train and vs.shape[0] > self.max_frames_per_pass:
+            step = int(self.max_frames_per_pass)
+            return torch.cat([self._run(*(t[i:i + step] for t in (vs, es, Rs, ts, zs, Rd, td, zd)), check_shape)
+                              for i in range(0, vs.shape[0], step)], dim=0)
+        main = torch.cuda.current_stream(vs.device)
         # training: one stream (autograd replays each op's backward on its forward stream; the overlap is an inference trick)
         side = self._side_stream(main) if (self.overlap_generators and not train) else None
         if side is not None:

@@ -535,6 +535,23 @@ def test_hot_slice_256px_config(dev, hot, sd):
     assert maxabs(got, want) < 1e-3
 
 
+def test_hot_slice_batches_beyond_one_pass(dev, hot, monkeypatch):
+    """Maximum sizes: the conv kernels address their input through one 2 GiB buffer resource (85 frames of the BASELINE volume);
+    a larger inference batch runs as consecutive passes (`max_frames_per_pass`, default 64) with the same results — here with the
+    limit lowered to 2 on a 5-frame batch; under autograd the batch is never split."""
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(5, 47, D=16, H=16, W=16).items()}
+    with torch.no_grad():
+        whole = hot.forward_any_size(**inp)
+        monkeypatch.setattr(type(hot), "max_frames_per_pass", 2)
+        split = hot.forward_any_size(**inp)
+    assert split.shape == whole.shape
+    assert maxabs(split, whole.cpu()) < 2e-4    # (not bitwise: the split-K plan of the small-volume convs depends on the batch size)
+    grad_in = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+    out = hot.forward_any_size(**grad_in)       # autograd: one pass, gradients for all 5 frames
+    out.sum().backward()
+    assert grad_in["vs"].grad.shape == inp["vs"].shape and float(grad_in["vs"].grad[4].abs().max()) > 0
+
+
 def test_hot_slice_full_golden(dev, hot):
     """BASELINE config: 512^2 frame = 96x16x64x64 volume, reference output [1,96,64,64]."""
     g = gold("hot_slice")
