@@ -360,6 +360,7 @@ class Eapp3DTail(nn.Module):
 
     _ORDER = ("resblock3D_96", "resblock3D_96_2", "resblock3D_96_1", "resblock3D_96_1_2", "resblock3D_96_2",
               "resblock3D_96_2_2")
+    max_frames_per_pass = 64
 
     def __init__(self):
         super().__init__()
@@ -373,6 +374,10 @@ class Eapp3DTail(nn.Module):
         """out: Eapp's conv_1 output [B,1536,H,W] (model.py:268) or the reshaped volume [B,96,16,H,W]."""
         out = _f32(out)
         vs = out.view(out.size(0), 96, 16, *out.shape[2:]) if out.dim() == 4 else out  # model.py:271
+        if vs.shape[0] > self.max_frames_per_pass and not ag.needs_grad(self, vs):
+            # (the conv kernels' 2 GiB buffer resource: see _HotSliceRunner.max_frames_per_pass; frames are independent)
+            step = int(self.max_frames_per_pass)
+            return torch.cat([self.forward(vs[i:i + step]) for i in range(0, vs.shape[0], step)], dim=0)
         for name in self._ORDER:
             vs = getattr(self, name)(vs)
         return vs

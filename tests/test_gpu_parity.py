@@ -535,7 +535,7 @@ def test_hot_slice_256px_config(dev, hot, sd):
     assert maxabs(got, want) < 1e-3
 
 
-def test_hot_slice_batches_beyond_one_pass(dev, hot, monkeypatch):
+def test_hot_slice_batches_beyond_one_pass(dev, hot, M, monkeypatch):
     """Maximum sizes: the conv kernels address their input through one 2 GiB buffer resource (85 frames of the BASELINE volume);
     a larger inference batch runs as consecutive passes (`max_frames_per_pass`, default 64) with the same results — here with the
     limit lowered to 2 on a 5-frame batch; under autograd the batch is never split."""
@@ -546,6 +546,13 @@ def test_hot_slice_batches_beyond_one_pass(dev, hot, monkeypatch):
         split = hot.forward_any_size(**inp)
     assert split.shape == whole.shape
     assert maxabs(split, whole.cpu()) < 2e-4    # (not bitwise: the split-K plan of the small-volume convs depends on the batch size)
+    tail = M.Eapp3DTail().to(dev).eval()
+    x = R.seeded_tensor((3, 96, 4, 8, 8), 48).to(dev)
+    with torch.no_grad():
+        a = tail(x)
+        monkeypatch.setattr(M.Eapp3DTail, "max_frames_per_pass", 1)
+        b = tail(x)
+    assert maxabs(a, b.cpu()) < 2e-4
     grad_in = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
     out = hot.forward_any_size(**grad_in)       # autograd: one pass, gradients for all 5 frames
     out.sum().backward()
