@@ -335,7 +335,7 @@ constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a 32 x 32 til
 __global__ void __launch_bounds__(256)
 warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                    float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */,
-                   int *__restrict__ todo, int B, int C, int D, int H, int W, unsigned range_slots) {
+                   int *__restrict__ todo, int B, int C, int D, int H, int W) {
     __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
     __shared__ int red[24];
     const int HW = H * W;
@@ -406,7 +406,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
             }
         }
     }
-    if (out_range) range_note_block(mbits, out_range, blockIdx.x, range_slots);  // (+ the direct kernel's slots)
+    if (out_range) range_note_block(mbits, out_range, blockIdx.x, gridDim.x);  // (the follow-up kernels fold into these slots)
 }
 
 // The tiles warp_gather_kernel marked: one position per lane, lanes running along w, so for a smooth field every tap load of
@@ -415,7 +415,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
 __device__ __forceinline__ void
 warp_gather_direct_body(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                         float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
-                        unsigned range_slots, unsigned blk_x, unsigned grid_x, unsigned blk_y, unsigned grid_y) {
+                        unsigned blk_x, unsigned grid_x, unsigned blk_y, unsigned grid_y) {
     unsigned mbits = 0;
     const unsigned bid = xcd_remap(blk_x, grid_x);  // same logical order as warp_gather_kernel
     if (todo[bid] == 2) {  // block-uniform
@@ -456,7 +456,12 @@ warp_gather_direct_body(const float *__restrict__ v, const float *__restrict__ c
             }
         }
     }
-    if (out_range) range_note_block(mbits, out_range, grid_x * (1 + blk_y) + blk_x, range_slots);
+    // the rare path folds its maximum into the slot warp_gather_kernel wrote for this tile (one atomic per wave that did work;
+    // idle workgroups leave without touching the descriptor)
+    if (out_range && todo[bid] == 2) {
+        mbits = wave_umax(mbits);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out_range) + 4 + bid, mbits);
+    }
 }
 
 // The same marked tiles, walked like K3 walks them: a workgroup owns a 16 x 16 tile of (h,w) positions, ALL D output slices and
@@ -470,7 +475,7 @@ constexpr int K2C_CPB = MPHIP_K2C_CPB;
 __device__ __forceinline__ void
 warp_gather_columns_body(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                          float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
-                         unsigned range_slot0, unsigned range_slots, unsigned blk, unsigned nblk) {
+                         unsigned blk, unsigned nblk) {
     const int HW = H * W;
     const int tiles_w = (W + 15) / 16, tiles_h = (H + 15) / 16, ntile = tiles_w * tiles_h;
     const int tiles32_w = (W + K2_TW - 1) / K2_TW, ntile32 = tiles32_w * ((H + K2_TH - 1) / K2_TH);
@@ -493,10 +498,7 @@ warp_gather_columns_body(const float *__restrict__ v, const float *__restrict__ 
     // nothing marked for this column (every launch on the reference's own fields): leave after ONE round of loads
     int mine = 0;
     for (int d = threadIdx.x; d < D; d += 256) mine |= marks[d] == 1;
-    if (!__syncthreads_or(mine)) {
-        if (out_range) range_note_block(0u, out_range, range_slot0 + blk, range_slots);
-        return;
-    }
+    if (!__syncthreads_or(mine)) return;
     for (int d = 0; d < D; ++d) {
         if (marks[d] != 1 || !active) continue;
         const float *q = coords + (((size_t)b * D + d) * HW + p) * 3;
@@ -509,23 +511,23 @@ warp_gather_columns_body(const float *__restrict__ v, const float *__restrict__ 
                 mbits = max(mbits, range_bits(r));
             }
     }
-    if (out_range) range_note_block(mbits, out_range, range_slot0 + blk, range_slots);
+    if (out_range) {  // into the slot warp_gather_kernel wrote for (frame, 32 x 32 tile, slice 0)
+        mbits = wave_umax(mbits);
+        if ((threadIdx.x & 63) == 0) atomicMax(reinterpret_cast<unsigned *>(out_range) + 4 + ((size_t)b * ntile32 + t32) * D, mbits);
+    }
 }
 
 // Two launches, not one kernel with two roles: merged, the column walk inherits the direct gather's 223 registers (two waves
 // per SIMD) and loses what it gained (smooth field 223 -> 325 us); the second, mostly idle launch costs the reference-field path ~4 us.
 __global__ void __launch_bounds__(256)
 warp_gather_columns_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
-                           float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
-                           unsigned nblocks, unsigned range_slots) {
-    warp_gather_columns_body(v, coords, out, out_range, todo, B, C, D, H, W, nblocks * (1 + K2_DIRECT_SPLIT), range_slots, blockIdx.x,
-                             gridDim.x);
+                           float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W) {
+    warp_gather_columns_body(v, coords, out, out_range, todo, B, C, D, H, W, blockIdx.x, gridDim.x);
 }
 __global__ void __launch_bounds__(256)
 warp_gather_direct_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
-                          float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W,
-                          unsigned range_slots) {
-    warp_gather_direct_body(v, coords, out, out_range, todo, B, C, D, H, W, range_slots, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
+                          float *__restrict__ out_range, const int *__restrict__ todo, int B, int C, int D, int H, int W) {
+    warp_gather_direct_body(v, coords, out, out_range, todo, B, C, D, H, W, blockIdx.x, gridDim.x, blockIdx.y, gridDim.y);
 }
 
 // K3: a workgroup owns a compact 16 x 16 tile of (h,w) positions of one frame and CPB channels; every thread walks the D
@@ -700,8 +702,7 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
     const size_t nblocks = k2_tiles(B, D, H, W);
-    const size_t ncol_all = (size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * cdiv(C, K2C_CPB);
-    if (out_range && (W % 4 != 0 || (1 + K2_DIRECT_SPLIT) * nblocks + ncol_all > RANGE_MAX_PARTS)) {
+    if (out_range && (W % 4 != 0 || nblocks > RANGE_MAX_PARTS)) {
         // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
         // max|out| <= max|v|, so v's own range serves
         rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);
@@ -710,15 +711,13 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     }
     if (W % 4 == 0) {
         const unsigned ncol = (unsigned)((size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * cdiv(C, K2C_CPB));
-        const unsigned slots = (unsigned)nblocks * (1 + K2_DIRECT_SPLIT) + ncol;
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W,
-                           slots);
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W);
         // the tiles it marked: smooth travelling fields -> column walk, incoherent ones -> direct gather (workgroups of the other
         // kind, and all of them on the reference's own fields, exit after one load)
         hipLaunchKernelGGL(warp_gather_columns_kernel, dim3(ncol), dim3(256), 0, s, v, (const float *)coords, out, out_range,
-                           (const int *)todo, B, C, D, H, W, (unsigned)nblocks, slots);
+                           (const int *)todo, B, C, D, H, W);
         hipLaunchKernelGGL(warp_gather_direct_kernel, dim3((unsigned)nblocks, K2_DIRECT_SPLIT), dim3(256), 0, s, v, (const float *)coords,
-                           out, out_range, (const int *)todo, B, C, D, H, W, slots);
+                           out, out_range, (const int *)todo, B, C, D, H, W);
     } else {
         const int cpb = C >= 48 ? 12 : C;
         hipLaunchKernelGGL(warp_gather_scalar_kernel, dim3(cdiv((size_t)B * D * H * W, 256), cdiv(C, cpb)), dim3(256), 0, s,

@@ -702,8 +702,8 @@ def test_f16x3_accepts_any_magnitude(ops, dev):
 
 def test_range_descriptors_are_correct_bounds(ops, dev):
     """What the producers leave in a range descriptor: max over [2] and the partial maxima must equal max|tensor| (K2's fused
-    note, GroupNorm apply, mphip_absmax_range) or bound it (K2 with more workgroups than partial slots falls back to the
-    SOURCE volume's maximum — a warp is a convex combination; the affine-table bound of a folded GroupNorm)."""
+    note — staged tiles, the column walk and the direct gather alike —, GroupNorm apply, mphip_absmax_range) or bound it (K2 with
+    more tiles than partial slots falls back to the SOURCE volume's maximum — a warp is a convex combination; the affine-table bound of a folded GroupNorm)."""
     def desc_max(r):
         r = r.cpu()
         n = int(r[3:4].view(torch.int32).item())
@@ -716,11 +716,20 @@ def test_range_descriptors_are_correct_bounds(ops, dev):
     v = R.seeded_tensor((2, 8, 16, 64, 64), 863, scale=2.0).to(dev)
     out = ops.warp_volume(v, field)
     assert desc_max(ops.tensor_range(out)) == out.abs().max().item()          # fused into the gather kernels
-    vb = R.seeded_tensor((14, 8, 16, 64, 64), 864, scale=2.0).to(dev)           # 14*16*4 tiles x 5 > 4096 partial slots
+    vb = R.seeded_tensor((14, 8, 16, 64, 64), 864, scale=2.0).to(dev)           # 14*16*4 = 896 tiles: one partial slot each
     fb = (R.seeded_tensor((14, 3, 64, 64, 64), 865, scale=1.3) + 0.4).to(dev)
     ob = ops.warp_volume(vb, fb)
-    m = desc_max(ops.tensor_range(ob))
-    assert ob.abs().max().item() <= m == vb.abs().max().item()                 # the source's maximum bounds the warp
+    assert desc_max(ops.tensor_range(ob)) == ob.abs().max().item()
+    travelling = fb.clone()                                                     # the follow-up kernels fold into the same slots
+    travelling[:7, 0] += torch.linspace(0, 50, 64, device=dev).view(1, 1, 1, 64)             # smooth: the column walk
+    travelling[7:] = (R.seeded_tensor((7, 3, 64, 64, 64), 868).to(dev) + 1.0) * 30.0         # incoherent: the direct gather
+    ot = ops.warp_volume(vb, travelling)
+    assert desc_max(ops.tensor_range(ot)) == ot.abs().max().item()
+    vc = R.seeded_tensor((65, 2, 16, 64, 64), 869, scale=2.0).to(dev)           # 65*16*4 tiles > 4096 partial slots
+    fc = (R.seeded_tensor((1, 3, 64, 64, 64), 870, scale=1.3) + 0.4).to(dev).expand(65, -1, -1, -1, -1).contiguous()
+    oc = ops.warp_volume(vc, fc)
+    m = desc_max(ops.tensor_range(oc))
+    assert oc.abs().max().item() <= m == vc.abs().max().item()                 # the source's maximum bounds the warp
     st = ops.groupnorm_stats(x, 32)
     g, b = R.seeded_tensor((96,), 866, scale=0.5, shift=1.0).to(dev), R.seeded_tensor((96,), 867, scale=0.5).to(dev)
     for kw in (dict(relu=True), dict(relu=True, pool2=True), dict(residual=x, relu=False)):
