@@ -518,6 +518,84 @@ conv_bwd_weight_wave_kernel(const float *__restrict__ x, const float *__restrict
     }
 }
 
+// The same small volumes as a GEMM on the exact-fp32 matrix cores: dW[co][ci][tap] = sum_v dY[co][v] * X[ci][v + tap] with
+// M = 32 output channels, N = 32 input channels, K = the voxels of the batch, one tap per workgroup (v_mfma_f32_32x32x2_f32:
+// lane l feeds row / column l & 31 and k index l >> 5).  A lane's K range is walked four voxels at a time: ONE 16-byte load of
+// dY (its channel's row) and four 4-byte loads of the shifted X row serve four k-steps; voxels whose shifted neighbour is
+// outside the volume contribute the zero padding.  The four waves of a workgroup split K and are folded through LDS in a fixed
+// order: deterministic.  (The wave-per-pair kernel above spends 162 shuffles per 27 outputs: 48 us per FlowField layer.)
+template <int KS, int NW>  // NW waves per workgroup split K (k = 1 has one tap, i.e. few workgroups: 16 waves each)
+__global__ void __launch_bounds__(NW * 64)
+conv_bwd_weight_small_mfma_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dw, int N, int Ci,
+                                  int Co, int D, int H, int W) {
+    constexpr int TAPS = KS * KS * KS;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int ci_tiles = (Ci + 31) / 32;
+    const int co0 = (blockIdx.x / ci_tiles) * 32, ci0 = (blockIdx.x % ci_tiles) * 32;
+    const int tap = blockIdx.y;
+    const int kd = KS == 3 ? tap / 9 - 1 : 0, kh = KS == 3 ? (tap / 3) % 3 - 1 : 0, kw = KS == 3 ? tap % 3 - 1 : 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int HW = H * W, DHW = D * HW;
+    const int co = min(co0 + col, Co - 1), ci = min(ci0 + col, Ci - 1);  // clamped rows: their products are never stored
+    const bool ci_ok = ci0 + col < Ci;
+    const int toff = kd * HW + kh * W + kw;
+    // groups of 8 voxels inside one sample (DHW % 4 == 0 is required by the dispatcher): half h takes voxels 4h .. 4h+3 of a group
+    const int groups_per_n = (DHW + 7) / 8, ngroups = N * groups_per_n;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // branch-free loads (clamped addresses, validity applied as selects when the values are used), the next group's issued
+    // before this group's MFMAs
+    float4 a_cur, a_nxt;
+    float b_cur[4], b_nxt[4];
+    unsigned ok_cur = 0, ok_nxt = 0;  // bit e: voxel e exists and its shifted neighbour is inside the volume; bit 4: the group exists
+    auto load = [&](int g, float4 &a4, float *b, unsigned &ok) {
+        const int gc = min(g, ngroups - 1);
+        const int n = gc / groups_per_n, r0 = min((gc % groups_per_n) * 8 + 4 * half, DHW - 4);
+        const bool have = g < ngroups && (gc % groups_per_n) * 8 + 4 * half < DHW;
+        a4 = *reinterpret_cast<const float4 *>(dy + ((size_t)n * Co + co) * DHW + r0);
+        const float *xc = x + ((size_t)n * Ci + ci) * DHW;
+        ok = have ? 16u : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = r0 + e;
+            const int d = r / HW, h = (r / W) % H, w = r % W;
+            const bool in = (unsigned)(d + kd) < (unsigned)D && (unsigned)(h + kh) < (unsigned)H && (unsigned)(w + kw) < (unsigned)W;
+            b[e] = xc[in ? r + toff : r];
+            ok |= (have && in) ? (1u << e) : 0u;
+        }
+    };
+    load(wave, a_cur, b_cur, ok_cur);
+    for (int g = wave; g < ngroups; g += NW) {
+        load(g + NW, a_nxt, b_nxt, ok_nxt);
+        const float a[4] = {a_cur.x, a_cur.y, a_cur.z, a_cur.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32((ok_cur & 16u) ? a[e] : 0.0f, ((ok_cur >> e) & 1u) ? b_cur[e] : 0.0f, acc, 0, 0, 0);
+        a_cur = a_nxt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) b_cur[e] = b_nxt[e];
+        ok_cur = ok_nxt;
+    }
+    // fold the waves (plain LDS stores / loads, fixed order), then wave 0 writes the 32 x 32 block of this tap
+    __shared__ float xch[NW - 1][16][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            for (int q = 0; q < NW - 1; ++q) v += xch[q][r][lane];
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * half;  // D layout: row = output channel, column = lane & 31 = input channel
+            if (co0 + row < Co && ci_ok) dw[((size_t)(co0 + row) * Ci + ci) * TAPS + tap] = v;
+        }
+    }
+}
+
 }  // namespace mphip
 
 using namespace mphip;
@@ -574,7 +652,13 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *x_range, con
             hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<3>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
         else if (per_thread)
             hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<1>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
-        else if (k == 3)
+        else if ((D * H * W) % 4 == 0 && ((uintptr_t)dy & 15) == 0 && !getenv("MPHIP_BWD_WEIGHT_WAVE")) {  // (env: the older kernel, for A/B)
+            const dim3 grid((unsigned)(((Co + 31) / 32) * ((Ci + 31) / 32)), k == 3 ? 27 : 1);
+            if (k == 3)
+                hipLaunchKernelGGL((conv_bwd_weight_small_mfma_kernel<3, 4>), grid, dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
+            else
+                hipLaunchKernelGGL((conv_bwd_weight_small_mfma_kernel<1, 16>), grid, dim3(1024), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
+        } else if (k == 3)
             hipLaunchKernelGGL(conv_bwd_weight_wave_kernel<3>, dim3(cdiv((size_t)Co * Ci, 4)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D,
                                H, W);
         else
