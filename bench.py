@@ -62,6 +62,8 @@ def parse():
     ap.add_argument("--stub-worker", action="store_true",
                     help="launcher self-test (CPU, gloo): every rank joins the process group, rank 0 prints "
                          '{"stub_worker": true, "ranks": N}; no GPU work')
+    ap.add_argument("--reenact-leg", action="store_true",
+                    help="also time BASELINE config 5's per-GPU shard (1 source x 64 drivers through Gbase.reenact) as a side measurement")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements on the line (fp32_exact, roofline_hbm, end_to_end)")
     return ap.parse_args()
@@ -240,6 +242,35 @@ def end_to_end(dev, B, steps=8, warmup=3, fp16=False, channels_last=False):
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 2), "batch": B, "steps": steps,
             "workload": "gbase.Gbase.forward(xs, xd) -> (image [B,3,512,512], pyramids), xs/xd ~ U[0,1), random init; "
                         "2D encoders/decoder on PyTorch-ROCm, 3D tail + hot slice + G2d head on libmphip", "precision_2d": prec}
+
+
+def reenact_leg(dev, drivers=64, chunk=16, repeats=3):
+    """BASELINE config 5 on one GPU: ONE source image x `drivers` driver frames through gbase.Gbase.reenact — the source-side
+    half (Eapp, Emtn(xs), S2C field, warp #1, G3d) runs once, per driver only Emtn(xd), the C2D field, the fused warp + depth sum
+    and G2d; autocast-fp16 2D modules in channels_last with MIOpen's find mode (the serving configuration).  Side measurement."""
+    from megaportrait_hack_amd import gbase
+
+    torch.manual_seed(20240501)
+    find_mode = torch.backends.cudnn.benchmark
+    torch.backends.cudnn.benchmark = True
+    g = gbase.Gbase().to(dev).eval().channels_last_2d()
+    gen = torch.Generator(device="cpu").manual_seed(20240502)
+    xs = torch.rand(1, 3, 512, 512, generator=gen).to(dev)
+    xd = torch.rand(drivers, 3, 512, 512, generator=gen).to(dev)
+    out = g.reenact(xs, xd, chunk=chunk, fp16=True)   # warm-up (MIOpen find)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        out = g.reenact(xs, xd, chunk=chunk, fp16=True)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / repeats
+    assert out.shape == (drivers, 3, 512, 512) and torch.isfinite(out).all()
+    torch.backends.cudnn.benchmark = find_mode
+    del g
+    torch.cuda.empty_cache()
+    return {"value": round(drivers / dt, 1), "unit": "driver frames/s", "ms_per_call": round(dt * 1e3, 1), "drivers": drivers, "chunk": chunk,
+            "workload": "gbase.Gbase.reenact: 1 source x N drivers (BASELINE config 5's per-GPU shard), source-side half once per call; "
+                        "autocast-fp16 + channels_last 2D modules, HIP kernels fp32 / f16x3"}
 
 
 def roofline_hbm(hot, inp, B):
@@ -508,6 +539,8 @@ def main():
             line["end_to_end"] = end_to_end(dev, B)
             line["end_to_end_autocast_fp16"] = end_to_end(dev, B, fp16=True)
             line["end_to_end_autocast_fp16_nhwc"] = end_to_end(dev, B, fp16=True, channels_last=True)
+            if args.reenact_leg:   # opt-in: MIOpen's find pass for its shapes adds ~2 minutes to the run
+                line["reenact_1_source_x_64_drivers"] = reenact_leg(dev)
         if world == 1 and args.torch_gpu_baseline:
             line["torch_rocm_baseline"] = torch_rocm_baseline(dev, B)
         if world == 1 and not args.no_cpu_baseline:
