@@ -647,7 +647,9 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *x_range, con
     hipStream_t s = (hipStream_t)stream;
     if (bwd_weight_direct(N, D, H, W)) {
         const size_t nw = (size_t)Co * Ci * k * k * k;
-        const bool per_thread = (long)N * D * H * W <= 64;  // a handful of voxels: one thread per dW element
+        // a handful of voxels whose count the MFMA kernel's 16-byte loads cannot take: one thread per dW element (maps of 4 k
+        // voxels, FlowField's 4x1x1 included, go to the MFMA kernel: 512x256x27 outputs 45 -> ~15 us)
+        const bool per_thread = (long)N * D * H * W <= 64 && (D * H * W) % 4 != 0;
         if (per_thread && k == 3)
             hipLaunchKernelGGL(conv_bwd_weight_direct_kernel<3>, dim3(cdiv(nw, 256)), dim3(256), 0, s, x, dy, dw, N, Ci, Co, D, H, W);
         else if (per_thread)
