@@ -45,6 +45,9 @@ def rel_err(got, want):
     (2, 40, 72, 3, 12, 20, 3),     # ragged channels (not multiples of 32 / 96) and H, W not multiples of 8
     (1, 192, 96, 4, 8, 8, 1),      # 1x1x1 shortcut
     (3, 768, 384, 2, 4, 4, 3),     # deepest level of the 256px configuration (4x4 maps)
+    (4, 64, 40, 4, 1, 1, 3),       # FlowField's first block (4x1x1 maps): the small-map MFMA kernel, one 8-voxel group per sample
+    (2, 8, 12, 1, 3, 3, 3),        # 9 voxels (not a multiple of 4): one thread per dW element
+    (2, 24, 16, 8, 2, 2, 1),       # 1x1x1 on a narrow map
 ])
 @pytest.mark.parametrize("dy_mag", [1.0, 3e-8, 5e4])
 def test_conv3d_bwd_weight(dev, ops, shape, dy_mag):
