@@ -385,6 +385,35 @@ def test_hot_slice_backward_is_bitwise_reproducible(dev, M):
         assert torch.equal(runs[0][1][n], runs[1][1][n]), n
 
 
+def test_hot_slice_on_a_caller_stream(dev, M):
+    """Nothing on the path assumes the null stream: forward and backward issued on a caller-chosen HIP stream (the generators'
+    helper stream forks from and joins back into it) give bitwise the default-stream results."""
+    sd = R.seeded_gbase_hot_state_dict(7)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 46, D=16, H=32, W=32).items()}
+
+    def run(stream):
+        hot = M.GbaseHotSlice()
+        M.load_hot_state_dict(hot, sd)
+        hot = hot.to(dev)
+        if stream is not None:
+            stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(stream if stream is not None else torch.cuda.current_stream()):
+            with torch.no_grad():
+                out = hot.eval().forward_any_size(**inp)
+            gin = {k: v.clone().requires_grad_(True) for k, v in inp.items()}
+            hot.train().forward_any_size(**gin).square().mean().backward()
+            grads = [gin["vs"].grad.clone(), hot.G3d.final_conv.weight.grad.clone(),
+                     hot.warp_generator_s2c.adaptive_matrix_gamma.grad.clone()]
+        torch.cuda.synchronize()
+        return out, grads
+
+    a, ga = run(None)
+    b, gb = run(torch.cuda.Stream())
+    assert torch.equal(a, b)
+    for x, y in zip(ga, gb):
+        assert torch.equal(x, y)
+
+
 def test_config3_train_step_full_size(dev, M):
     """BASELINE config 3's per-GPU shard at its own size: B=4 frames of the 512^2 volume (96x16x64x64) through the
     whole hot slice under autograd — the full-resolution bwd-weight split/slab-reduce plan, warp_volume_bwd at
