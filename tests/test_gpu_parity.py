@@ -559,6 +559,25 @@ def test_hot_slice_batches_beyond_one_pass(dev, hot, M, monkeypatch):
     assert grad_in["vs"].grad.shape == inp["vs"].shape and float(grad_in["vs"].grad[4].abs().max()) > 0
 
 
+def test_hot_slice_accepts_strided_and_half_inputs(dev, hot):
+    """What upstream PyTorch modules hand over: non-contiguous views (a channels_last-style permute, an expanded batch) and
+    fp16 / bf16 tensors from an autocast region (train.py:188) — made contiguous fp32 at the boundary, same results."""
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 49, D=16, H=16, W=16).items()}
+    with torch.no_grad():
+        want = hot.forward_any_size(**inp)
+        strided = dict(inp)
+        strided["vs"] = inp["vs"].permute(0, 2, 3, 4, 1).contiguous().permute(0, 4, 1, 2, 3)      # same values, channel-last strides
+        strided["es"] = inp["es"][:1].expand(2, -1) * 0 + inp["es"]                               # a fresh, contiguous-by-accident copy
+        strided["zs"] = torch.stack([inp["zs"], inp["zs"]], dim=2)[:, :, 0]                        # stride-2 view
+        assert not strided["vs"].is_contiguous() and not strided["zs"].is_contiguous()
+        got = hot.forward_any_size(**strided)
+        assert torch.equal(got, want)
+        half = {k: v.half() for k, v in inp.items()}
+        got16 = hot.forward_any_size(**half)
+        ref16 = hot.forward_any_size(**{k: v.float() for k, v in half.items()})
+        assert got16.dtype == torch.float32 and torch.equal(got16, ref16)
+
+
 def test_hot_slice_full_golden(dev, hot):
     """BASELINE config: 512^2 frame = 96x16x64x64 volume, reference output [1,96,64,64]."""
     g = gold("hot_slice")
