@@ -37,6 +37,9 @@ extern "C" {
 #define MPHIP_ELAUNCH (-2)  /* hipLaunchKernel / runtime error, see mphip_last_error() */
 #define MPHIP_EWORKSPACE (-3) /* workspace too small */
 
+/* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
+ * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
+#define MPHIP_ABI_VERSION 3
 int mphip_version(void);
 const char *mphip_last_error(void);
 

@@ -82,6 +82,17 @@ SIGNATURES = {
 _lib = None
 
 
+def header_abi_version() -> int:
+    """MPHIP_ABI_VERSION of include/mphip.h (the header this binding's SIGNATURES table mirrors)."""
+    import re
+
+    with open(os.path.join(os.path.dirname(_HERE), "include", "mphip.h")) as f:
+        m = re.search(r"#define\s+MPHIP_ABI_VERSION\s+(\d+)", f.read())
+    if m is None:
+        raise RuntimeError("include/mphip.h does not define MPHIP_ABI_VERSION")
+    return int(m.group(1))
+
+
 def build(force: bool = False) -> str:
     """Compile csrc/*.hip for gfx950 into libmphip.so (hipcc cross-compiles without a GPU)."""
     if force or not os.path.isfile(LIB_PATH) or _stale():
@@ -112,6 +123,10 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
         fn.restype = res
         fn.argtypes = args
+    want, got = header_abi_version(), lib.mphip_version()
+    if want != got:   # a stale build next to a newer header (or the reverse): arguments would be passed shifted
+        raise RuntimeError(f"{LIB_PATH} was built with MPHIP_ABI_VERSION {got} but include/mphip.h declares {want}; rebuild "
+                           "it (`python -c 'import __graft_entry__ as g; g.build()'`)")
     _lib = lib
     return lib
 

@@ -14,7 +14,7 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace mphip
 
-extern "C" int mphip_version(void) { return 1; }
+extern "C" int mphip_version(void) { return MPHIP_ABI_VERSION; }
 extern "C" const char *mphip_last_error(void) { return mphip::g_err; }
 
 namespace mphip {

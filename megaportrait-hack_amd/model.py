@@ -448,7 +448,9 @@ class _HotSliceRunner:
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
                 # training: stay connected to the parameters (zero gradients), so this rank's loss.backward() runs and it
                 # enters the gradient all-reduce with the others instead of leaving them blocked in the collective
-                out = out + sum(p.sum() for p in self.parameters() if p.requires_grad) * 0.0
+                # (multiply-free: `p.sum() * 0` would turn one Inf/NaN weight into a NaN loss on this rank and, through the
+                #  all-reduce, on every rank; an empty slice sums to an exact 0 with zero gradients and launches no reduction)
+                out = out + sum(p.reshape(-1)[:0].sum() for p in self.parameters() if p.requires_grad)
             return out
         train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
         if not train and vs.shape[0] > self.max_frames_per_pass:
@@ -529,6 +531,7 @@ class GraphedHotSlice:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.graph = torch.cuda.CUDAGraph()
+            ops.begin_capture()   # range descriptors measured on the warm-up batch are not frozen into the graph
             with torch.cuda.graph(self.graph):
                 self.static_out = fn(**self.static_in)
 

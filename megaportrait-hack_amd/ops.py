@@ -60,7 +60,19 @@ def new_range(device) -> torch.Tensor:
 def tag_range(t: torch.Tensor, rng: Optional[torch.Tensor]) -> torch.Tensor:
     if rng is not None:
         t._mphip_range = (rng, t._version)
+        # produced by a kernel that is itself part of the capture in progress (replays refill it): remember WHICH capture
+        t._mphip_range_capture = _capture_epoch if torch.cuda.is_current_stream_capturing() else -1
     return t
+
+
+_capture_epoch = 0
+
+
+def begin_capture() -> None:
+    """Called by GraphedHotSlice / training.GraphedTrainStep right before `torch.cuda.graph(...)`: descriptors noted during an
+    earlier capture (or during warm-up) are not trusted inside the new one."""
+    global _capture_epoch
+    _capture_epoch += 1
 
 
 def tensor_range(t: torch.Tensor) -> Optional[torch.Tensor]:
@@ -78,7 +90,17 @@ def absmax_range(x: torch.Tensor) -> torch.Tensor:
 
 
 def _range_for(x: torch.Tensor, given: Optional[torch.Tensor] = None) -> torch.Tensor:
-    return given if given is not None else (tensor_range(x) if tensor_range(x) is not None else absmax_range(x))
+    """Operand-scale descriptor of a conv input: the one its producer noted, else one streaming pass.
+    While a hipGraph is being captured a descriptor cached on a tensor of unknown origin is NOT
+    trusted: it was measured on the warm-up batch, and a cache hit would record no absmax kernel — every replay would
+    then scale new inputs by the warm-up batch's range (overflow to Inf for larger inputs, lost precision for smaller
+    ones).  Descriptors produced INSIDE the capture (warp gather, GroupNorm apply) are recorded with it and stay valid."""
+    if given is not None:
+        return given
+    hit = tensor_range(x)
+    if hit is not None and torch.cuda.is_current_stream_capturing() and getattr(x, "_mphip_range_capture", -1) != _capture_epoch:
+        hit = None
+    return hit if hit is not None else absmax_range(x)
 
 
 # ------------------------------------------------------------------ host-built tables
@@ -627,9 +649,13 @@ def upsample_trilinear_bwd(dout: torch.Tensor, scale) -> torch.Tensor:
     dout = _req(dout, "dout")
     n, c, d, h, w = dout.shape
     sd, sh, sw = _int_scale(scale)
+    if d % sd or h % sh or w % sw:
+        raise RuntimeError(f"upsample_trilinear_bwd: gradient dims {(d, h, w)} are not multiples of the scale factors {(sd, sh, sw)}")
     dx = torch.empty((n, c, d // sd, h // sh, w // sw), dtype=torch.float32, device=dout.device)
     if dx.numel() % 4:
-        raise RuntimeError("upsample_trilinear_bwd: gradient tensor size must be a multiple of 4 elements")
+        # (the kernel zero-fills dx with 16-byte stores before its fp32 atomic scatter: not bitwise reproducible run to run,
+        #  unlike the x2 align_corners=True adjoint G3d uses — no module of Gbase sets `upsample=True`, model.py:404,525)
+        raise RuntimeError(f"upsample_trilinear_bwd: input-gradient size {dx.numel()} must be a multiple of 4 elements")
     _lib.check(_lib.load().mphip_upsample_trilinear_bwd(_ptr(dout), _ptr(dx), n * c, d // sd, h // sh, w // sw, sd, sh, sw, _stream()),
                "mphip_upsample_trilinear_bwd")
     return dx

@@ -76,6 +76,16 @@ class OverlappedGradReducer:
 
         reducer = OverlappedGradReducer(model.parameters())          # after the process group exists
         reducer.prepare(); loss_fn(model, **shard).backward(); reducer.finish(); optimizer.step()
+
+    Two contracts that differ from the reference's single-GPU loop, both guarded:
+    * ONE backward per prepare()/finish() pair.  A second backward() without prepare() (gradient accumulation) would find
+      every bucket already launched and its gradients would never be all-reduced: `_on_grad` raises instead.  Accumulate by
+      calling prepare(zero=False) between micro-batches of a step that should NOT be reduced yet, or sum the losses first.
+    * Every parameter's `.grad` is a view into a zero-filled bucket, so a parameter that took no part in the step (the
+      reference's unused `adaptive_matrix_beta`, or everything on an empty-shard rank) holds a ZERO gradient, not None — an
+      optimizer with weight decay or Adam-style step counters would still update it where the reference's loop skips it.
+      `finish(skip_unused=True)` restores the reference's semantics: parameters that received no gradient on ANY rank get
+      `.grad = None` for the optimizer step (one extra 1-byte-per-parameter all-reduce); prepare() re-attaches the views.
     """
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group=None, bucket_bytes: int = 64 << 20, average: bool = True):
@@ -99,10 +109,12 @@ class OverlappedGradReducer:
         self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for b in self.buckets for p in b]
         self.prepare()
 
-    def prepare(self) -> None:
+    def prepare(self, zero: bool = True) -> None:
         """Start of a step: zero the flat buffers in place (the `.grad` views stay) and reset the bookkeeping."""
-        for flat in self.flats:
-            flat.zero_()
+        if zero:
+            for flat in self.flats:
+                flat.zero_()
+        self._touched = set()
         for p, view in self.views.items():
             if p.grad is not view:          # someone called zero_grad(set_to_none=True): re-attach the view
                 p.grad = view
@@ -113,6 +125,10 @@ class OverlappedGradReducer:
         self.launched_during_backward = 0
 
     def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if self._next > self.bucket_of[p] or not self._in_backward:
+            raise RuntimeError("OverlappedGradReducer: a gradient arrived for a bucket that was already all-reduced in this step "
+                               "(second backward() without prepare(), or backward() after finish()); call prepare() first")
+        self._touched.add(p)
         view = self.views[p]
         if p.grad is not view:               # autograd installed a fresh tensor (grad was None): fold it into the bucket
             if p.grad is not None:
@@ -132,9 +148,13 @@ class OverlappedGradReducer:
                     self.launched_during_backward += 1
             self._next += 1
 
-    def finish(self) -> int:
+    def finish(self, skip_unused: bool = False) -> int:
         """After backward: launch what is still pending (buckets holding parameters without a gradient on this rank),
-        wait for every collective, average in place.  Returns the number of all-reduces of this step."""
+        wait for every collective, average in place.  Returns the number of all-reduces of this step.
+        skip_unused: parameters no rank produced a gradient for get `.grad = None` (the optimizer then skips them, like the
+        reference's loop does for `adaptive_matrix_beta`)."""
+        import torch.distributed as dist
+
         self._in_backward = False
         self._launch_ready(force=True)
         for w in self._works:
@@ -142,6 +162,14 @@ class OverlappedGradReducer:
         if self.average and self.world > 1:
             for flat in self.flats:
                 flat.div_(self.world)
+        if skip_unused:
+            order = [p for b in self.buckets for p in b]
+            used = torch.tensor([p in self._touched for p in order], dtype=torch.uint8, device=self.flats[0].device if self.flats else "cpu")
+            if self.world > 1:
+                dist.all_reduce(used, op=dist.ReduceOp.MAX, group=self.group)
+            for p, u in zip(order, used.tolist()):
+                if not u:
+                    p.grad = None
         return len(self._works)
 
     def remove(self) -> None:
@@ -227,6 +255,7 @@ class GraphedTrainStep:
         optimizer.zero_grad(set_to_none=True)
         for v in self.static_in.values():
             v.grad = None
+        ops.begin_capture()   # range descriptors measured on the warm-up batch are not frozen into the graph (ops._range_for)
         with ops.repack_always(), torch.cuda.graph(self.graph):
             self.static_loss = loss_fn(model, **self.static_in)
             self.static_loss.backward()

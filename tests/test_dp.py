@@ -192,3 +192,43 @@ def test_overlapped_gradient_allreduce_equals_posthoc_gloo():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_overlapped_reducer_guards_single_process():
+    """ADVICE r2: (a) a second backward() without prepare() must raise instead of silently skipping the all-reduce;
+    (b) finish(skip_unused=True) gives parameters that took no part in the step `.grad = None` (the reference's single-GPU
+    loop never updates `adaptive_matrix_beta`; an Adam / weight-decay step on a zero gradient would)."""
+    from megaportrait_hack_amd import training
+
+    torch.manual_seed(5)
+    m = torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 2))
+    m.unused = torch.nn.Parameter(torch.ones(3))
+    red = training.OverlappedGradReducer(m.parameters(), bucket_bytes=64)
+    x = torch.randn(5, 4)
+    red.prepare()
+    m(x).sum().backward()
+    with pytest.raises(RuntimeError, match="prepare"):
+        m(x).sum().backward()          # gradient accumulation without prepare(): every bucket of the step already went out
+    red.prepare()
+    m(x).sum().backward()
+    red.finish()
+    assert m.unused.grad is not None and float(m.unused.grad.abs().max()) == 0.0   # default: zero gradient (documented)
+    red.prepare()
+    m(x).sum().backward()
+    red.finish(skip_unused=True)
+    assert m.unused.grad is None and all(p.grad is not None for p in m[0].parameters())
+    opt = torch.optim.Adam(m.parameters(), lr=0.1, weight_decay=0.1)
+    before = m.unused.detach().clone()
+    opt.step()
+    assert torch.equal(m.unused, before)                                            # skipped, like the reference's loop
+    red.prepare()                                                                   # views are re-attached for the next step
+    assert m.unused.grad is red.views[m.unused]
+
+
+def test_empty_shard_loss_is_multiply_free():
+    """the empty-shard connection to the parameters must not turn an Inf/NaN weight into a NaN loss."""
+    ps = [torch.nn.Parameter(torch.tensor([1.0, float("inf")])), torch.nn.Parameter(torch.tensor([float("nan")]))]
+    z = sum(p.reshape(-1)[:0].sum() for p in ps)
+    assert float(z) == 0.0
+    z.backward()
+    assert all(p.grad is not None and float(p.grad.abs().max()) == 0.0 for p in ps)

@@ -544,6 +544,49 @@ def test_graphed_train_step_matches_eager(dev, M):
         assert rel_err(graphed(x), eager(x).cpu()) < 1e-5
 
 
+def test_graph_replay_follows_the_input_range(dev, M):
+    """a static input that feeds an f16x3 conv directly (G3d(x)) got its operand scale measured on the
+    warm-up batch and frozen into the hipGraph.  Replays with a 100x larger / 1000x smaller input must match eager runs."""
+    from megaportrait_hack_amd import training
+
+    g = M.G3d(96)
+    sd = R.seeded_state_dict(R.g3d_shapes(96), 91, prefix="G3d.")
+    g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+    g = g.to(dev).eval()
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 92).to(dev)
+
+    class Wrap:  # GraphedHotSlice drives any callable with keyword inputs
+        def forward(self, x):
+            return g(x)
+        forward_any_size = forward
+
+    graphed = M.GraphedHotSlice(Wrap(), {"x": x}, any_size=True)
+    for scale in (1.0, 100.0, 1e-3):
+        xin = x * scale
+        with torch.no_grad():
+            want = g(xin.clone())
+        got = graphed(x=xin).clone()
+        assert torch.isfinite(got).all(), scale
+        assert rel_err(got, want.cpu()) < 1e-5, scale
+    # ... and through the training graph (Conv3dFn reuses the forward range for bwd-weight)
+    gt = M.G3d(96)
+    gt.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+    gt = gt.to(dev).train()
+    ge = M.G3d(96)
+    ge.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+    ge = ge.to(dev).train()
+    tgt = R.seeded_tensor((1, 96, 8, 16, 16), 93).to(dev)
+    loss_fn = lambda m, x: F.mse_loss(m(x), tgt)
+    opt_g = torch.optim.SGD(gt.parameters(), lr=1e-3)
+    opt_e = torch.optim.SGD(ge.parameters(), lr=1e-3)
+    step = training.GraphedTrainStep(gt, loss_fn, opt_g, {"x": x}, warmup=2)
+    for scale in (100.0, 1.0):
+        lg = step(x=x * scale)
+        le = training.train_step(ge, loss_fn, opt_e, {"x": x * scale})
+        assert torch.isfinite(lg).all()
+        assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item()), (scale, le.item(), lg.item())
+
+
 def test_autocast_inputs_are_computed_in_fp32(dev, M):
     """train.py:188 calls the generator under autocast: half-precision inputs / an enabled autocast region must not
     change what the HIP path computes (fp32), forward or backward."""

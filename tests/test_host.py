@@ -31,7 +31,17 @@ def test_header_symbols_are_exported(lib):
     for name in declared:
         assert hasattr(raw, name), f"{name} declared in mphip.h but not exported by libmphip.so"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with mphip.h"
-    assert lib.mphip_version() == 1
+    # the library reports the ABI version it was built with; the binding refuses a mismatch with the header
+    assert lib.mphip_version() == _lib.header_abi_version() >= 3
+
+
+def test_stale_library_is_refused(lib, monkeypatch):
+    from megaportrait_hack_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "header_abi_version", lambda: 999)
+    with pytest.raises(RuntimeError, match="MPHIP_ABI_VERSION"):
+        _lib.load()
 
 
 def test_argument_validation_needs_no_gpu(lib):
