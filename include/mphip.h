@@ -310,6 +310,47 @@ int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *
 int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
                        int invert, void *stream);
 
+/* ------------------------------------------------------------------ one-call entries: the hot slice and G3d as plans
+ * Replace the single calls of the reference: Gbase.forward's slice (model.py:1151-1171: WarpGeneratorS2C ->
+ * apply_warping_field -> G3d -> WarpGeneratorC2D -> apply_warping_field -> torch.sum(dim=2)) and G3d.forward
+ * (model.py:593-597).  A plan is built from the reference's state-dict: `names[i]` = the key relative to Gbase
+ * ("warp_generator_s2c.flowfield.resblock1.conv1.weight", "G3d.downsampling.0.gn1.bias", "G3d.final_conv.weight", ...; the
+ * keys of WarpGeneratorS2C / WarpGeneratorC2D / G3d listed in SURVEY.md Appendix C, `adaptive_matrix_beta` is not read —
+ * the reference never uses it, model.py:958-963), `tensors[i]` = that tensor on the device, fp32, contiguous, in the
+ * reference's own layout (OIDHW conv weights).  The plan keeps the POINTERS (the caller keeps the tensors alive) and
+ * owns what it derives from them: packed conv weights (hipMalloc, built on the first forward's stream), the side stream
+ * on which the C2D generator runs underneath G3d, and the carve-up of the caller's workspace.  The launches are the
+ * per-op entry points above in the order the Python host issues them: results are bitwise identical to that path.
+ *   flags: MPHIP_PLAN_G3D_ONLY — only the G3d.* keys are needed (mphip_g3d_forward only);
+ *          MPHIP_PLAN_SINGLE_STREAM — no side stream (everything on the caller's stream).
+ *   C,D,H,W: the appearance volume (96,16,64,64 in the reference, model.py:1157).  torch.linspace(-1,1,n) tables for
+ *          n = 16 and 64 and F.affine_grid's 64^3 base grid are built in (bit patterns captured from the reference's CPU
+ *          path); for other sizes hand the device tables in with mphip_hot_slice_plan_set_tables before the first forward.
+ *   refresh: after an in-place weight update call it with (NULL, NULL, 0) — every pack is rebuilt on the next forward's
+ *          stream; after the parameters moved (new storage) pass the new name/pointer lists.
+ *   forward: vs [B,96,D,H,W], es/zs/zd [B,512], Rs/Rd [B,3] Euler degrees, ts/td [B,3] -> out [B,96,H,W]; any B (more than
+ *          MPHIP_PLAN_MAX_FRAMES_PER_PASS frames run as consecutive passes).  No allocation, no host sync: capturable in a
+ *          hipGraph after one warm-up call (the first call of a batch size allocates the packed weights).  Two forwards
+ *          of one plan in flight on different streams need different workspaces.
+ *   mphip_g3d_forward: x [B,96,D,H,W] (+ its range descriptor or NULL) -> y [B,96,D,H,W], B <= MPHIP_PLAN_MAX_FRAMES_PER_PASS. */
+typedef struct mphip_hot_slice_plan mphip_hot_slice_plan;
+#define MPHIP_PLAN_G3D_ONLY 1
+#define MPHIP_PLAN_SINGLE_STREAM 2
+#define MPHIP_PLAN_MAX_FRAMES_PER_PASS 64   /* the conv kernels address their input through one 2 GiB buffer resource */
+int mphip_hot_slice_plan_create(const char *const *names, const void *const *tensors, int n_tensors, int C, int D, int H, int W,
+                                int flags, mphip_hot_slice_plan **out);
+int mphip_hot_slice_plan_set_tables(mphip_hot_slice_plan *plan, const float *lin_d, const float *lin_h, const float *lin_w,
+                                    const float *affine_base);
+int mphip_hot_slice_plan_refresh(mphip_hot_slice_plan *plan, const char *const *names, const void *const *tensors, int n_tensors);
+size_t mphip_hot_slice_workspace_bytes(mphip_hot_slice_plan *plan, int B);
+int mphip_hot_slice_forward(mphip_hot_slice_plan *plan, const float *vs, const float *es, const float *Rs, const float *ts,
+                            const float *zs, const float *Rd, const float *td, const float *zd, float *out, int B, void *workspace,
+                            size_t workspace_bytes, void *stream);
+size_t mphip_g3d_workspace_bytes(mphip_hot_slice_plan *plan, int B);
+int mphip_g3d_forward(mphip_hot_slice_plan *plan, const float *x, const float *x_range, float *y, int B, void *workspace,
+                      size_t workspace_bytes, void *stream);
+void mphip_hot_slice_plan_destroy(mphip_hot_slice_plan *plan);
+
 /* Diagnostic (synchronous, not stream-ordered): operand elements of the f16x3 conv kernels whose scaled value was outside
  * the f16 range since the last reset — Inf/NaN inputs, or finite values beyond a wrong caller-supplied range descriptor.
  * They are NOT clamped (the output carries Inf/NaN like the reference's fp32 conv would); 0 in normal operation.     */

@@ -77,6 +77,14 @@ SIGNATURES = {
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2_bwd_workspace_bytes": (_sz, [_i] * 4),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_hot_slice_plan_create": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
+    "mphip_hot_slice_plan_set_tables": (_i, [_p, _p, _p, _p, _p]),
+    "mphip_hot_slice_plan_refresh": (_i, [_p, _p, _p, _i]),
+    "mphip_hot_slice_workspace_bytes": (_sz, [_p, _i]),
+    "mphip_hot_slice_forward": (_i, [_p] * 10 + [_i, _p, _sz, _p]),
+    "mphip_g3d_workspace_bytes": (_sz, [_p, _i]),
+    "mphip_g3d_forward": (_i, [_p, _p, _p, _p, _i, _p, _sz, _p]),
+    "mphip_hot_slice_plan_destroy": (None, [_p]),
 }
 
 _lib = None

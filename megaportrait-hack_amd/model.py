@@ -441,7 +441,33 @@ class _HotSliceRunner:
             st = table[key] = torch.cuda.Stream(device=main.device)
         return st
 
+    # Inference goes through the C-side plan (csrc/plan.hip, include/mphip.h "one-call entries"): ONE ctypes call per step
+    # issues the same launches in the same order as `_run_python` below (bitwise identical results, tests/test_gpu_plan.py);
+    # a single frame is launch-bound and the ~135 Python/ctypes round trips cost more than the kernels.  MPHIP_C_PLAN=0 or
+    # `use_c_plan = False` selects the per-op schedule (also taken under autograd and when a measurement hook is installed).
+    use_c_plan = os.environ.get("MPHIP_C_PLAN", "1") != "0"
+
+    def _plan_for(self, vs):
+        from . import plan as _plan
+
+        key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators))
+        table = self.__dict__.setdefault("_plans", {})
+        pl = table.get(key)
+        if pl is None:
+            pl = table[key] = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators)
+        return pl
+
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
+        vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
+        if (self.use_c_plan and vs.shape[0] > 0 and vs.dim() == 5 and vs.shape[1] == 96 and ops._conv_hook is None
+                and not ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
+                and all(v % 8 == 0 for v in vs.shape[2:])):
+            if check_shape:
+                assert vs.shape[1:] == (96, 16, 64, 64), f"Expected vc shape (_, 96, 16, 64, 64), got {vs.shape}"
+            return self._plan_for(vs).forward(vs, es, Rs, ts, zs, Rd, td, zd)
+        return self._run_python(vs, es, Rs, ts, zs, Rd, td, zd, check_shape)
+
+    def _run_python(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
         if vs.shape[0] == 0:  # an empty frame shard (dp.shard_inputs with more ranks than frames): nothing to launch
             out = vs.new_zeros((0, vs.shape[1]) + tuple(vs.shape[3:]))
@@ -455,7 +481,7 @@ class _HotSliceRunner:
         train = ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
         if not train and vs.shape[0] > self.max_frames_per_pass:
             step = int(self.max_frames_per_pass)
-            return torch.cat([self._run(*(t[i:i + step] for t in (vs, es, Rs, ts, zs, Rd, td, zd)), check_shape)
+            return torch.cat([self._run_python(*(t[i:i + step] for t in (vs, es, Rs, ts, zs, Rd, td, zd)), check_shape)
                               for i in range(0, vs.shape[0], step)], dim=0)
         main = torch.cuda.current_stream(vs.device)
         # training: one stream (autograd replays each op's backward on its forward stream; the overlap is an inference trick)

@@ -1,0 +1,147 @@
+"""GPU tests of the one-call entries (include/mphip.h: mphip_hot_slice_plan_*, mphip_g3d_forward).
+The plan issues the same launches as the Python schedule (model._HotSliceRunner._run), so the results must be BITWISE
+equal to it — and through it pinned to the oracle / the reference's goldens (tests/test_gpu_parity.py)."""
+import os
+import subprocess
+
+import pytest
+import torch
+
+from oracle import hotpath_ref as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def M():
+    from megaportrait_hack_amd import _lib, model
+
+    _lib.load()
+    return model
+
+
+def _hot(M, dev, seed=21):
+    hot = M.GbaseHotSlice()
+    M.load_hot_state_dict(hot, R.seeded_gbase_hot_state_dict(seed))
+    return hot.to(dev).eval()
+
+
+@pytest.mark.parametrize("shape", [(1, 16, 16, 16), (3, 8, 16, 16), (2, 16, 64, 64)])
+def test_plan_equals_python_schedule_bitwise(dev, M, shape):
+    from megaportrait_hack_amd import plan as P
+
+    b, d, h, w = shape
+    hot = _hot(M, dev)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(b, 5, D=d, H=h, W=w).items()}
+    pl = P.HotSlicePlan(hot, dims=(96, d, h, w))
+    with torch.no_grad():
+        want = hot._run_python(check_shape=False, **inp)
+        got = pl(**inp)
+        again = pl(**inp)      # the workspace is reused: same result
+    assert got.shape == want.shape == (b, 96, h, w)
+    assert torch.equal(got, want)
+    assert torch.equal(again, want)
+    # ... and against the CPU oracle at the small sizes
+    if d * h * w <= 16 * 16 * 16:
+        ref = R.hot_slice(sd=R.seeded_gbase_hot_state_dict(21), **R.seeded_hot_inputs(b, 5, D=d, H=h, W=w))
+        assert (got.cpu() - ref).abs().max().item() < 1e-3
+    single = P.HotSlicePlan(hot, dims=(96, d, h, w), single_stream=True)
+    with torch.no_grad():
+        assert torch.equal(single(**inp), want)
+
+
+def test_plan_is_the_default_inference_path(dev, M):
+    """GbaseHotSlice.forward under no_grad goes through the plan (one ctypes call); MPHIP_C_PLAN=0 / use_c_plan=False
+    selects the per-op Python schedule.  Same bits either way."""
+    hot = _hot(M, dev)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 7, D=8, H=16, W=16).items()}
+    with torch.no_grad():
+        a = hot.forward_any_size(**inp)
+        assert hot.__dict__.get("_plans"), "the plan was not used"
+        hot.use_c_plan = False
+        b = hot.forward_any_size(**inp)
+    assert torch.equal(a, b)
+
+
+def test_plan_follows_weight_updates(dev, M):
+    from megaportrait_hack_amd import plan as P
+
+    hot = _hot(M, dev)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 9, D=8, H=16, W=16).items()}
+    pl = P.HotSlicePlan(hot, dims=(96, 8, 16, 16))
+    with torch.no_grad():
+        before = pl(**inp).clone()
+        hot.G3d.final_conv.weight.mul_(1.5)                              # in-place update: version counter bumps
+        hot.warp_generator_c2d.flowfield.conv1x1.bias.add_(0.25)
+        after = pl(**inp)
+        want = hot._run_python(check_shape=False, **inp)
+    assert not torch.equal(before, after)
+    assert torch.equal(after, want)
+    M.load_hot_state_dict(hot, R.seeded_gbase_hot_state_dict(33))        # load_state_dict copies in place
+    with torch.no_grad():
+        assert torch.equal(pl(**inp), hot._run_python(check_shape=False, **inp))
+
+
+def test_g3d_forward_entry(dev, M):
+    from megaportrait_hack_amd import ops, plan as P
+
+    hot = _hot(M, dev)
+    x = R.seeded_tensor((2, 96, 8, 16, 16), 41).to(dev)
+    pl = P.HotSlicePlan(hot, dims=(96, 8, 16, 16), g3d_only=True)
+    with torch.no_grad():
+        want = hot.G3d(x.clone())
+        got = pl.g3d(x)                                  # x_range = NULL: the library measures x
+        rng = ops.absmax_range(x)
+        got2 = pl.g3d(x, rng)
+    assert torch.equal(got, want) and torch.equal(got2, want)
+    with pytest.raises(RuntimeError, match="generators"):
+        pl(**{k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 5, D=8, H=16, W=16).items()})
+
+
+def test_plan_argument_errors(dev, M):
+    from megaportrait_hack_amd import plan as P
+
+    hot = _hot(M, dev)
+    pl = P.HotSlicePlan(hot, dims=(96, 8, 16, 16))
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 5, D=8, H=16, W=16).items()}
+    with pytest.raises(RuntimeError, match="does not match"):
+        pl(**{**inp, "vs": inp["vs"][:, :, :4].contiguous()})
+    lib = pl.lib
+    need = lib.mphip_hot_slice_workspace_bytes(pl._handle, 1)
+    assert need > 0
+    small = torch.empty(1024, dtype=torch.uint8, device=dev)
+    import ctypes
+    out = torch.empty((1, 96, 16, 16), device=dev)
+    rc = lib.mphip_hot_slice_forward(pl._handle, *(ctypes.c_void_p(inp[k].data_ptr()) for k in ("vs", "es", "Rs", "ts", "zs", "Rd", "td", "zd")),
+                                     ctypes.c_void_p(out.data_ptr()), 1, ctypes.c_void_p(small.data_ptr()), small.numel(), None)
+    assert rc == -3 and b"workspace" in lib.mphip_last_error()
+
+
+def test_plan_graph_capture(dev, M):
+    """No allocation / host sync in forward: the one-call entry is capturable after a warm-up call."""
+    from megaportrait_hack_amd import plan as P
+
+    hot = _hot(M, dev)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(1, 5, D=8, H=16, W=16).items()}
+    pl = P.HotSlicePlan(hot, dims=(96, 8, 16, 16))
+    with torch.no_grad():
+        want = pl(**inp).clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            pl(**inp)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = pl(**inp)
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+    assert torch.equal(out, want)
