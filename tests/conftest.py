@@ -56,3 +56,21 @@ def c_abi_exe(tmp_path):
            "-L", "/opt/rocm/lib", "-lamdhip64", "-lm", f"-Wl,-rpath,{pkg}", "-Wl,-rpath,/opt/rocm/lib"]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
     return exe
+
+
+@pytest.fixture
+def plan_c_exe(tmp_path, oracle_c):
+    """tests/c_abi/plan_smoke.c (C99, gcc) against include/mphip.h + libmphip.so, checked against the plain-C oracle
+    (oracle/libmphip_oracle.so: test infrastructure) — compiling/linking needs no GPU; running it does."""
+    import subprocess
+
+    pkg = os.path.join(ROOT, "megaportrait-hack_amd")
+    orc = os.path.join(ROOT, "oracle")
+    exe = os.path.join(str(tmp_path), "plan_smoke")
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I", os.path.join(ROOT, "include"),
+           "-I", "/opt/rocm/include", os.path.join(ROOT, "tests", "c_abi", "plan_smoke.c"), "-o", exe, "-L", pkg, "-lmphip",
+           "-L", orc, "-lmphip_oracle", "-L", "/opt/rocm/lib", "-lamdhip64", "-lm", "-fopenmp", f"-Wl,-rpath,{pkg}", f"-Wl,-rpath,{orc}",
+           "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe

@@ -145,3 +145,15 @@ def test_plan_graph_capture(dev, M):
         g.replay()
         torch.cuda.synchronize()
     assert torch.equal(out, want)
+
+
+def test_plan_from_plain_c(plan_c_exe):
+    """tests/c_abi/plan_smoke.c: K2 coordinates / indices / values bit-exact vs the C oracle, K3, an f16x3 3x3x3 conv with a
+    caller-built range descriptor, and the whole slice through mphip_hot_slice_plan_* against the committed oracle golden
+    (tests/golden/plan_c_expected.bin, oracle/make_golden_plan.py) — no Python between the C program and the library."""
+    gold = os.path.join(ROOT, "tests", "golden")
+    r = subprocess.run([plan_c_exe, os.path.join(gold, "plan_c_manifest.txt"), os.path.join(gold, "plan_c_expected.bin")],
+                       capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "bit-exact" in r.stdout and "PLAN C ABI OK" in r.stdout

@@ -146,6 +146,12 @@ def test_c_abi_compiles_and_links_from_plain_c(c_abi_exe):
     assert os.path.isfile(c_abi_exe)
 
 
+def test_plan_c_program_compiles_and_links(plan_c_exe):
+    """tests/c_abi/plan_smoke.c (the one-call entries + index-contract ops from C99) builds against the header and links
+    against libmphip.so without a GPU; tests/test_gpu_plan.py runs it."""
+    assert os.path.isfile(plan_c_exe)
+
+
 def test_bench_self_launches_ranks():
     """`python bench.py --gpus N` with no torchrun environment must start N ranks itself (the driver's
     SCALE command).  --dry-launch shows the command; --stub-worker runs the real launch path on CPU over gloo."""
