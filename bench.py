@@ -63,7 +63,10 @@ def parse():
                     help="launcher self-test (CPU, gloo): every rank joins the process group, rank 0 prints "
                          '{"stub_worker": true, "ranks": N}; no GPU work')
     ap.add_argument("--reenact-leg", action="store_true",
-                    help="also time BASELINE config 5's per-GPU shard (1 source x 64 drivers through Gbase.reenact) as a side measurement")
+                    help="also time BASELINE config 5's per-GPU shard in its serving configuration (channels_last + MIOpen find mode; "
+                         "the default line carries the immediate-mode leg `reenact_1x64`)")
+    ap.add_argument("--e2e-nhwc", action="store_true", help="also time the end-to-end generator with channels_last 2D modules + MIOpen find mode")
+    ap.add_argument("--extras-budget", type=float, default=100.0, help="seconds of side measurements after which remaining legs are skipped")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements on the line (fp32_exact, roofline_hbm, end_to_end)")
     return ap.parse_args()
@@ -98,6 +101,23 @@ def launch_ranks(args):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL needs it on this driver
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
     return subprocess.run(cmd, env=env).returncode
+
+
+def pin_rank(local_rank: int, world: int) -> dict:
+    """One rank per GPU: give every rank its own contiguous slice of the host cores this process may use (Linux numbers the
+    cores of a NUMA node contiguously, and GPUs are attached to nodes in order on the 8-GPU MI355X boards), and size the OpenMP /
+    ATen thread pools to it — otherwise N ranks each start a pool as wide as the whole machine.  MPHIP_PIN_RANKS=0 disables."""
+    if world <= 1 or os.environ.get("MPHIP_PIN_RANKS", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return {}
+    cores = sorted(os.sched_getaffinity(0))
+    per = max(1, len(cores) // world)
+    mine = cores[local_rank * per:(local_rank + 1) * per] or cores
+    try:
+        os.sched_setaffinity(0, mine)
+    except OSError:
+        return {}
+    torch.set_num_threads(max(1, min(len(mine), int(os.environ.get("OMP_NUM_THREADS", len(mine))))))
+    return {"cores": [mine[0], mine[-1]], "threads": torch.get_num_threads()}
 
 
 def stub_worker(args, rank, world):
@@ -244,16 +264,19 @@ def end_to_end(dev, B, steps=8, warmup=3, fp16=False, channels_last=False):
                         "2D encoders/decoder on PyTorch-ROCm, 3D tail + hot slice + G2d head on libmphip", "precision_2d": prec}
 
 
-def reenact_leg(dev, drivers=64, chunk=16, repeats=3):
+def reenact_leg(dev, drivers=64, chunk=16, repeats=3, find=True):
     """BASELINE config 5 on one GPU: ONE source image x `drivers` driver frames through gbase.Gbase.reenact — the source-side
     half (Eapp, Emtn(xs), S2C field, warp #1, G3d) runs once, per driver only Emtn(xd), the C2D field, the fused warp + depth sum
-    and G2d; autocast-fp16 2D modules in channels_last with MIOpen's find mode (the serving configuration).  Side measurement."""
+    and G2d; autocast-fp16 2D modules.  find=True: channels_last + MIOpen's find mode (the serving configuration; its kernel
+    search adds ~2 minutes to a fresh process); find=False (the default line's compact leg): MIOpen immediate mode, NCHW."""
     from megaportrait_hack_amd import gbase
 
     torch.manual_seed(20240501)
     find_mode = torch.backends.cudnn.benchmark
-    torch.backends.cudnn.benchmark = True
-    g = gbase.Gbase().to(dev).eval().channels_last_2d()
+    torch.backends.cudnn.benchmark = bool(find)
+    g = gbase.Gbase().to(dev).eval()
+    if find:
+        g.channels_last_2d()
     gen = torch.Generator(device="cpu").manual_seed(20240502)
     xs = torch.rand(1, 3, 512, 512, generator=gen).to(dev)
     xd = torch.rand(drivers, 3, 512, 512, generator=gen).to(dev)
@@ -270,7 +293,8 @@ def reenact_leg(dev, drivers=64, chunk=16, repeats=3):
     torch.cuda.empty_cache()
     return {"value": round(drivers / dt, 1), "unit": "driver frames/s", "ms_per_call": round(dt * 1e3, 1), "drivers": drivers, "chunk": chunk,
             "workload": "gbase.Gbase.reenact: 1 source x N drivers (BASELINE config 5's per-GPU shard), source-side half once per call; "
-                        "autocast-fp16 + channels_last 2D modules, HIP kernels fp32 / f16x3"}
+                        "autocast-fp16 2D modules (" + ("channels_last, MIOpen find mode" if find else "NCHW, MIOpen immediate mode") +
+                        "), HIP kernels fp32 / f16x3"}
 
 
 def roofline_hbm(hot, inp, B):
@@ -329,6 +353,41 @@ def fp32_exact(hot, inp, B, steps=10, warmup=2):
         ops.set_conv_precision(old)
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
             "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
+
+
+def train_leg(dev, B=4, steps=10, warmup=3):
+    """BASELINE config 3's per-GPU shard on the default line: one training step of the hot slice (forward + backward + SGD,
+    eager launches) at B=4, 96x16x64x64.  Side measurement; `--mode train` is the full-featured version (hipGraph, N ranks)."""
+    import torch.nn.functional as F
+
+    from megaportrait_hack_amd import model as M, training
+
+    torch.manual_seed(20240501)
+    hot = M.GbaseHotSlice().to(dev).train()
+    g = torch.Generator(device="cpu").manual_seed(20240501)
+    inp = dict(vs=torch.randn(B, 96, 16, 64, 64, generator=g), es=torch.randn(B, 512, generator=g),
+               zs=torch.randn(B, 512, generator=g), zd=torch.randn(B, 512, generator=g),
+               Rs=(torch.rand(B, 3, generator=g) * 60 - 30), Rd=(torch.rand(B, 3, generator=g) * 60 - 30),
+               ts=torch.randn(B, 3, generator=g) * 0.1, td=torch.randn(B, 3, generator=g) * 0.1)
+    inp = {k: v.to(dev) for k, v in inp.items()}
+    inp["vs"].requires_grad_(True)
+    tgt = torch.randn(B, 96, 64, 64, generator=g).to(dev)
+    loss_fn = lambda m, **kw: F.mse_loss(m(**kw), tgt)
+    opt = torch.optim.SGD(hot.parameters(), lr=1e-5)
+    for _ in range(warmup):
+        loss = training.train_step(hot, loss_fn, opt, inp)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = training.train_step(hot, loss_fn, opt, inp)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss).all()
+    del hot, opt
+    torch.cuda.empty_cache()
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "steps": steps,
+            "workload": "GbaseHotSlice training step (forward + backward + SGD, eager launches), BASELINE config 3's per-GPU shard",
+            "dtype": "f16x3 forward/backward convs, fp32 everything else"}
 
 
 def train_mode(args, rank, world, dev, dist):
@@ -405,6 +464,7 @@ def main():
     if args.stub_worker:
         return stub_worker(args, rank, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    pinned = pin_rank(local_rank, world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -513,6 +573,7 @@ def main():
                        "launch": "hipGraph replay of the captured step" if args.graph else "eager stream launches",
                        "batches_in_flight": 1 if (args.graph or args.inflight < 2) else args.inflight},
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "rank0_host_pinning": pinned or None,
             "step_ms": ({"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)}
                         if step_ms else None),
             "hot_slice_tflops": round(fps * FRAME_FLOPS / 1e12, 2),
@@ -532,15 +593,32 @@ def main():
                                  "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         }
         if world == 1 and not args.no_extras:
+            # side measurements (N=1 only, never inside the timed region): each leg is timed, and legs that would push the
+            # default run past its budget are skipped and say so
             ops.set_conv_hook(None)
-            line["roofline_hbm"] = roofline_hbm(hot, inp, B)
+            t_legs, secs = time.perf_counter(), {}
+
+            def leg(key, fn, *a, **kw):
+                spent = time.perf_counter() - t_legs
+                if spent > args.extras_budget:
+                    line[key] = {"skipped": f"extras budget ({args.extras_budget:.0f} s) spent after {spent:.0f} s"}
+                    return
+                t0_ = time.perf_counter()
+                line[key] = fn(*a, **kw)
+                secs[key] = round(time.perf_counter() - t0_, 1)
+
+            leg("roofline_hbm", roofline_hbm, hot, inp, B)
             if f16x3:
-                line["fp32_exact"] = fp32_exact(hot, inp, B)
-            line["end_to_end"] = end_to_end(dev, B)
-            line["end_to_end_autocast_fp16"] = end_to_end(dev, B, fp16=True)
-            line["end_to_end_autocast_fp16_nhwc"] = end_to_end(dev, B, fp16=True, channels_last=True)
+                leg("fp32_exact", fp32_exact, hot, inp, B)
+            leg("train_step", train_leg, dev)                                    # BASELINE config 3's per-GPU shard
+            leg("reenact_1x64", reenact_leg, dev, repeats=2, find=False)         # BASELINE config 5's per-GPU shard
+            leg("end_to_end", end_to_end, dev, B, steps=5, warmup=2)
+            leg("end_to_end_autocast_fp16", end_to_end, dev, B, steps=5, warmup=2, fp16=True)
+            if args.e2e_nhwc:      # opt-in: MIOpen's find pass adds ~1 minute
+                line["end_to_end_autocast_fp16_nhwc"] = end_to_end(dev, B, fp16=True, channels_last=True)
             if args.reenact_leg:   # opt-in: MIOpen's find pass for its shapes adds ~2 minutes to the run
                 line["reenact_1_source_x_64_drivers"] = reenact_leg(dev)
+            line["leg_seconds"] = secs
         if world == 1 and args.torch_gpu_baseline:
             line["torch_rocm_baseline"] = torch_rocm_baseline(dev, B)
         if world == 1 and not args.no_cpu_baseline:

@@ -326,6 +326,7 @@ int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, f
  *   C,D,H,W: the appearance volume (96,16,64,64 in the reference, model.py:1157).  torch.linspace(-1,1,n) tables for
  *          n = 16 and 64 and F.affine_grid's 64^3 base grid are built in (bit patterns captured from the reference's CPU
  *          path); for other sizes hand the device tables in with mphip_hot_slice_plan_set_tables before the first forward.
+ *   (plan sizes are cached per batch size and precision.)
  *   refresh: after an in-place weight update call it with (NULL, NULL, 0) — every pack is rebuilt on the next forward's
  *          stream; after the parameters moved (new storage) pass the new name/pointer lists.
  *   forward: vs [B,96,D,H,W], es/zs/zd [B,512], Rs/Rd [B,3] Euler degrees, ts/td [B,3] -> out [B,96,H,W]; any B (more than
@@ -341,6 +342,9 @@ int mphip_hot_slice_plan_create(const char *const *names, const void *const *ten
                                 int flags, mphip_hot_slice_plan **out);
 int mphip_hot_slice_plan_set_tables(mphip_hot_slice_plan *plan, const float *lin_d, const float *lin_h, const float *lin_w,
                                     const float *affine_base);
+/* conv arithmetic of the plan's launches: 1 (default) = "auto", f16x3 wherever mphip_conv3d_supported(..., 1), exact fp32 elsewhere;
+ * 0 = exact fp32 MFMA everywhere.  Changes the workspace size: query mphip_hot_slice_workspace_bytes again. */
+int mphip_hot_slice_plan_set_precision(mphip_hot_slice_plan *plan, int precision);
 int mphip_hot_slice_plan_refresh(mphip_hot_slice_plan *plan, const char *const *names, const void *const *tensors, int n_tensors);
 size_t mphip_hot_slice_workspace_bytes(mphip_hot_slice_plan *plan, int B);
 int mphip_hot_slice_forward(mphip_hot_slice_plan *plan, const float *vs, const float *es, const float *Rs, const float *ts,

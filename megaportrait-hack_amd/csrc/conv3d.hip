@@ -48,6 +48,7 @@ __global__ void __launch_bounds__(256)
 conv3d_gather_kernel(const float *__restrict__ x, const float *__restrict__ wp, const float *__restrict__ bias,
                      float *__restrict__ y, int N, int Ci, int CiP, int Co, int CoP, int D, int H, int W,
                      int ci_per_split, unsigned x_bytes) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     constexpr int TAPS = KS * KS * KS;
     constexpr int WVOX = 4 / WCO;
     const int lane = threadIdx.x & 63;
@@ -372,6 +373,7 @@ conv3d_k3_tiled_kernel(const float *__restrict__ x, const float *__restrict__ wp
 __global__ void __launch_bounds__(256)
 splitk_reduce_kernel(const float *__restrict__ partial, const float *__restrict__ bias, float *__restrict__ y,
                      size_t n_out, int Co, int DHW, int splits) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_out) return;
     float s = sum_slabs(partial, splits, n_out, i);
@@ -397,8 +399,11 @@ static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
     p.NT = (M >= 64 * 64 && k == 3) ? 2 : 1;  // k=1: short K loop, favour more (lighter) waves: 2 per SIMD
     const long vox_tiles = (M + p.NT * 32 - 1) / (p.NT * 32);
     // Largest split-K factor the channel range allows (>= 8 channels per slice, power of two, <= 32).
+    static const long target = getenv("MPHIP_GATHER_TARGET_WAVES") ? atol(getenv("MPHIP_GATHER_TARGET_WAVES")) : 1024;   // dev: sweep
+    static const int min_ch = getenv("MPHIP_GATHER_MIN_CH") ? atoi(getenv("MPHIP_GATHER_MIN_CH")) : 8;
+    static const int split_cap = getenv("MPHIP_GATHER_MAX_SPLITS") ? atoi(getenv("MPHIP_GATHER_MAX_SPLITS")) : 32;
     int max_splits = 1;
-    while (max_splits < 32 && p.CiP / (max_splits * 2) >= 8 && p.CiP % (max_splits * 4) == 0) max_splits *= 2;
+    while (max_splits < split_cap && p.CiP / (max_splits * 2) >= min_ch && p.CiP % (max_splits * 4) == 0) max_splits *= 2;
     // Rows of 32 output channels per wave: as many as possible (operand reuse) while the launch still
     // offers ~one wave per SIMD (1024); small volumes trade reuse for parallelism (MT -> 1, more slices),
     // because there a wave's serial MFMA chain, not bandwidth, is the critical path.
@@ -407,7 +412,7 @@ static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
     for (int ci = 0; ci < 4; ++ci) {
         const int mt = cands[ci];
         if (co_tiles32 % mt) continue;
-        if ((long)(co_tiles32 / mt) * vox_tiles * max_splits >= 1024 || mt == 1) {
+        if ((long)(co_tiles32 / mt) * vox_tiles * max_splits >= target || mt == 1) {
             p.MT = mt;
             break;
         }
@@ -421,7 +426,7 @@ static ConvPlan plan_conv(int N, int Ci, int Co, int D, int H, int W, int k) {
     p.grid.x = (unsigned)((vox_tiles + wvox - 1) / wvox);
     p.grid.y = (unsigned)((co_wave_tiles + p.WCO - 1) / p.WCO);
     int splits = 1;
-    while ((long)co_wave_tiles * vox_tiles * splits < 1024 && splits < max_splits) splits *= 2;
+    while ((long)co_wave_tiles * vox_tiles * splits < target && splits < max_splits) splits *= 2;
     p.splits = splits;
     p.ci_per_split = p.CiP / splits;
     p.grid.z = splits;

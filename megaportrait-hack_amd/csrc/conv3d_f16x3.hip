@@ -448,6 +448,10 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
                     F16X3_LD_BL(tg)
                     if (tg + 1 < gt) { F16X3_LD_BH(cur ^ 1, tg + 1) }
                     __builtin_amdgcn_sched_barrier(0);  // the loads above stay above this tap's MFMAs
+#ifdef MPHIP_ABL_TAPS18  /* dev (timing only, wrong results): every third tap's MFMAs and fragment reads dropped = the matrix work of a
+                            1-D F(2,3) Winograd transform with TODAY's staging and weight stream (an optimistic bound) */
+                    if ((g * GT + tg) % 3 == 2) continue;
+#endif
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -528,9 +532,17 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 #ifndef MPHIP_ABL_NOX
         if (more) {
             F16X3_WRITE_X(c + 1);  // every wave is past its last read of the X tile (barrier above)
+#ifdef MPHIP_ABL_X2  /* dev (timing only): the staging VALU + LDS-write work done twice (what a transformed-domain input tile costs) */
+            asm volatile("" : "+v"(tz)::"memory");
+            F16X3_WRITE_X(c + 1);
+#endif
             __syncthreads();
         } else if (has_next) {
             F16X3_WRITE_X(c_begin);  // the next tile's first halo chunk; its barrier doubles as the next tile's "prologue done"
+#ifdef MPHIP_ABL_X2
+            asm volatile("" : "+v"(tz)::"memory");
+            F16X3_WRITE_X(c_begin);
+#endif
             __syncthreads();
         }
 #endif

@@ -41,6 +41,16 @@ __device__ __forceinline__ unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 
+// Latency-bound helper kernels (the FlowField chain: small gather convs, one-launch GroupNorms, the dense heads, the field
+// compose) raise their wave priority.  When they share CUs with the persistent MFMA workgroups of G3d — the C2D generator on the
+// side stream, or a second batch in flight — the issue arbiter otherwise serves the older conv waves first ("priority, then
+// age", MI355X_MICROARCH.md) and a 10 us kernel stretches 10-20x.  -DMPHIP_NO_PRIO: same-box A/B builds.
+#ifdef MPHIP_NO_PRIO
+#define MPHIP_LATENCY_KERNEL_PRIO()
+#else
+#define MPHIP_LATENCY_KERNEL_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 // zero fill as a KERNEL (float4 stores; n_bytes % 16 == 0, 16-B aligned).  Used instead of hipMemsetAsync: the memset
 // nodes of a captured hipGraph were not reliably ordered with the kernels around them on ROCm 7.2 (a replayed
 // training step went wrong in ~40 % of runs until the two memsets on this path became kernels).

@@ -2,6 +2,8 @@
 // Reference call sites: nn.GroupNorm model.py:506,508,460,309; AdaptiveGroupNorm 314-316;
 // ReLU/residual 517-523, 390-403; AvgPool3d 576-580; nn.Upsample 427-433, 585-589;
 // (z+e)@Gamma 945-957; 1x1 Conv2d 446; relu+tanh 462-465.
+#include <stdlib.h>
+
 #include "mphip_common.h"
 #include "mphip_conv.h"
 #include "mphip_resample.h"
@@ -265,6 +267,7 @@ __device__ __forceinline__ float split_value(const float *__restrict__ x, int sp
 }
 
 __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, size_t total) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     const GnParams &p = q.p;
     unsigned mbits = 0;
     for (size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (size_t)gridDim.x * blockDim.x) {
@@ -315,9 +318,14 @@ __global__ void __launch_bounds__(256) gn_apply_split_kernel(GnSplitParams q, si
 // writes every nearest-upsampled copy.  Same arithmetic as gn_stats_split_kernel + gn_apply_split_kernel.
 constexpr int GN_FUSED_MAX = 12288;  // floats of LDS cache (48 KB)
 __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, float eps, float *__restrict__ stats_out) {
-    __shared__ float vals[GN_FUSED_MAX];
-    __shared__ double red[32];
-    __shared__ float mr[2];
+    MPHIP_LATENCY_KERNEL_PRIO();
+    // LDS sized to the span at launch (dynamic): [red: 32 doubles][mr: 2 floats + pad][vals: cnt floats].  A fixed 48 KB cache kept
+    // these workgroups from becoming resident beside G3d's persistent conv workgroups (112 KB of the CU's 160 KB), so the C2D
+    // generator on the side stream waited for a conv launch to END before each of its GroupNorms could start.
+    extern __shared__ __attribute__((aligned(16))) unsigned char gn_dyn_[];
+    double *red = reinterpret_cast<double *>(gn_dyn_);
+    float *mr = reinterpret_cast<float *>(gn_dyn_ + 256);
+    float *vals = reinterpret_cast<float *>(gn_dyn_ + 272);
     const int nthr = blockDim.x, nwaves = blockDim.x >> 6;  // 256 threads, or 1024 when only a few groups exist
     const GnParams &p = q.p;
     const int grp = blockIdx.x;
@@ -557,6 +565,7 @@ template <bool TRANS>
 __global__ void __launch_bounds__(256)
 add_matmul_kernel(const float *__restrict__ a, const float *__restrict__ a2, const float *__restrict__ m,
                   const float *__restrict__ bias, float *__restrict__ out, int B, int K, int N) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     constexpr int BMAX = 8;
     const int lane = threadIdx.x & 63;
     const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -586,16 +595,20 @@ add_matmul_kernel(const float *__restrict__ a, const float *__restrict__ a2, con
     }
 }
 
-// trans=0 fast path ([K][N] matrix, N contiguous): a workgroup of 16 waves owns 64 output columns (one per
-// lane, coalesced 256-byte row reads); each wave covers K/16 rows with the (a+a2) rows broadcast from LDS,
-// and the 16 partial sums per output are combined through LDS in wave order (deterministic).
-constexpr int MM_WAVES = 16, MM_BMAX = 8, MM_KMAX = 1024;
+// trans=0 fast path ([K][N] matrix, N contiguous): a workgroup of 8 waves owns 16 output columns; a wave-iteration reads four
+// 64-byte row segments (lane = 16*r + col), so K = 512 is 16 iterations per wave and N = 2048 gives 128 workgroups (the 64-column
+// version ran the generators' 4 MB head product on 32 workgroups: 35 us, 0.12 TB/s).  The (a+a2) rows are broadcast from LDS; the
+// 4 x 8 partial sums per output are combined by two shuffles and an LDS pass in wave order (deterministic).
+// (8 waves, 16 KB + 4 KB of LDS: also resident beside a 112 KB conv workgroup — see gn_small_fused_kernel)
+constexpr int MM_WAVES = 8, MM_BMAX = 8, MM_KMAX = 512, MM_COLS = 16;
 __global__ void __launch_bounds__(MM_WAVES * 64)
 add_matmul_kn_kernel(const float *__restrict__ a, const float *__restrict__ a2, const float *__restrict__ m,
                      const float *__restrict__ bias, float *__restrict__ out, int B, int K, int N, int b0) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     __shared__ float as[MM_BMAX * MM_KMAX];
-    __shared__ float part[MM_WAVES][MM_BMAX][64];
+    __shared__ float part[MM_WAVES][MM_BMAX][MM_COLS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & (MM_COLS - 1), r = lane / MM_COLS;   // 4 rows per wave-iteration
     const int nb = min(MM_BMAX, B - b0);
     for (int i = threadIdx.x; i < nb * K; i += MM_WAVES * 64) {
         const int bb = i / K, k = i - bb * K;
@@ -604,26 +617,30 @@ add_matmul_kn_kernel(const float *__restrict__ a, const float *__restrict__ a2, 
         as[bb * MM_KMAX + k] = v;
     }
     __syncthreads();
-    const int n = blockIdx.x * 64 + lane;
-    const int kper = (K + MM_WAVES - 1) / MM_WAVES;
-    const int k0 = wave * kper, k1 = min(K, k0 + kper);
+    const int n = blockIdx.x * MM_COLS + col;
     float acc[MM_BMAX];
 #pragma unroll
     for (int i = 0; i < MM_BMAX; ++i) acc[i] = 0.0f;
     if (n < N) {
-#pragma unroll 8
-        for (int k = k0; k < k1; ++k) {
+        constexpr int RPI = MM_WAVES * (64 / MM_COLS);   // rows per workgroup-iteration
+#pragma unroll 4
+        for (int k = wave * (64 / MM_COLS) + r; k < K; k += RPI) {
             const float mv = m[(size_t)k * N + n];
 #pragma unroll
             for (int i = 0; i < MM_BMAX; ++i) acc[i] = fmaf(as[i * MM_KMAX + k], mv, acc[i]);
         }
     }
 #pragma unroll
-    for (int i = 0; i < MM_BMAX; ++i) part[wave][i][lane] = acc[i];
+    for (int i = 0; i < MM_BMAX; ++i) {
+        float v = acc[i];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if (r == 0) part[wave][i][col] = v;
+    }
     __syncthreads();
-    for (int o = threadIdx.x; o < nb * 64; o += MM_WAVES * 64) {
-        const int bb = o >> 6, l = o & 63;
-        const int nn = blockIdx.x * 64 + l;
+    for (int o = threadIdx.x; o < nb * MM_COLS; o += MM_WAVES * 64) {
+        const int bb = o / MM_COLS, l = o % MM_COLS;
+        const int nn = blockIdx.x * MM_COLS + l;
         if (nn >= N) continue;
         float v = 0.0f;
 #pragma unroll
@@ -635,6 +652,7 @@ add_matmul_kn_kernel(const float *__restrict__ a, const float *__restrict__ a2, 
 // K0: theta[b] = rows 0..2 of A = [R|t; 0 0 0 1], optionally inverted (Gauss-Jordan, partial pivoting).
 __global__ void rt_theta_kernel(const float *__restrict__ rot, const float *__restrict__ tr, float *__restrict__ theta,
                                 int B, int invert) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float k = 0.017453292519943295f;  // torch.pi / 180.0 as fp32 (model.py:823)
@@ -846,7 +864,8 @@ extern "C" int mphip_groupnorm_small_fused(const float *x, int x_splits, const f
     GnSplitParams q{{x, nullptr, gamma, beta, w2, b2, residual, y, C, C / G, relu, tanh_}, x_splits, res_splits,
                     (size_t)N * C * D * H * W, x_bias, res_bias, D, H, W, 0, uD, uH, uW};
     const int threads = (N * G < 64 && (size_t)(C / G) * D * H * W >= 4096) ? 1024 : 256;
-    hipLaunchKernelGGL(gn_small_fused_kernel, dim3(N * G), dim3(threads), 0, (hipStream_t)stream, q, eps, stats_out);
+    const size_t lds = 272 + (size_t)(C / G) * D * H * W * sizeof(float);
+    hipLaunchKernelGGL(gn_small_fused_kernel, dim3(N * G), dim3(threads), lds, (hipStream_t)stream, q, eps, stats_out);
     return check_launch("groupnorm_small_fused");
 }
 
@@ -868,6 +887,8 @@ extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D
         const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
         const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
         const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
+        // (an LDS-staged variant of this kernel — 7 coalesced staging loads per thread instead of 36 scalar ones — measured
+        //  +-0 on the 201 MB upsample, r03: the kernel is bound by its write stream, not by load issue)
         hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 16, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D,
                            H, W, sD, sH, sW, total / 16);
     } else {
@@ -906,7 +927,7 @@ extern "C" int mphip_add_matmul(const float *a, const float *a2, const float *m,
         hipLaunchKernelGGL(add_matmul_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, a2, m, bias, out, B, K, N);
     } else if (K <= MM_KMAX) {
         for (int b0 = 0; b0 < B; b0 += MM_BMAX)
-            hipLaunchKernelGGL(add_matmul_kn_kernel, dim3(cdiv(N, 64)), dim3(MM_WAVES * 64), 0, (hipStream_t)stream, a, a2, m,
+            hipLaunchKernelGGL(add_matmul_kn_kernel, dim3(cdiv(N, MM_COLS)), dim3(MM_WAVES * 64), 0, (hipStream_t)stream, a, a2, m,
                                bias, out, B, K, N, b0);
     } else {
         hipLaunchKernelGGL(add_matmul_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, a2, m, bias, out, B, K, N);

@@ -104,6 +104,7 @@ struct ResBlock { ConvW conv1, conv2, shortcut; bool identity = false; Norm gn1,
 struct FlowFieldW {
     const float *w1x1 = nullptr, *b1x1 = nullptr;   // conv1x1 [2048,512,1,1]
     float *w1x1_kn = nullptr;                          // [512][2048] (owned)
+    float *w_head = nullptr;                           // Gamma @ W^T [512][2048] (owned): (z+e)@Gamma and the 1x1 conv as ONE product
     bool kn_fresh = false;
     ResBlockAda rb[4];
     ConvW conv_out;
@@ -125,6 +126,7 @@ struct mphip_hot_slice_plan {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;
+    int precision = 1;   // 1 = auto (f16x3 where supported), 0 = exact fp32 everywhere (ops.set_conv_precision)
     Arena main_arena, side_arena;
     std::unordered_map<int, std::pair<size_t, size_t>> slice_sizes;   // B -> (main, side) arena peaks of the dry pass
     std::vector<void *> owned;   // hipMalloc'ed by the plan
@@ -188,7 +190,9 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
         if (bx + i < cols && by + tx < rows) out[(size_t)(bx + i) * rows + by + tx] = tile[tx][i];
 }
 
+int g_precision_mode = 1;   // set per forward from the plan (host-side, single-threaded per call)
 int precision_for(int n, int ci, int co, int d, int h, int w, int k) {
+    if (g_precision_mode == 0) return 0;                                // exact fp32 MFMA everywhere
     return mphip_conv3d_supported(n, ci, co, d, h, w, k, 1) ? 1 : 0;   // "auto": f16x3 wherever the kernel covers the shape
 }
 
@@ -321,7 +325,7 @@ T5 groupnorm_small(Ctx &c, ConvOut &x, const Norm &nm, int groups, const ConvOut
 }
 
 bool gn_in_conv_ok(const ConvOut &y, const ConvW &pc2) {
-    if (pc2.k != 3 || pc2.ci > 768) return false;
+    if (g_precision_mode != 1 || pc2.k != 3 || pc2.ci > 768) return false;
     return mphip_conv3d_supported(y.t.n, pc2.ci, pc2.co, y.t.d, y.t.h, y.t.w, pc2.k, 1) != 0;
 }
 
@@ -390,16 +394,18 @@ T5 resblock_ada(Ctx &c, ResBlockAda &b, T5 &x, int ud, int uh, int uw) {
     return out;
 }
 
-// FlowField.forward (model.py:415-471) on s [B,512] -> em [B,3,16,16,16]
-T5 flowfield(Ctx &c, FlowFieldW &ff, const float *s, int B) {
+// FlowField.forward_from_codes (model.py:945-957 + 415-471): (z, e) [B,512] -> em [B,3,16,16,16]
+T5 flowfield(Ctx &c, FlowFieldW &ff, const float *gamma, const float *z, const float *e, int B) {
     static const int UPS[4][3] = {{2, 2, 2}, {2, 2, 2}, {1, 2, 2}, {1, 2, 2}};
-    if (!c.dry && !ff.kn_fresh) {   // conv1x1.weight [2048][512] -> [K=512][N=2048] for the coalesced matmul kernel
+    if (!c.dry && !ff.kn_fresh) {
+        // conv1x1.weight [2048][512] -> [K=512][N=2048], then Gamma @ that: (z+e)@Gamma followed by the 1x1 conv is one linear map
         hipLaunchKernelGGL(transpose_kernel, dim3(512 / 32, 2048 / 32), dim3(256), 0, c.s, ff.w1x1, ff.w1x1_kn, 2048, 512);
         if (c.rc == MPHIP_OK) c.rc = check_launch("hot_slice(transpose conv1x1)");
+        RUN(c, mphip_small_gemm(gamma, nullptr, ff.w1x1_kn, nullptr, ff.w_head, 512, 2048, 512, 512, 1, 2048, 1, c.s));
         ff.kn_fresh = true;
     }
     T5 x = new_t5(c, B, 512, 4, 1, 1, false);   // [B,2048] viewed as [B,512,4,1,1] (model.py:425)
-    RUN(c, mphip_add_matmul(s, nullptr, ff.w1x1_kn, ff.b1x1, x.data.p, B, 512, 2048, 0, c.s));
+    RUN(c, mphip_add_matmul(z, e, ff.w_head, ff.b1x1, x.data.p, B, 512, 2048, 0, c.s));
     for (int i = 0; i < 4; ++i) x = resblock_ada(c, ff.rb[i], x, UPS[i][0], UPS[i][1], UPS[i][2]);
     ConvOut y = conv3d_split(c, x, ff.conv_out, 0);
     give(c, x);
@@ -416,10 +422,7 @@ T5 flowfield(Ctx &c, FlowFieldW &ff, const float *s, int B) {
 
 // _WarpGenerator.forward (model.py:927-1024) -> warp field [B,3,G,G,G]
 T5 warp_generator(Ctx &c, Generator &g, const float *R, const float *t, const float *z, const float *e, int B) {
-    Buf s = take(c, (size_t)B * 512 * sizeof(float));
-    RUN(c, mphip_add_matmul(z, e, g.gamma, nullptr, s.p, B, 512, 512, 0, c.s));   // (z+e) @ Gamma, model.py:945-957
-    T5 em = flowfield(c, g.ff, s.p, B);
-    give(c, s);
+    T5 em = flowfield(c, g.ff, g.gamma, z, e, B);
     Buf theta = take(c, (size_t)B * 12 * sizeof(float));
     RUN(c, mphip_rt_theta(R, t, theta.p, B, g.invert, c.s));
     const int G = c.p->G;
@@ -504,6 +507,7 @@ T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook) {
 int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const float *ts, const float *zs, const float *Rd, const float *td,
               const float *zd, float *out, int B, void *workspace, size_t workspace_bytes, hipStream_t s, bool dry, size_t *need) {
     const bool overlap = p->overlap && !dry;
+    g_precision_mode = p->precision;
     // the side stream's arena sits behind the main one: sizes from the dry pass
     size_t side_bytes = 0, main_bytes = 0;
     if (!dry) {
@@ -565,6 +569,7 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
 
 int run_g3d(Plan *p, const float *x, const float *x_range, bool have_range, float *y, int B, void *workspace, size_t workspace_bytes, hipStream_t s,
             bool dry) {
+    g_precision_mode = p->precision;
     if (!dry) {
         run_g3d(p, nullptr, nullptr, have_range, nullptr, B, nullptr, 0, nullptr, true);
         if (workspace_bytes < p->main_arena.peak || !workspace) {
@@ -696,6 +701,9 @@ extern "C" int mphip_hot_slice_plan_create(const char *const *names, const void 
             if (hipMalloc(&q, (size_t)512 * 2048 * 4) != hipSuccess) { set_error("hot_slice_plan_create: hipMalloc failed"); rc = MPHIP_ELAUNCH; break; }
             p->owned.push_back(q);
             g->ff.w1x1_kn = (float *)q;
+            if (hipMalloc(&q, (size_t)512 * 2048 * 4) != hipSuccess) { set_error("hot_slice_plan_create: hipMalloc failed"); rc = MPHIP_ELAUNCH; break; }
+            p->owned.push_back(q);
+            g->ff.w_head = (float *)q;
         }
     }
     if (rc == MPHIP_OK) {   // built-in tables for the captured sizes; other sizes: mphip_hot_slice_plan_set_tables
@@ -727,6 +735,16 @@ extern "C" int mphip_hot_slice_plan_set_tables(mphip_hot_slice_plan *p, const fl
     if (lin_h) p->lin_h = const_cast<float *>(lin_h);
     if (lin_w) p->lin_w = const_cast<float *>(lin_w);
     if (affine_base) p->aff_base = const_cast<float *>(affine_base);
+    return MPHIP_OK;
+}
+
+extern "C" int mphip_hot_slice_plan_set_precision(mphip_hot_slice_plan *p, int precision) {
+    MPHIP_REQUIRE(p, "hot_slice_plan_set_precision: null plan");
+    MPHIP_REQUIRE(precision == 0 || precision == 1, "hot_slice_plan_set_precision: 0 (exact fp32) or 1 (auto: f16x3 where supported), got %d", precision);
+    if (p->precision != precision) {
+        p->precision = precision;
+        p->slice_sizes.clear();   // the workspace carve-up depends on the kernels chosen
+    }
     return MPHIP_OK;
 }
 

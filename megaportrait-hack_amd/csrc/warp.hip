@@ -14,6 +14,7 @@ __global__ void __launch_bounds__(256)
 warp_field_compose_kernel(const float *__restrict__ theta, const float *__restrict__ em,
                           const float *__restrict__ base, float *__restrict__ wout, float *__restrict__ rt_out,
                           float *__restrict__ em_out, int B, int eD, int eH, int eW, int G) {
+    MPHIP_LATENCY_KERNEL_PRIO();
     const size_t vol = (size_t)G * G * G;
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (size_t)B * vol) return;

@@ -196,6 +196,25 @@ class FlowField(nn.Module):
             self.__dict__["_w_kn"] = hit
         return hit[1]
 
+    def _head_kn(self, gamma):
+        """(z+e) @ Gamma followed by the 1x1 conv on the 1x1 map (model.py:945-957 -> 446) is one linear map of (z+e):
+        Gamma @ W^T, [512][2048], built once per weight version — one dense product per step instead of two dependent ones
+        at the head of the latency-bound generator chain."""
+        w = self.conv1x1.weight
+        key = (w.data_ptr(), w._version, gamma.data_ptr(), gamma._version, str(w.device), ops.weight_epoch())
+        hit = self.__dict__.get("_w_head")
+        if hit is None or hit[0] != key or ops.repacking():
+            hit = (key, ops.small_gemm(gamma.detach(), self._conv1x1_kn()))
+            self.__dict__["_w_head"] = hit
+        return hit[1]
+
+    def forward_from_codes(self, z, e, gamma):
+        """Inference entry used by the warp generators: FlowField((z+e) @ Gamma) with the two dense products merged."""
+        z, e = _f32(z, e)
+        b = z.shape[0]
+        x = ops.add_matmul(z.reshape(b, 512), e.reshape(b, 512), self._head_kn(gamma), self.conv1x1.bias)
+        return self._tail(x.view(b, 512, 4, 1, 1), False)
+
     def forward(self, zs, adaptive_gamma=0, adaptive_beta=0):  # last two ignored, as in the reference
         zs = _f32(zs)
         train = ag.needs_grad(self, zs)
@@ -205,7 +224,9 @@ class FlowField(nn.Module):
             x = ag.Conv1x1OnVectorFn.apply(s, self.conv1x1.weight, self.conv1x1.bias, self._conv1x1_kn())
         else:
             x = ops.add_matmul(s, None, self._conv1x1_kn(), self.conv1x1.bias)  # 1x1 conv on a 1x1 map == s @ W^T + b
-        x = x.view(b, 512, 4, 1, 1)  # model.py:425: channel c*4+d -> (c,d)
+        return self._tail(x.view(b, 512, 4, 1, 1), train)  # model.py:425: channel c*4+d -> (c,d)
+
+    def _tail(self, x, train):
         for blk, up in zip((self.resblock1, self.resblock2, self.resblock3, self.resblock4), self._UPS):
             x = blk(x, _up=up)  # nn.Upsample (nearest, model.py:450-457) fused into the block's last pass
         if train:
@@ -245,8 +266,7 @@ class _WarpGenerator(nn.Module):
             em = self.flowfield(s.unsqueeze(-1).unsqueeze(-1), 0, 0)
             theta = ag.RtThetaFn.apply(R, t, self._INVERT)
             return ag.WarpFieldComposeFn.apply(theta, em, 64)
-        s = ops.add_matmul(z, e, self.adaptive_matrix_gamma)  # (z+e) @ Gamma, model.py:945-957
-        em = self.flowfield(s.unsqueeze(-1).unsqueeze(-1), 0, 0)
+        em = self.flowfield.forward_from_codes(z, e, self.adaptive_matrix_gamma)  # FlowField((z+e) @ Gamma), model.py:945-957
         theta = ops.rt_theta(R, t, self._INVERT)
         return ops.warp_field_compose(theta, em, 64)
 
@@ -460,6 +480,7 @@ class _HotSliceRunner:
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
         if (self.use_c_plan and vs.shape[0] > 0 and vs.dim() == 5 and vs.shape[1] == 96 and ops._conv_hook is None
+                and ops._GNIN_ENABLED and ops._GN_SMALL_ENABLED and ops._RANGES_ENABLED   # (dev A/B switches act on the per-op path)
                 and not ag.needs_grad(self, vs, es, Rs, ts, zs, Rd, td, zd)
                 and all(v % 8 == 0 for v in vs.shape[2:])):
             if check_shape:

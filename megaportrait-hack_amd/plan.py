@@ -72,9 +72,16 @@ class HotSlicePlan:
     def _weights_key(tensors):
         return (ops.weight_epoch(),) + tuple((t.data_ptr(), t._version) for t in tensors.values())
 
+    def _sync_precision(self):
+        prec = ops.get_conv_precision()   # ops.set_conv_precision / MPHIP_CONV_PRECISION apply to the plan's launches too
+        if prec != getattr(self, "_prec", 1):
+            _lib.check(self.lib.mphip_hot_slice_plan_set_precision(self._handle, prec), "mphip_hot_slice_plan_set_precision")
+            self._prec = prec
+
     def _sync_weights(self):
         """Re-pack (on the forward's stream) when a parameter changed: in-place update, load_state_dict, .to(), or
         ops.invalidate_packs() — the same conditions under which model._PackCache rebuilds its packs."""
+        self._sync_precision()
         tensors = _hot_tensors(self.module, self.g3d_only)
         key = self._weights_key(tensors)
         if key != self._key or ops.repacking():

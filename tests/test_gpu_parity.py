@@ -590,6 +590,20 @@ def test_hot_slice_full_golden(dev, hot):
     assert err < 1e-3
 
 
+def test_hot_slice_full_size_batch8_vs_oracle(dev, hot):
+    """the GRADED batch (B=8 frames of 96x16x64x64) against the CPU oracle DIRECTLY, all eight frames — not
+    through properties.  (~7 s of ATen-CPU work on the GPU box's host cores.)"""
+    B = 8
+    inp = R.seeded_hot_inputs(B, 23)
+    with torch.no_grad():
+        got = hot(**{k: v.to(dev) for k, v in inp.items()}).cpu()
+        want = R.hot_slice(sd=R.seeded_gbase_hot_state_dict(WEIGHT_SEED), **inp)
+    assert got.shape == want.shape == (B, 96, 64, 64)
+    per_frame = (got - want).abs().flatten(1).max(dim=1).values
+    print(f"B=8 full size vs the CPU oracle: per-frame max-abs {[f'{v:.2e}' for v in per_frame.tolist()]} (|ref|max {want.abs().max():.2f})")
+    assert per_frame.max().item() < 1e-3
+
+
 def test_full_size_properties(ops, M, dev, hot):
     """Size-independent properties at BASELINE batch size (B=8, 96x16x64x64)."""
     B = 8
@@ -835,3 +849,21 @@ def test_c_abi_from_plain_c(c_abi_exe):
     r = subprocess.run([c_abi_exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "C ABI OK" in r.stdout
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs >= 2 GPUs on the node (the gpurun boxes have one)")
+def test_bench_two_ranks_over_rccl():
+    """`bench.py --gpus 2` end to end over RCCL (self-launch, one rank per GPU, barrier + MAX over ranks):
+    runs wherever a node has two GPUs; the 1-GPU boxes of this pool skip it (the launch path itself is covered on the
+    CPU with gloo: tests/test_host.py::test_bench_self_launches_ranks)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 16 and line["value"] > 0

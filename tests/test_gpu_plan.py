@@ -69,6 +69,28 @@ def test_plan_is_the_default_inference_path(dev, M):
     assert torch.equal(a, b)
 
 
+def test_plan_honours_the_conv_precision_switch(dev, M):
+    """ops.set_conv_precision('fp32') (bench.py's `fp32_exact` leg, MPHIP_CONV_PRECISION) must reach the plan's launches."""
+    from megaportrait_hack_amd import ops
+
+    hot = _hot(M, dev)
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 11, D=16, H=32, W=32).items()}
+    old = ops.get_conv_precision()
+    try:
+        with torch.no_grad():
+            fast = hot.forward_any_size(**inp)
+            ops.set_conv_precision("fp32")
+            exact = hot.forward_any_size(**inp)
+            want = hot._run_python(check_shape=False, **inp)
+            ops.set_conv_precision("auto")
+            fast2 = hot.forward_any_size(**inp)
+    finally:
+        ops.set_conv_precision(old)
+    assert torch.equal(exact, want) and torch.equal(fast, fast2)
+    assert not torch.equal(exact, fast)          # different arithmetic (f16x3 vs exact fp32), same answer to fp32 class
+    assert (exact - fast).abs().max().item() < 1e-4
+
+
 def test_plan_follows_weight_updates(dev, M):
     from megaportrait_hack_amd import plan as P
 
