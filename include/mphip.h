@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 3
+#define MPHIP_ABI_VERSION 4
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -310,6 +310,32 @@ int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *
 int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
                        int invert, void *stream);
 
+/* ------------------------------------------------------------------ demand-driven evaluation of a gather's producer
+ * G3d's last conv feeds apply_warping_field + torch.sum(dim=2) (model.py:1160 -> 1167-1171): a gather whose sample positions
+ * depend only on the C2D warp field, known long before the conv runs.  Only the voxels the gather reads need to exist:
+ *   mphip_warp_coords(field, ...) -> coords [B,D,H,W,3]                  (K3's coordinate pass, the bit-exact index chain)
+ *   mphip_warp_sample_box(coords) -> box [B][8] = {lx, ly, lz, ex, ey, ez, -, -}: per frame the box of source voxels the samples
+ *                                     touch (all 8 trilinear corners, zero-weight ones included)
+ *   mphip_upsample_trilinear2_roi / mphip_conv3d_fwd_roi: produce only the output tiles (of the conv kernel's own tiling,
+ *                                     mphip_conv3d_roi_granule) a box touches, and of the upsample only those tiles' halos; every
+ *                                     other voxel of y is LEFT UNTOUCHED (uninitialised memory).  roi_frames == 0: box b belongs to
+ *                                     frame b; roi_frames > 0: N == 1 volume serves that many boxes (1 source x many drivers).
+ *                                     Shapes / precisions without a tiled kernel (granule() == 0) compute everything.
+ *   mphip_warp_volume_dsum_coords(v, coords) = mphip_warp_volume_dsum with the coordinate pass already done.
+ * The values that are computed are bit-identical to the full evaluation; nothing else is ever read.  On the reference's
+ * fields (samples inside the ~5^3 low corner) the box covers 2 of the 256 tiles of a 16x64x64 frame; a field
+ * that travels through the volume makes the box the volume, i.e. the full conv.  The hot-slice plan uses this for final_conv. */
+int mphip_warp_sample_box(const float *coords, int *box, int B, int D, int H, int W, void *stream);
+int mphip_conv3d_roi_granule(int N, int Ci, int Co, int D, int H, int W, int k, int precision, int *tile_dhw);
+size_t mphip_conv3d_roi_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);   /* conv workspace + the tile list */
+int mphip_conv3d_fwd_roi(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, const int *roi,
+                         int roi_frames, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                         size_t workspace_bytes, void *stream);
+int mphip_upsample_trilinear2_roi(const float *x, float *y, const int *roi, int roi_frames, int N, int C, int D, int H, int W, int tD,
+                                  int tH, int tW, void *stream);
+int mphip_warp_volume_dsum_coords(const float *v, const float *coords, float *out, int B, int C, int D, int H, int W, int shared,
+                                  void *stream);
+
 /* ------------------------------------------------------------------ one-call entries: the hot slice and G3d as plans
  * Replace the single calls of the reference: Gbase.forward's slice (model.py:1151-1171: WarpGeneratorS2C ->
  * apply_warping_field -> G3d -> WarpGeneratorC2D -> apply_warping_field -> torch.sum(dim=2)) and G3d.forward
@@ -337,6 +363,7 @@ int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, f
 typedef struct mphip_hot_slice_plan mphip_hot_slice_plan;
 #define MPHIP_PLAN_G3D_ONLY 1
 #define MPHIP_PLAN_SINGLE_STREAM 2
+#define MPHIP_PLAN_FULL_FINAL_CONV 4   /* evaluate G3d's last upsample + conv everywhere (default: demand-driven, see above) */
 #define MPHIP_PLAN_MAX_FRAMES_PER_PASS 64   /* the conv kernels address their input through one 2 GiB buffer resource */
 int mphip_hot_slice_plan_create(const char *const *names, const void *const *tensors, int n_tensors, int C, int D, int H, int W,
                                 int flags, mphip_hot_slice_plan **out);

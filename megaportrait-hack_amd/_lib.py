@@ -77,6 +77,12 @@ SIGNATURES = {
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2_bwd_workspace_bytes": (_sz, [_i] * 4),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _sz, _p]),
+    "mphip_warp_sample_box": (_i, [_p, _p, _i, _i, _i, _i, _p]),
+    "mphip_conv3d_roi_granule": (_i, [_i] * 8 + [_p]),
+    "mphip_conv3d_roi_workspace_bytes": (_sz, [_i] * 8),
+    "mphip_conv3d_fwd_roi": (_i, [_p] * 6 + [_i] * 9 + [_p, _sz, _p]),
+    "mphip_upsample_trilinear2_roi": (_i, [_p, _p, _p] + [_i] * 9 + [_p]),
+    "mphip_warp_volume_dsum_coords": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "mphip_hot_slice_plan_create": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mphip_hot_slice_plan_set_tables": (_i, [_p, _p, _p, _p, _p]),
     "mphip_hot_slice_plan_refresh": (_i, [_p, _p, _p, _i]),

@@ -508,9 +508,13 @@ static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int
 
 constexpr size_t RANGE_BYTES = ((MPHIP_RANGE_FLOATS * sizeof(float) + 255) / 256) * 256;  // descriptor + padding: keeps what follows aligned
 
+static size_t conv_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision, bool roi);
 extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    return conv_ws_bytes(N, Ci, Co, D, H, W, k, precision, false);
+}
+static size_t conv_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision, bool roi) {
     if (!mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
-    int splits = precision == 1 ? (k == 1 ? 1 : f16x3_plan(N, Ci, Co, D, H, W).splits) : plan_conv(N, Ci, Co, D, H, W, k).splits;
+    int splits = precision == 1 ? (k == 1 ? 1 : f16x3_plan(N, Ci, Co, D, H, W, roi).splits) : plan_conv(N, Ci, Co, D, H, W, k).splits;
     // precision 1: room in front for the range descriptor the library computes itself when the caller passes none
     return (precision == 1 ? RANGE_BYTES : 0) + (splits > 1 ? (size_t)splits * N * Co * D * H * W * sizeof(float) : 0);
 }
@@ -559,7 +563,7 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
 
 static int conv3d_run(const float *x, const float *in_affine, int in_relu, const float *x_range, const void *w_packed, const float *bias, float *y,
                       float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
-                      size_t workspace_bytes, void *stream) {
+                      size_t workspace_bytes, void *stream, const int *roi = nullptr, int roi_frames = 0) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
     MPHIP_REQUIRE(k == 1 || k == 3, "conv3d_fwd: kernel size %d not supported (1 or 3)", k);
@@ -578,7 +582,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         MPHIP_REQUIRE(!in_affine, "conv3d_fwd: the fused input GroupNorm is for the 3x3x3 f16x3 kernel");
         splits = 1;   // the k=1 GEMM kernel (conv3d_f16x3.hip): no split-K
     } else if (precision == 1) {
-        fp = f16x3_plan(N, Ci, Co, D, H, W);
+        fp = f16x3_plan(N, Ci, Co, D, H, W, roi != nullptr);
         splits = fp.splits;
     } else {
         p = plan_conv(N, Ci, Co, D, H, W, k);
@@ -621,7 +625,16 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     if (precision == 1 && k == 1) {
         rc = f16x3_launch_k1(x, w_packed, bias, dst, N, Ci, Co, D * H * W, x_range, s);
     } else if (precision == 1) {
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s);
+        int *tile_list = nullptr;
+        if (roi) {   // the tile list lives at the END of the caller's workspace (mphip_conv3d_roi_workspace_bytes)
+            const size_t list_bytes = (((size_t)fp.grid.x + 1) * sizeof(int) + 255) / 256 * 256;
+            if (workspace_bytes < slab_bytes + gn_bytes + list_bytes) {
+                set_error("conv3d_fwd_roi: workspace too small for the tile list (query mphip_conv3d_roi_workspace_bytes)");
+                return MPHIP_EWORKSPACE;
+            }
+            tile_list = (int *)((char *)workspace + workspace_bytes - list_bytes);
+        }
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -653,6 +666,33 @@ extern "C" int mphip_conv3d_fwd(const float *x, const float *x_range, const void
                                 size_t workspace_bytes, void *stream) {
     return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
+}
+
+// Demand-driven conv (include/mphip.h): only the output tiles that intersect the consumer's sample boxes are computed.
+extern "C" int mphip_conv3d_roi_granule(int N, int Ci, int Co, int D, int H, int W, int k, int precision, int *tile_dhw) {
+    if (!tile_dhw || precision != 1 || k != 3 || !mphip_conv3d_supported(N, Ci, Co, D, H, W, k, 1)) return 0;
+    f16x3_tile_dims(f16x3_plan(N, Ci, Co, D, H, W, true), tile_dhw);
+    return 1;
+}
+
+extern "C" size_t mphip_conv3d_roi_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    int dims[3];
+    if (!mphip_conv3d_roi_granule(N, Ci, Co, D, H, W, k, precision, dims)) return mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, k, precision);
+    const size_t base = conv_ws_bytes(N, Ci, Co, D, H, W, k, precision, true);
+    const size_t tiles = (size_t)N * (D / dims[0]) * (H / dims[1]) * (W / dims[2]);
+    return (base + 255) / 256 * 256 + ((tiles + 1) * sizeof(int) + 255) / 256 * 256;
+}
+
+extern "C" int mphip_conv3d_fwd_roi(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, const int *roi,
+                                    int roi_frames, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                    size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(roi, "conv3d_fwd_roi: null box list (mphip_warp_sample_box makes it)");
+    MPHIP_REQUIRE(roi_frames >= 0 && (roi_frames == 0 || N == 1), "conv3d_fwd_roi: roi_frames > 0 (several boxes on one volume) needs N == 1");
+    int dims[3];
+    const bool tiled = mphip_conv3d_roi_granule(N, Ci, Co, D, H, W, k, precision, dims) != 0;
+    // (shapes / precisions without a tiled kernel compute every voxel: the result is a superset of what was asked for)
+    return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
+                      workspace_bytes, stream, tiled ? roi : nullptr, tiled ? roi_frames : 0);
 }
 
 extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {

@@ -181,10 +181,23 @@ __device__ __forceinline__ void
 conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                      const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                      int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                     const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware) {
+                     const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware,
+                     const int *__restrict__ roi, int roi_frames) {
     constexpr int MT = 3, KC = F16X3_KC;
     // operand scale of the input tensor: from its range descriptor (activations: max|x| noted by the producing kernel or
     // mphip_absmax_range; gradients: mphip_grad_prep) — per tensor, a power of two
+    // Demand-driven evaluation (tile_list != nullptr): only the listed output tiles are computed — G3d's final_conv feeds
+    // apply_warping_field + sum(dim=2) (model.py:1167-1171), a gather whose sample positions are known before the conv is
+    // launched; on the reference's fields they cover a ~5^3 corner of the 16x64x64 volume, i.e. 2 of this
+    // conv's 256 tiles per frame.  tile_list = {count, id, id, ...} (roi_tile_list_kernel below); the persistent workgroups
+    // deal the LISTED tiles round-robin, so sixteen needed tiles run on sixteen CUs (walking the full id range and skipping
+    // would leave them on the four workgroups whose stride-256 walks contain the low-corner tiles of every frame).
+    const int *const tile_list = roi;
+    const int ntiles = tile_list ? tile_list[0] : tiles_total;
+    auto tile_at = [&](int j) -> int { return tile_list ? tile_list[1 + j] : j; };
+    const int j_first = (tile_list || !xcd_aware) ? (int)blockIdx.x : (int)xcd_remap(blockIdx.x, gridDim.x);
+    if (j_first >= ntiles) return;   // (workgroup-uniform, before any barrier)
+    (void)roi_frames;
     float x_scale = X_SCALE, x_unscale = 1.0f / X_SCALE;
     if (x_scale_p) range_scale_block(x_scale_p, x_scale, x_unscale);  // (folds the producer's per-workgroup maxima; barriers inside)
     constexpr int TVOX = TD * TH * TW;
@@ -226,8 +239,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     };
     // XCD-aware start: workgroup ids go round-robin over the 8 XCDs, so consecutive ids get consecutive RANGES of tiles —
     // neighbouring tiles (which share halo rows) then run on the same XCD and meet in its L2
-    const int tile0 = xcd_aware ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-    decode_tile(tile0);
+    decode_tile(tile_at(j_first));
     const int cot = blockIdx.y;
     const int nchunks = Ci / KC;
     const int c_begin = blockIdx.z * chunks_per_split;
@@ -377,9 +389,9 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     __syncthreads();
     PROF_ADD(0)
     int wb = 0;
-  for (int tile_id = tile0; tile_id < tiles_total; tile_id += gridDim.x) {
+  for (int tj = j_first; tj < ntiles; tj += (int)gridDim.x) {
     const int en = n, ed0 = d0, eh0 = h0, ew0 = w0;  // this tile's coordinates (the staging variables move on to the next tile)
-    const bool has_next = tile_id + (int)gridDim.x < tiles_total;
+    const bool has_next = tj + (int)gridDim.x < ntiles;
     asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps per-tile-invariant index math / bias loads from being hoisted into registers
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -395,7 +407,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
         if (more) {
             F16X3_LOAD_X(c + 1);
         } else if (has_next) {
-            decode_tile(tile_id + (int)gridDim.x);  // staging now addresses the next tile (the epilogue uses en, ed0, ...)
+            decode_tile(tile_at(tj + (int)gridDim.x));  // staging now addresses the next tile (the epilogue uses en, ed0, ...)
             nbase = (long)n * Ci * DHW;
             // (the previous affine table was last read by the WRITE_X that ended the previous chunk, a barrier ago)
             if (fuse_in && n != aff_n) load_aff();
@@ -591,14 +603,42 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     PROF_FLUSH
 }
 
+// Demand-driven conv: the ids of the output tiles (TD x TH x TW voxels, id = ((n*tiles_d + td)*tiles_h + th)*tiles_w + tw) that
+// one of the sample boxes {lx,ly,lz,ex,ey,ez,-,-} touches -> list = {count, id, ...}.  roi_frames == 0: box n belongs to frame n;
+// > 0: the single frame serves that many boxes.  One workgroup; the order of the ids is irrelevant (tiles are independent).
+__global__ void __launch_bounds__(1024)
+roi_tile_list_kernel(const int *__restrict__ roi, int roi_frames, int tiles_total, int D, int H, int W, int TD, int TH, int TW,
+                     int *__restrict__ list) {
+    __shared__ int cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
+    const int tiles_w = W / TW, tiles_h = H / TH, tiles_d = D / TD;
+    for (int t = threadIdx.x; t < tiles_total; t += 1024) {
+        int bid = t;
+        const int w0 = (bid % tiles_w) * TW; bid /= tiles_w;
+        const int h0 = (bid % tiles_h) * TH; bid /= tiles_h;
+        const int d0 = (bid % tiles_d) * TD;
+        const int n = bid / tiles_d;
+        const int first = roi_frames > 0 ? 0 : n, count = roi_frames > 0 ? roi_frames : 1;
+        bool need = false;
+        for (int f = first; f < first + count && !need; ++f) {
+            const int *b = roi + f * 8;
+            need = w0 < b[0] + b[3] && w0 + TW > b[0] && h0 < b[1] + b[4] && h0 + TH > b[1] && d0 < b[2] + b[5] && d0 + TD > b[2];
+        }
+        if (need) list[1 + atomicAdd(&cnt, 1)] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) list[0] = cnt;
+}
+
 template <int TD, int TH, int TW, int NWAVES, int GS>
 __global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))  // 256 registers: two waves per SIMD
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware) {
+                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames) {
     conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
-                                                 in_relu, x_scale_p, tiles_total, xcd_aware);
+                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames);
 }
 
 // One wave per SIMD with up to 512 registers: a wave owns 96 output channels x 128 voxels (12 accumulator tiles), so every
@@ -609,9 +649,9 @@ __global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_e
 conv3d_k3_f16x3_wide_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                             const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                             int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                            const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware) {
+                            const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames) {
     conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
-                                                 in_relu, x_scale_p, tiles_total, xcd_aware);
+                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames);
 }
 
 // ---- k = 1: the 1x1x1 shortcut convs of G3d (model.py:510) on the same split-f16 arithmetic ---------------------------------
@@ -753,7 +793,7 @@ size_t f16x3_packed_bytes(int Co, int Ci) {
     return 16 + (size_t)(Co / F16X3_COT) * (Ci / F16X3_KC) * F16X3_NG * SLAB_HALFS * sizeof(_Float16);
 }
 
-F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
+F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     F16x3Plan p;
     p.td = D % 4 == 0 ? 4 : 2;
     // variant: 0 = (td,8,8) tile, 256 voxels per workgroup; 1 = (4,8,16) tile, 512 voxels per workgroup (halves the
@@ -774,6 +814,9 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     if (!force && p.td == 4 && tiles8 * cot >= v2min) p.variant = 2;
     if (force && force[0] == '2' && p.td == 4) p.variant = 2;
     if (force && force[0] == '3' && tiles1) p.variant = 3;   // the 512-voxel tile on FOUR wide waves (dev: same-box A/B)
+    // demand-driven launches compute a handful of tiles, one per CU: the time is ONE tile's latency, so the smallest tile wins
+    // (a ~5^3 box is 2 tiles either way: 4x8x8 halves the work per tile)
+    if (roi && p.td == 4 && !force) p.variant = 0;
     const long tiles = (p.variant == 1 || p.variant == 3) ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup: each split adds a slab write + a reduce pass
@@ -784,6 +827,12 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W) {
     p.chunks_per_split = (nchunks + sp - 1) / sp;
     p.grid = dim3((unsigned)tiles, Co / F16X3_COT, sp);
     return p;
+}
+
+void f16x3_tile_dims(const F16x3Plan &p, int dims[3]) {   // output tile (d,h,w) of the kernel variant f16x3_launch picks
+    dims[0] = (p.variant == 1 || p.variant == 2 || p.variant == 3) ? 4 : p.td;
+    dims[1] = 8;
+    dims[2] = (p.variant == 1 || p.variant == 3) ? 16 : 8;
 }
 
 int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed, const void *header_from, hipStream_t s) {
@@ -817,7 +866,8 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
 }
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s) {
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s, const int *roi,
+                 int roi_frames, int *tile_list) {
     if (in_affine && Ci > 768) {
         set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
         return MPHIP_EINVAL;
@@ -825,6 +875,13 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const float *hdr = (const float *)wpacked;
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
+    if (roi) {   // demand-driven: boxes -> the list of tiles they touch (1 + tiles ints of caller workspace); the kernel gets the LIST
+        int dims[3];
+        f16x3_tile_dims(p, dims);
+        hipLaunchKernelGGL(roi_tile_list_kernel, dim3(1), dim3(1024), 0, s, roi, roi_frames, (int)p.grid.x, D, H, W, dims[0], dims[1], dims[2],
+                           tile_list);
+        roi = tile_list;
+    }
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles
     const int tiles_total = (int)p.grid.x;
@@ -839,19 +896,19 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
     if (p.variant == 3)
         hipLaunchKernelGGL((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
     else if (p.variant == 2)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
     else if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
     else if (p.td == 4)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
     else
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
     return check_launch("conv3d_fwd(f16x3)");
 }
 

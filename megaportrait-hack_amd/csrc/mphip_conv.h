@@ -26,10 +26,14 @@ size_t f16x3_packed_bytes(int Co, int Ci);
 size_t f16x3_packed_bytes_k1(int Co, int Ci);
 int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci, int Co, int DHW,
                     const float *x_range, hipStream_t s);
-F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W);
+F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi = false);
 int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int k, int transposed, const void *header_from, hipStream_t s);
+// roi (optional): 8 ints per box {lx,ly,lz,ex,ey,ez,-,-}: only the output tiles a box touches are computed (roi_frames == 0: one box per
+// frame; > 0: the conv's frames... single frame serves that many boxes)
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
-                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s);
+                 int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s,
+                 const int *roi = nullptr, int roi_frames = 0, int *tile_list = nullptr /* 1 + plan.grid.x ints when roi */);
+void f16x3_tile_dims(const F16x3Plan &p, int dims[3]);
 
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)

@@ -437,8 +437,12 @@ __device__ __forceinline__ SrcIdx src_index_scaled(int dst, int in, float scale)
 // every output is the same nested W->H->D lerp as the scalar form, so results stay bit-identical.
 __global__ void __launch_bounds__(256)
 upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, int D, int H, int W, float sD, float sH,
-                           float sW, size_t nbricks) {
-    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+                           float sW, size_t nbricks, const int *__restrict__ roi, int roi_frames, int C, int gD, int gH, int gW,
+                           int groups) {
+  // groups: 256-brick groups per workgroup (1 for the full upsample; 16 for the demand-driven one, where almost every brick
+  // only runs the box test — 12288 workgroups that exit at once cost 70 us of dispatch, 768 that loop cost a tenth)
+  for (int grp = 0; grp < groups; ++grp) {
+    size_t t = ((size_t)blockIdx.x * groups + grp) * blockDim.x + threadIdx.x;
     if (t >= nbricks) return;
     const int oH = 2 * H, oW = 2 * W;
     const int bw = W / 2;  // bricks per output row (2W / 4)
@@ -448,6 +452,20 @@ upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, i
     r /= H;
     int kd = (int)(r % D);      // output slices 2kd, 2kd+1
     size_t plane = r / D;
+    if (roi) {
+        // demand-driven (mphip_upsample_trilinear2_roi): only bricks inside the halo of a conv tile (gD x gH x gW output voxels)
+        // that one of the consumer's sample boxes touches are produced — what mphip_conv3d_fwd_roi will read
+        const int first = roi_frames > 0 ? 0 : (int)(plane / C), count = roi_frames > 0 ? roi_frames : 1;
+        bool need = false;
+        for (int f = first; f < first + count && !need; ++f) {
+            const int *b = roi + f * 8;
+            const int wl = (b[0] / gW) * gW - 1, wh = ((b[0] + b[3] - 1) / gW + 1) * gW;   // inclusive range incl. the 1-voxel conv halo
+            const int hl = (b[1] / gH) * gH - 1, hh = ((b[1] + b[4] - 1) / gH + 1) * gH;
+            const int dl = (b[2] / gD) * gD - 1, dh = ((b[2] + b[5] - 1) / gD + 1) * gD;
+            need = 4 * kw + 3 >= wl && 4 * kw <= wh && 2 * kh + 1 >= hl && 2 * kh <= hh && 2 * kd + 1 >= dl && 2 * kd <= dh;
+        }
+        if (!need) continue;
+    }
     const float *p = x + plane * D * H * W;
     SrcIdx sd[2], sh[2], sw[4];
 #pragma unroll
@@ -509,6 +527,7 @@ upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, i
             *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
         }
     }
+  }
 }
 
 // generic (odd W) fallback: one output per thread
@@ -890,12 +909,28 @@ extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D
         // (an LDS-staged variant of this kernel — 7 coalesced staging loads per thread instead of 36 scalar ones — measured
         //  +-0 on the 201 MB upsample, r03: the kernel is bound by its write stream, not by load issue)
         hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 16, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D,
-                           H, W, sD, sH, sW, total / 16);
+                           H, W, sD, sH, sW, total / 16, (const int *)nullptr, 0, 1, 1, 1, 1, 1);
     } else {
         hipLaunchKernelGGL(upsample_trilinear2_scalar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                            D, H, W, total);
     }
     return check_launch("upsample_trilinear2");
+}
+
+// The x2 upsample restricted to what a demand-driven conv will read (see mphip_conv3d_fwd_roi): x [N*C, D,H,W] -> the parts of
+// y [N*C, 2D,2H,2W] inside the 1-voxel halo of every (tD,tH,tW) conv tile a sample box touches; the rest of y is left untouched.
+extern "C" int mphip_upsample_trilinear2_roi(const float *x, float *y, const int *roi, int roi_frames, int N, int C, int D, int H, int W,
+                                             int tD, int tH, int tW, void *stream) {
+    MPHIP_REQUIRE(x && y && roi, "upsample_trilinear2_roi: null pointer");
+    MPHIP_REQUIRE(N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && tD > 0 && tH > 0 && tW > 0 && W % 2 == 0, "upsample_trilinear2_roi: bad dims");
+    MPHIP_REQUIRE(roi_frames >= 0 && (roi_frames == 0 || N == 1), "upsample_trilinear2_roi: roi_frames > 0 needs N == 1");
+    const size_t total = (size_t)N * C * D * H * W * 8;
+    const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
+    const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
+    const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
+    hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 16, 256 * 16)), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W, sD, sH, sW,
+                       total / 16, roi, roi_frames, C, tD, tH, tW, 16);
+    return check_launch("upsample_trilinear2_roi");
 }
 
 extern "C" int mphip_upsample_trilinear(const float *x, float *y, int NC, int D, int H, int W, int sD, int sH, int sW,

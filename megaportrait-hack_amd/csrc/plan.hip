@@ -127,6 +127,7 @@ struct mphip_hot_slice_plan {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int overlap = 1;
     int precision = 1;   // 1 = auto (f16x3 where supported), 0 = exact fp32 everywhere (ops.set_conv_precision)
+    int demand = 1;      // G3d's last upsample + conv only where the final warp reads them (include/mphip.h "demand-driven")
     Arena main_arena, side_arena;
     std::unordered_map<int, std::pair<size_t, size_t>> slice_sizes;   // B -> (main, side) arena peaks of the dry pass
     std::vector<void *> owned;   // hipMalloc'ed by the plan
@@ -458,11 +459,20 @@ T5 resblock(Ctx &c, ResBlock &b, T5 &x, bool pool_after, Hook hook) {
     return out;
 }
 
-T5 upsample2(Ctx &c, T5 &x) {   // nn.Upsample(scale_factor=2, trilinear, align_corners=True), model.py:585-589; consumes x
+struct Roi {   // demand-driven tail of G3d: the boxes of voxels the final warp reads (device) and the conv kernel's tile
+    const int *box = nullptr;
+    bool on = false;
+    int tile[3] = {0, 0, 0};
+};
+
+T5 upsample2(Ctx &c, T5 &x, const Roi *roi = nullptr) {   // nn.Upsample(scale_factor=2, trilinear, align_corners=True), model.py:585-589; consumes x
     T5 y;
     y.n = x.n; y.c = x.c; y.d = 2 * x.d; y.h = 2 * x.h; y.w = 2 * x.w;
     y.data = take(c, y.numel() * sizeof(float));
-    RUN(c, mphip_upsample_trilinear2(x.data.p, y.data.p, x.n * x.c, x.d, x.h, x.w, c.s));
+    if (roi && roi->on)
+        RUN(c, mphip_upsample_trilinear2_roi(x.data.p, y.data.p, roi->box, 0, x.n, x.c, x.d, x.h, x.w, roi->tile[0], roi->tile[1], roi->tile[2], c.s));
+    else
+        RUN(c, mphip_upsample_trilinear2(x.data.p, y.data.p, x.n * x.c, x.d, x.h, x.w, c.s));
     y.range = x.range;   // convex combinations of x: the descriptor carries over (ops.upsample_trilinear2)
     y.has_range = x.has_range;
     x.range = Buf();
@@ -472,8 +482,9 @@ T5 upsample2(Ctx &c, T5 &x) {   // nn.Upsample(scale_factor=2, trilinear, align_
 }
 
 // G3d.forward (model.py:571-597); consumes x.  out: caller buffer (may be nullptr: arena)
-template <typename Hook>
-T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook) {
+// `tail(n)`: called before the last upsample; returns the sample boxes of the warp that will read the result (or an "off" Roi)
+template <typename Hook, typename Tail>
+T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook, Tail tail) {
     Plan *p = c.p;
     auto none = [] {};
     T5 t = resblock(c, p->down[0], x, true, hook);
@@ -485,19 +496,25 @@ T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook) {
     t = resblock(c, p->up[1], t, false, none);
     t = upsample2(c, t);
     t = resblock(c, p->up[2], t, false, none);
-    t = upsample2(c, t);
-    // final_conv: ops.conv3d (finished tensor)
     ConvW &cw = p->final_conv;
+    Roi roi = tail();
+    if (roi.on) roi.on = mphip_conv3d_roi_granule(t.n, cw.ci, cw.co, 2 * t.d, 2 * t.h, 2 * t.w, cw.k, precision_for(t.n, cw.ci, cw.co, 2 * t.d, 2 * t.h, 2 * t.w, cw.k), roi.tile) != 0;
+    t = upsample2(c, t, &roi);
+    // final_conv: ops.conv3d (finished tensor); demand-driven: only the tiles the final warp reads
     const int prec = precision_for(t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k);
     const void *wp = packed(c, cw, prec);
     const float *xr = prec == 1 ? range_for(c, t) : nullptr;
-    const size_t ws_bytes = mphip_conv3d_workspace_bytes(t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec);
+    const size_t ws_bytes = roi.on ? mphip_conv3d_roi_workspace_bytes(t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec)
+                                   : mphip_conv3d_workspace_bytes(t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec);
     Buf ws;
     if (ws_bytes) ws = take(c, ws_bytes);
     T5 y;
     y.n = t.n; y.c = cw.co; y.d = t.d; y.h = t.h; y.w = t.w;
     if (external_out) y.data.p = out; else y.data = take(c, y.numel() * sizeof(float));
-    RUN(c, mphip_conv3d_fwd(t.data.p, xr, wp, cw.b, y.data.p, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
+    if (roi.on)
+        RUN(c, mphip_conv3d_fwd_roi(t.data.p, xr, wp, cw.b, y.data.p, roi.box, 0, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
+    else
+        RUN(c, mphip_conv3d_fwd(t.data.p, xr, wp, cw.b, y.data.p, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
     give(c, ws);
     give(c, t);
     return y;
@@ -533,7 +550,28 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
             return MPHIP_ELAUNCH;
         }
     }
-    // critical path first: S2C field, warp #1, G3d's first conv; the C2D generator's ~25 launches are issued behind that conv
+    // side stream: C2D field, then K3's coordinate pass and the per-frame box of voxels it will read (demand-driven final_conv)
+    T5 w_c2d;
+    Buf coords, box;
+    bool c2d_issued = false;
+    auto issue_c2d = [&] {
+        if (c2d_issued) return;
+        c2d_issued = true;
+        w_c2d = warp_generator(cs, p->c2d, Rd, td, zd, es, B);
+        coords = take(cs, (size_t)B * p->D * p->H * p->W * 3 * sizeof(float));
+        RUN(cs, mphip_warp_coords(w_c2d.data.p, p->lin_d, p->lin_h, p->lin_w, coords.p, B, p->D, p->H, p->W, p->G, p->G, p->G, cs.s));
+        give(cs, w_c2d);
+        if (p->demand) {
+            box = take(cs, (size_t)B * 8 * sizeof(int));
+            RUN(cs, mphip_warp_sample_box(coords.p, (int *)box.p, B, p->D, p->H, p->W, cs.s));
+        }
+    };
+    // Demand-driven tail: the boxes must exist before G3d's LAST upsample, so the C2D chain can no longer hide under final_conv
+    // (G3d's persistent conv workgroups own every register of a CU: a side-stream kernel only runs in the gaps between conv
+    // launches).  It is issued FIRST, next to the equally latency-bound S2C chain on the caller's stream — the two ~0.3 ms
+    // chains of tiny kernels run side by side while the GPU is otherwise idle.  With the full tail the old order stands:
+    // critical path first, the C2D generator's ~25 launches behind G3d's first conv.
+    if (p->demand && overlap) issue_c2d();
     T5 w_s2c = warp_generator(cm, p->s2c, Rs, ts, zs, es, B);
     T5 vc = new_t5(cm, B, p->C, p->D, p->H, p->W, true);
     {
@@ -544,25 +582,25 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
         give(cm, ws);
     }
     give(cm, w_s2c);
-    T5 w_c2d;
-    auto issue_c2d = [&] { w_c2d = warp_generator(cs, p->c2d, Rd, td, zd, es, B); };
-    T5 vc2d = g3d(cm, vc, false, nullptr, issue_c2d);
-    if (cs.rc != MPHIP_OK && cm.rc == MPHIP_OK) cm.rc = cs.rc;
-    if (overlap) {   // join
-        if (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess) {
+    int join_rc = MPHIP_OK;
+    auto tail = [&]() -> Roi {   // the boxes are needed from here on: join the side stream before G3d's last upsample
+        if (overlap && (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)) {
             set_error("hot_slice_forward: stream join failed: %s", hipGetErrorString(hipGetLastError()));
-            return MPHIP_ELAUNCH;
+            join_rc = MPHIP_ELAUNCH;
         }
-    }
-    {   // apply_warping_field + torch.sum(dim=2) (model.py:1167-1171) in one kernel (K3)
-        const size_t wsb = mphip_warp_workspace_bytes(B, p->D, p->H, p->W);
-        Buf ws = take(cm, wsb);
-        RUN(cm, mphip_warp_volume_dsum(vc2d.data.p, w_c2d.data.p, p->lin_d, p->lin_h, p->lin_w, out, B, p->C, p->D, p->H, p->W, p->G, p->G, p->G,
-                                       ws.p, wsb, s));
-        give(cm, ws);
-    }
+        Roi r;
+        r.on = p->demand != 0;
+        r.box = (const int *)box.p;
+        return r;
+    };
+    T5 vc2d = g3d(cm, vc, false, nullptr, issue_c2d, tail);
+    if (cs.rc != MPHIP_OK && cm.rc == MPHIP_OK) cm.rc = cs.rc;
+    if (join_rc != MPHIP_OK) return join_rc;
+    // apply_warping_field + torch.sum(dim=2) (model.py:1167-1171) in one kernel (K3), on the coordinates computed above
+    RUN(cm, mphip_warp_volume_dsum_coords(vc2d.data.p, coords.p, out, B, p->C, p->D, p->H, p->W, 0, s));
+    give(cs, coords);
+    give(cs, box);
     give(cm, vc2d);
-    give(cs, w_c2d);
     if (need) *need = p->main_arena.peak + p->side_arena.peak;
     return cm.rc;
 }
@@ -586,7 +624,7 @@ int run_g3d(Plan *p, const float *x, const float *x_range, bool have_range, floa
     xt.range.p = const_cast<float *>(x_range);
     xt.has_range = have_range;   // else range_for() measures x (one extra pass) into an arena descriptor
     // the caller's tensors are not arena blocks: give() ignores them (off == SIZE_MAX)
-    T5 out = g3d(cm, xt, true, y, [] {});
+    T5 out = g3d(cm, xt, true, y, [] {}, [] { return Roi(); });
     (void)out;
     return cm.rc;
 }
@@ -694,6 +732,7 @@ extern "C" int mphip_hot_slice_plan_create(const char *const *names, const void 
     p->C = C; p->D = D; p->H = H; p->W = W;
     p->have_generators = !(flags & MPHIP_PLAN_G3D_ONLY);
     p->overlap = !(flags & MPHIP_PLAN_SINGLE_STREAM);
+    p->demand = !(flags & MPHIP_PLAN_FULL_FINAL_CONV);
     int rc = bind_all(p, names, tensors, n_tensors, p->have_generators);
     if (rc == MPHIP_OK && p->have_generators) {
         for (Generator *g : {&p->s2c, &p->c2d}) {

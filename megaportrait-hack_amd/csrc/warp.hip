@@ -748,6 +748,19 @@ static int warp_volume_dsum_impl(const char *name, const float *v, size_t v_fram
     return check_launch(name);
 }
 
+// K3 with the coordinate pass already done (mphip_warp_coords): lets a caller look at the sample positions BEFORE the volume is
+// produced (mphip_warp_sample_box -> mphip_conv3d_fwd_roi).  shared != 0: v is ONE volume [1,C,D,H,W] for all B coordinate sets.
+extern "C" int mphip_warp_volume_dsum_coords(const float *v, const float *coords, float *out, int B, int C, int D, int H, int W, int shared,
+                                             void *stream) {
+    MPHIP_REQUIRE(v && coords && out, "warp_volume_dsum_coords: null pointer");
+    MPHIP_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "warp_volume_dsum_coords: bad dims");
+    constexpr int CPB = 16;
+    const int tiles = ((H + K3_TH - 1) / K3_TH) * ((W + K3_TW - 1) / K3_TW);
+    hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles * cdiv(C, CPB))), dim3(256), 0, (hipStream_t)stream, v,
+                       coords, out, B, C, D, H, W, shared ? (size_t)0 : (size_t)C * D * H * W);
+    return check_launch("warp_volume_dsum_coords");
+}
+
 extern "C" int mphip_warp_volume_dsum(const float *v, const float *field, const float *lin_d, const float *lin_h,
                                       const float *lin_w, float *out, int B, int C, int D, int H, int W, int fD,
                                       int fH, int fW, void *workspace, size_t workspace_bytes, void *stream) {
@@ -1490,6 +1503,15 @@ extern "C" int mphip_warp_coords(const float *field, const float *lin_d, const f
     MPHIP_REQUIRE(field && lin_d && lin_h && lin_w && coords, "warp_coords: null pointer");
     MPHIP_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0 && fD > 0 && fH > 0 && fW > 0, "warp_coords: bad dims");
     return launch_coords(field, lin_d, lin_h, lin_w, coords, nullptr, B, D, H, W, fD, fH, fW, (hipStream_t)stream);
+}
+
+// Per frame, the box of source voxels the samples of `coords` [B,D,H,W,3] touch (all 8 trilinear corners, zero-weight ones
+// included): box[b*8 ..] = {lx, ly, lz, ex, ey, ez, -, -} — origin and extent in voxels.  One workgroup per frame.
+extern "C" int mphip_warp_sample_box(const float *coords, int *box, int B, int D, int H, int W, void *stream) {
+    MPHIP_REQUIRE(coords && box, "warp_sample_box: null pointer");
+    MPHIP_REQUIRE(B > 0 && D > 0 && H > 0 && W > 0, "warp_sample_box: bad dims");
+    hipLaunchKernelGGL(warp_frame_box_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, coords, box, D, H, W, 0);
+    return check_launch("warp_sample_box");
 }
 
 extern "C" size_t mphip_warp_volume_bwd_workspace_bytes(int B, int C, int D, int H, int W) {

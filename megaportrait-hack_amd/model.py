@@ -466,15 +466,18 @@ class _HotSliceRunner:
     # a single frame is launch-bound and the ~135 Python/ctypes round trips cost more than the kernels.  MPHIP_C_PLAN=0 or
     # `use_c_plan = False` selects the per-op schedule (also taken under autograd and when a measurement hook is installed).
     use_c_plan = os.environ.get("MPHIP_C_PLAN", "1") != "0"
+    # G3d's last upsample + conv only where the final warp reads them (MPHIP_FULL_FINAL_CONV=1: everywhere; same output bits)
+    full_final_conv = os.environ.get("MPHIP_FULL_FINAL_CONV", "0") == "1"
 
     def _plan_for(self, vs):
         from . import plan as _plan
 
-        key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators))
+        key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators), bool(self.full_final_conv))
         table = self.__dict__.setdefault("_plans", {})
         pl = table.get(key)
         if pl is None:
-            pl = table[key] = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators)
+            pl = table[key] = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators,
+                                                 full_final_conv=self.full_final_conv)
         return pl
 
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):

@@ -37,7 +37,10 @@ def _hot_tensors(module: torch.nn.Module, g3d_only: bool) -> Dict[str, torch.Ten
 
 
 class HotSlicePlan:
-    def __init__(self, module: torch.nn.Module, dims=(96, 16, 64, 64), g3d_only: bool = False, single_stream: bool = False):
+    def __init__(self, module: torch.nn.Module, dims=(96, 16, 64, 64), g3d_only: bool = False, single_stream: bool = False,
+                 full_final_conv: bool = False):
+        """full_final_conv: evaluate G3d's last upsample + conv on every voxel.  Default: demand-driven — only the tiles the
+        final warp (apply_warping_field + depth sum) reads are produced (include/mphip.h); same output bits either way."""
         self.lib = _lib.load()
         self.module = module
         self.dims = tuple(int(v) for v in dims)
@@ -48,7 +51,7 @@ class HotSlicePlan:
             raise RuntimeError("HotSlicePlan: the module has no warp_generator_s2c / warp_generator_c2d / G3d parameters")
         self.device = next(iter(tensors.values())).device
         names, ptrs = self._tables(tensors)
-        flags = (1 if g3d_only else 0) | (2 if single_stream else 0)
+        flags = (1 if g3d_only else 0) | (2 if single_stream else 0) | (4 if full_final_conv else 0)
         c, d, h, w = self.dims
         with torch.cuda.device(self.device):
             _lib.check(self.lib.mphip_hot_slice_plan_create(names, ptrs, len(tensors), c, d, h, w, flags, ctypes.byref(self._handle)),

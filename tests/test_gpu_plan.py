@@ -179,3 +179,79 @@ def test_plan_from_plain_c(plan_c_exe):
     print(r.stdout)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "bit-exact" in r.stdout and "PLAN C ABI OK" in r.stdout
+
+
+def _rand_boxes(n, d, h, w, gen):
+    lo = torch.stack([torch.randint(0, w - 2, (n,), generator=gen), torch.randint(0, h - 2, (n,), generator=gen),
+                      torch.randint(0, d - 1, (n,), generator=gen)], dim=1)
+    ext = torch.stack([torch.randint(1, 7, (n,), generator=gen), torch.randint(1, 7, (n,), generator=gen), torch.randint(1, 4, (n,), generator=gen)], dim=1)
+    ext = torch.minimum(ext, torch.tensor([w, h, d]) - lo)
+    return torch.cat([lo, ext, torch.zeros(n, 2, dtype=torch.long)], dim=1).int()
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 8, 16, 32), (3, 96, 4, 16, 16), (1, 96, 16, 64, 64)])
+def test_demand_driven_conv_and_upsample_equal_the_full_ops_inside_the_boxes(dev, shape):
+    """mphip_conv3d_fwd_roi / mphip_upsample_trilinear2_roi write exactly the full ops' bits wherever a box's tiles (and their
+    halos) reach, and NOTHING else (the output starts as NaN and must stay NaN outside)."""
+    import ctypes
+
+    from megaportrait_hack_amd import _lib, ops
+
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    n, c, d, h, w = shape
+    gen = torch.Generator().manual_seed(5)
+    x_lo = torch.randn(n, c, d // 2, h // 2, w // 2, generator=gen).to(dev)
+    pc = ops.PackedConv((torch.randn(96, c, 3, 3, 3, generator=gen) * 0.03).to(dev), torch.randn(96, generator=gen).to(dev))
+    boxes = _rand_boxes(n, d, h, w, gen).to(dev)
+    tile = (ctypes.c_int * 3)()
+    assert lib.mphip_conv3d_roi_granule(n, c, 96, d, h, w, 3, 1, tile) == 1
+    td, th, tw = tile[0], tile[1], tile[2]
+    st = P(torch.cuda.current_stream().cuda_stream)
+    up_full = ops.upsample_trilinear2(x_lo)
+    up_roi = torch.full_like(up_full, float("nan"))
+    _lib.check(lib.mphip_upsample_trilinear2_roi(P(x_lo.data_ptr()), P(up_roi.data_ptr()), P(boxes.data_ptr()), 0, n, c, d // 2, h // 2, w // 2,
+                                                 td, th, tw, st), "upsample roi")
+    y_full = ops.conv3d(up_full, pc, precision=1)
+    rng = ops.tensor_range(up_full)
+    # the demand-driven conv reads the demand-driven upsample: NaN anywhere it should not look would surface in y
+    y_roi = torch.full_like(y_full, float("nan"))
+    ws_bytes = lib.mphip_conv3d_roi_workspace_bytes(n, c, 96, d, h, w, 3, 1)
+    ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=dev)
+    _lib.check(lib.mphip_conv3d_fwd_roi(P(up_roi.data_ptr()), P(rng.data_ptr()), P(pc.packed(1).data_ptr()), P(pc.bias.data_ptr()), P(y_roi.data_ptr()),
+                                        P(boxes.data_ptr()), 0, n, c, 96, d, h, w, 3, 1, P(ws.data_ptr()), ws.numel(), st), "conv roi")
+    need = torch.zeros((n, d, h, w), dtype=torch.bool)
+    for i, (lx, ly, lz, ex, ey, ez, _, _) in enumerate(boxes.cpu().tolist()):
+        need[i, lz // td * td:((lz + ez - 1) // td + 1) * td, ly // th * th:((ly + ey - 1) // th + 1) * th, lx // tw * tw:((lx + ex - 1) // tw + 1) * tw] = True
+    need = need.to(dev)[:, None].expand_as(y_full)
+    assert torch.equal(y_roi[need], y_full[need])             # bit-identical where asked for
+    if lib.mphip_conv3d_splits(n, c, 96, d, h, w, 3, 1) == 1:   # (a split-K launch reduces its slabs over the whole tensor)
+        assert torch.isnan(y_roi[~need]).all()                # untouched elsewhere
+    assert need.float().mean().item() < 1.0 or shape[2] <= 4
+
+
+def test_demand_driven_plan_never_reads_what_it_did_not_compute(dev, M):
+    """The plan's workspace is pre-filled with NaN: if the final warp (or anything else) read a voxel the demand-driven tail
+    skipped, the output would carry it.  Same bits as the full evaluation, reference-like fields and a batch that mixes them
+    with frames whose C2D field travels through the whole volume (box = volume: every tile is computed)."""
+    from megaportrait_hack_amd import plan as P
+
+    hot = _hot(M, dev)
+    b, d, h, w = 3, 16, 32, 32
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(b, 13, D=d, H=h, W=w).items()}
+    with torch.no_grad():
+        # make frame 1's driver field travel: a large translation pushes its sample positions across the volume
+        inp["td"][1] = torch.tensor([9.0, -7.0, 11.0], device=dev)
+        inp["Rd"][2] = torch.tensor([170.0, 95.0, -120.0], device=dev)
+        full = P.HotSlicePlan(hot, dims=(96, d, h, w), full_final_conv=True)
+        lazy = P.HotSlicePlan(hot, dims=(96, d, h, w))
+        want = full(**inp)
+        for key, ws in list(lazy._ws.items()):
+            ws.fill_(0xFF)
+        nbytes = lazy.lib.mphip_hot_slice_workspace_bytes(lazy._handle, b)
+        poisoned = lazy._workspace("slice", b, nbytes)
+        poisoned.view(torch.float32)[: nbytes // 4].fill_(float("nan"))
+        got = lazy(**inp)
+        ref = hot._run_python(check_shape=False, **inp)
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, want) and torch.equal(got, ref)
