@@ -31,6 +31,7 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH
 PEAK_F16_MFMA_TFLOPS = 2500.0  # MI355X dense f16/bf16 matrix peak (MI355X_MICROARCH.md)
 FRAME_FLOPS = 164.1e9          # G3d 163.11 + 2 x FlowField 0.50 GFLOP per frame
 FRAME_BYTES = 309e6            # layer-wise-minimal HBM bytes per frame
+FINAL_CONV_FLOPS = 2.0 * 16 * 64 * 64 * 96 * 96 * 27   # G3d.final_conv per frame (32.6 GFLOP): skipped where nobody reads it
 
 
 def parse():
@@ -67,6 +68,9 @@ def parse():
                          "the default line carries the immediate-mode leg `reenact_1x64`)")
     ap.add_argument("--e2e-nhwc", action="store_true", help="also time the end-to-end generator with channels_last 2D modules + MIOpen find mode")
     ap.add_argument("--extras-budget", type=float, default=100.0, help="seconds of side measurements after which remaining legs are skipped")
+    ap.add_argument("--per-op", action="store_true", help="drive the step through the per-op Python schedule instead of the C-side plan")
+    ap.add_argument("--full-final-conv", action="store_true",
+                    help="evaluate G3d's last upsample + conv on every voxel (default: demand-driven, only what the final warp reads)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements on the line (fp32_exact, roofline_hbm, end_to_end)")
     return ap.parse_args()
@@ -333,6 +337,26 @@ def roofline_hbm(hot, inp, B):
     return out
 
 
+def full_final_conv_leg(hot, inp, B, steps=20, warmup=3):
+    """The same step with G3d's last upsample + conv evaluated on EVERY voxel (MPHIP_PLAN_FULL_FINAL_CONV) — what the headline
+    would be without the demand-driven tail; same output bits."""
+    old = hot.full_final_conv
+    hot.full_final_conv = True
+    try:
+        with torch.no_grad():
+            for _ in range(warmup):
+                hot(**inp)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                hot(**inp)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+    finally:
+        hot.full_final_conv = old
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
+
+
 def fp32_exact(hot, inp, B, steps=10, warmup=2):
     """The same hot slice with every conv on the exact fp32 MFMA kernels (precision 0) — beside the default f16x3 line."""
     from megaportrait_hack_amd import ops
@@ -494,7 +518,16 @@ def main():
 
     dom = DominantKernelTimer((96, 96, 16, 64, 64))
     step = hot
-    if args.graph:
+    use_plan = bool(hot.use_c_plan and not args.graph and not args.per_op)
+    if args.full_final_conv:
+        hot.full_final_conv = True
+    if use_plan:
+        # default: ONE ctypes call per step into the C-side plan (csrc/plan.hip); the dominant conv is timed by HIP events the
+        # plan records around its launches on the launch stream (a Python hook would force the per-op path)
+        with torch.no_grad():
+            hot(**inp)                      # builds the plan, packs the weights
+        plan = hot._plan_for(inp["vs"])
+    elif args.graph:
         # the dominant conv is timed with HIP events in a short eager pass (events cannot be queried inside
         # a captured graph); the throughput loop then replays the captured step.
         ops.set_conv_hook(dom)
@@ -522,6 +555,8 @@ def main():
             out = step(**inp)
         sync_all()
         dom.active = not args.graph
+        if use_plan:
+            plan.profile(True)
         lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 and not args.graph else None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if lanes is None else None
         t0 = time.perf_counter()
@@ -549,14 +584,25 @@ def main():
         dt = float(t.item())
 
     step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])) if marks else []
-    dom_ms = dom.mean_ms()
+    dom_ms, dom_launches, demand = dom.mean_ms(), len(dom.events), None
+    if use_plan:
+        tot, dom_launches = plan.profile_read(0)
+        dom_ms = tot / max(1, dom_launches)
+        dtot, dcnt = plan.profile_read(1)
+        plan.profile(False)
+        if dcnt:
+            demand = {"launch_ms": round(dtot / dcnt, 4), "launches_timed": dcnt,
+                      "what": "G3d's last conv (same kernel family, 4x8x8 tiles) evaluated only on the output tiles the final warp reads: "
+                              "the sample boxes of apply_warping_field + sum(dim=2) (model.py:1167-1171) are known from the C2D field "
+                              "before the conv runs; on the reference's fields ~2 of a frame's 512 tiles; bit-identical output"}
     dom_flops = 2.0 * B * 16 * 64 * 64 * 96 * 96 * 27
     line = None
     if rank == 0:
         fps = world * B * args.steps / dt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
         if f16x3:
-            dom_name = "conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)"
+            dom_name = ("conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, "
+                        + ("2 full launches/step + 1 demand-driven" if demand else "3 launches/step") + ")")
             peak, dtype = PEAK_F16_MFMA_TFLOPS, "f16x3 (fp32 in/out, operands split into 2 f16 halves, 3 f16 MFMAs per product, fp32 accumulate)"
         else:
             dom_name = "conv3d_k3_tiled_kernel<4,8,8,3,2> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)"
@@ -570,19 +616,24 @@ def main():
                                    "WarpGeneratorC2D -> 3D warp + depth sum; BASELINE config 2 (inference 512x512, "
                                    "96ch 16x64x64 volume), inputs resident in HBM, random-init weights",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": f"dp{world} (frame shards, no collective)",
-                       "launch": "hipGraph replay of the captured step" if args.graph else "eager stream launches",
+                       "launch": ("hipGraph replay of the captured step" if args.graph else
+                                  "one call per step into the C-side plan (mphip_hot_slice_forward), eager stream launches" if use_plan else
+                                  "eager stream launches, per-op Python schedule"),
+                       "final_conv": ("demand-driven: only the tiles the final warp reads (mphip_conv3d_fwd_roi)" if demand else "evaluated everywhere"),
                        "batches_in_flight": 1 if (args.graph or args.inflight < 2) else args.inflight},
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "rank0_host_pinning": pinned or None,
             "step_ms": ({"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)}
                         if step_ms else None),
-            "hot_slice_tflops": round(fps * FRAME_FLOPS / 1e12, 2),
+            "hot_slice_tflops": round(fps * FRAME_FLOPS / 1e12, 2),   # algorithmic: the reference graph's FLOPs per frame x frames/s
+            "hot_slice_tflops_executed": round(fps * (FRAME_FLOPS - (FINAL_CONV_FLOPS if demand else 0.0)) / 1e12, 2),
             "hot_slice_vs_f32_mfma_peak": round(fps * FRAME_FLOPS / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "hot_slice_layerwise_GBps": round(fps * FRAME_BYTES / 1e9, 1),
             "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                          "traffic": pmc_traffic("conv3d_k3_f16x3_kernel") if (f16x3 and B == 8) else None,
-                         "launch_ms": round(dom_ms, 4), "launches_timed": len(dom.events),
+                         "launch_ms": round(dom_ms, 4), "launches_timed": dom_launches,
+                         "demand_driven_launch": demand,
                          "flops_per_launch": dom_flops,
                          "note": ("algorithmic (fp32-equivalent) FLOPs; the kernel issues 3x that on the f16 pipe: "
                                   f"{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the f16 peak; "
@@ -607,6 +658,8 @@ def main():
                 line[key] = fn(*a, **kw)
                 secs[key] = round(time.perf_counter() - t0_, 1)
 
+            if demand:
+                leg("full_final_conv", full_final_conv_leg, hot, inp, B)
             leg("roofline_hbm", roofline_hbm, hot, inp, B)
             if f16x3:
                 leg("fp32_exact", fp32_exact, hot, inp, B)

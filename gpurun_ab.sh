@@ -1,4 +1,4 @@
 cd /root/repo
-python -m pytest tests/test_gpu_plan.py -x -q -m gpu 2>&1 | tail -5
-python tools/bench_plan.py 2>&1 | grep -v amdgpu
-MPHIP_FULL_FINAL_CONV=1 python tools/bench_plan.py 2>&1 | grep -v amdgpu
+( time python bench.py 2>/dev/null ) > gpurun_out/r03_bench_default.log 2>&1
+tail -5 gpurun_out/r03_bench_default.log | cut -c1-400
+python -m pytest tests -x -q -m gpu 2>&1 | tail -5

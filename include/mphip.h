@@ -372,6 +372,12 @@ int mphip_hot_slice_plan_set_tables(mphip_hot_slice_plan *plan, const float *lin
 /* conv arithmetic of the plan's launches: 1 (default) = "auto", f16x3 wherever mphip_conv3d_supported(..., 1), exact fp32 elsewhere;
  * 0 = exact fp32 MFMA everywhere.  Changes the workspace size: query mphip_hot_slice_workspace_bytes again. */
 int mphip_hot_slice_plan_set_precision(mphip_hot_slice_plan *plan, int precision);
+/* Measurement: with profiling on, every launch of the dominant conv (Conv3d 3x3x3 96->96 at the plan's full volume) is bracketed by
+ * HIP events on the stream it is launched on (the conv alone: the GroupNorm statistics of its output are launched after the closing
+ * event).  _read sums the durations recorded since the last read — kind 0: full launches, 1: the demand-driven launch of G3d's
+ * last conv — and synchronises on them.  Not for captured forwards. */
+int mphip_hot_slice_plan_profile(mphip_hot_slice_plan *plan, int enable);
+int mphip_hot_slice_plan_profile_read(mphip_hot_slice_plan *plan, int kind, double *sum_ms, int *count);
 int mphip_hot_slice_plan_refresh(mphip_hot_slice_plan *plan, const char *const *names, const void *const *tensors, int n_tensors);
 size_t mphip_hot_slice_workspace_bytes(mphip_hot_slice_plan *plan, int B);
 int mphip_hot_slice_forward(mphip_hot_slice_plan *plan, const float *vs, const float *es, const float *Rs, const float *ts,

@@ -86,6 +86,8 @@ SIGNATURES = {
     "mphip_hot_slice_plan_create": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "mphip_hot_slice_plan_set_tables": (_i, [_p, _p, _p, _p, _p]),
     "mphip_hot_slice_plan_refresh": (_i, [_p, _p, _p, _i]),
+    "mphip_hot_slice_plan_profile": (_i, [_p, _i]),
+    "mphip_hot_slice_plan_profile_read": (_i, [_p, _i, _p, _p]),
     "mphip_hot_slice_plan_set_precision": (_i, [_p, _i]),
     "mphip_hot_slice_workspace_bytes": (_sz, [_p, _i]),
     "mphip_hot_slice_forward": (_i, [_p] * 10 + [_i, _p, _sz, _p]),

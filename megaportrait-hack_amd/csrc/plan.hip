@@ -128,6 +128,11 @@ struct mphip_hot_slice_plan {
     int overlap = 1;
     int precision = 1;   // 1 = auto (f16x3 where supported), 0 = exact fp32 everywhere (ops.set_conv_precision)
     int demand = 1;      // G3d's last upsample + conv only where the final warp reads them (include/mphip.h "demand-driven")
+    // measurement (bench.py): HIP events around every launch of the dominant conv (96->96 3x3x3 at the plan's full volume) on the
+    // stream it is launched on; kind 0 = full launches, 1 = the demand-driven launch
+    bool profile = false;
+    std::vector<hipEvent_t> prof_ev[2];   // begin/end pairs, in launch order
+    size_t prof_used[2] = {0, 0};
     Arena main_arena, side_arena;
     std::unordered_map<int, std::pair<size_t, size_t>> slice_sizes;   // B -> (main, side) arena peaks of the dry pass
     std::vector<void *> owned;   // hipMalloc'ed by the plan
@@ -219,6 +224,23 @@ const void *packed(Ctx &c, ConvW &cw, int prec) {
     return cw.pk[prec];
 }
 
+bool prof_begin(Ctx &c, const ConvW &cw, int d, int h, int w, int kind) {
+    Plan *p = c.p;
+    if (c.dry || !p->profile || cw.ci != 96 || cw.co != 96 || cw.k != 3 || d != p->D || h != p->H || w != p->W) return false;
+    if (p->prof_used[kind] + 2 > p->prof_ev[kind].size())
+        for (int i = 0; i < 2; ++i) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return false;
+            p->prof_ev[kind].push_back(e);
+        }
+    return hipEventRecord(p->prof_ev[kind][p->prof_used[kind]], c.s) == hipSuccess;
+}
+void prof_end(Ctx &c, int kind) {
+    Plan *p = c.p;
+    (void)hipEventRecord(p->prof_ev[kind][p->prof_used[kind] + 1], c.s);
+    p->prof_used[kind] += 2;
+}
+
 const float *range_for(Ctx &c, T5 &x) {   // ops._range_for: the producer's descriptor, else one streaming pass
     if (!x.has_range) {
         x.range = take(c, MPHIP_RANGE_FLOATS * sizeof(float));
@@ -243,6 +265,14 @@ ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
     if (gn_groups) {
         o.stats = take(c, (size_t)n * gn_groups * 2 * sizeof(float));
         o.stats_groups = gn_groups;
+        // (timed without the statistics pass: conv launch alone, then the GroupNorm statistics of its output)
+        const bool timed = prof_begin(c, cw, d, h, w, 0);
+        if (timed) {
+            RUN(c, mphip_conv3d_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, n, cw.ci, cw.co, d, h, w, cw.k, prec, ws.p, ws_bytes, c.s));
+            prof_end(c, 0);
+            const size_t gb = mphip_groupnorm_workspace_bytes(n, cw.co, d * h * w, gn_groups);
+            RUN(c, mphip_groupnorm_stats(o.t.data.p, o.stats.p, n, cw.co, d * h * w, gn_groups, GN_EPS, (char *)ws.p + (ws_bytes - gb), gb, c.s));
+        } else
         RUN(c, mphip_conv3d_gn_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, o.stats.p, n, cw.ci, cw.co, d, h, w, cw.k, prec, gn_groups, GN_EPS,
                                    ws.p, ws_bytes, c.s));
     } else {
@@ -343,6 +373,12 @@ ConvOut conv3d_gn_in(Ctx &c, ConvOut &y, const Norm &nm, int groups, ConvW &pc2,
     o.t = new_t5(c, n, pc2.co, d, h, w, false);
     o.stats = take(c, (size_t)n * out_gn_groups * 2 * sizeof(float));
     o.stats_groups = out_gn_groups;
+    if (prof_begin(c, pc2, d, h, w, 0)) {   // (measurement: the conv launch alone between the events, then the statistics of its output)
+        RUN(c, mphip_conv3d_gnin_fwd(y.t.data.p, table.p, xr.p, 1, wp, pc2.b, o.t.data.p, n, ci, pc2.co, d, h, w, pc2.k, 1, ws.p, ws_bytes, c.s));
+        prof_end(c, 0);
+        const size_t gb = mphip_groupnorm_workspace_bytes(n, pc2.co, d * h * w, out_gn_groups);
+        RUN(c, mphip_groupnorm_stats(o.t.data.p, o.stats.p, n, pc2.co, d * h * w, out_gn_groups, GN_EPS, (char *)ws.p + (ws_bytes - gb), gb, c.s));
+    } else
     RUN(c, mphip_conv3d_gnin_gn_fwd(y.t.data.p, table.p, xr.p, 1, wp, pc2.b, o.t.data.p, o.stats.p, n, ci, pc2.co, d, h, w, pc2.k, 1, out_gn_groups,
                                     GN_EPS, ws.p, ws_bytes, c.s));
     give(c, ws);
@@ -511,10 +547,12 @@ T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook, Tail tail) {
     T5 y;
     y.n = t.n; y.c = cw.co; y.d = t.d; y.h = t.h; y.w = t.w;
     if (external_out) y.data.p = out; else y.data = take(c, y.numel() * sizeof(float));
+    const bool timed = prof_begin(c, cw, t.d, t.h, t.w, roi.on ? 1 : 0);
     if (roi.on)
         RUN(c, mphip_conv3d_fwd_roi(t.data.p, xr, wp, cw.b, y.data.p, roi.box, 0, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
     else
         RUN(c, mphip_conv3d_fwd(t.data.p, xr, wp, cw.b, y.data.p, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
+    if (timed) prof_end(c, roi.on ? 1 : 0);
     give(c, ws);
     give(c, t);
     return y;
@@ -787,6 +825,34 @@ extern "C" int mphip_hot_slice_plan_set_precision(mphip_hot_slice_plan *p, int p
     return MPHIP_OK;
 }
 
+extern "C" int mphip_hot_slice_plan_profile(mphip_hot_slice_plan *p, int enable) {
+    MPHIP_REQUIRE(p, "hot_slice_plan_profile: null plan");
+    p->profile = enable != 0;
+    p->prof_used[0] = p->prof_used[1] = 0;
+    return MPHIP_OK;
+}
+
+// Sum and count of the launch durations recorded since the last read (synchronises on the recorded events): kind 0 = full
+// launches of the dominant conv, 1 = its demand-driven launch.
+extern "C" int mphip_hot_slice_plan_profile_read(mphip_hot_slice_plan *p, int kind, double *sum_ms, int *count) {
+    MPHIP_REQUIRE(p && sum_ms && count && (kind == 0 || kind == 1), "hot_slice_plan_profile_read: bad arguments");
+    double tot = 0.0;
+    int cnt = 0;
+    for (size_t i = 0; i + 1 < p->prof_used[kind]; i += 2) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(p->prof_ev[kind][i + 1]) != hipSuccess || hipEventElapsedTime(&ms, p->prof_ev[kind][i], p->prof_ev[kind][i + 1]) != hipSuccess) {
+            set_error("hot_slice_plan_profile_read: %s", hipGetErrorString(hipGetLastError()));
+            return MPHIP_ELAUNCH;
+        }
+        tot += ms;
+        ++cnt;
+    }
+    p->prof_used[kind] = 0;
+    *sum_ms = tot;
+    *count = cnt;
+    return MPHIP_OK;
+}
+
 extern "C" int mphip_hot_slice_plan_refresh(mphip_hot_slice_plan *p, const char *const *names, const void *const *tensors, int n_tensors) {
     MPHIP_REQUIRE(p, "hot_slice_plan_refresh: null plan");
     if (names && tensors && n_tensors > 0) {   // new parameter storage (e.g. after .to()): re-bind, keep the pack buffers
@@ -872,6 +938,8 @@ extern "C" void mphip_hot_slice_plan_destroy(mphip_hot_slice_plan *p) {
     if (!p) return;
     if (p->side) (void)hipStreamSynchronize(p->side);
     for (void *q : p->owned) (void)hipFree(q);
+    for (int k = 0; k < 2; ++k)
+        for (hipEvent_t e : p->prof_ev[k]) (void)hipEventDestroy(e);
     if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
     if (p->ev_join) (void)hipEventDestroy(p->ev_join);
     if (p->side) (void)hipStreamDestroy(p->side);

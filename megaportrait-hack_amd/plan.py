@@ -136,6 +136,17 @@ class HotSlicePlan:
                                               _P(ws.data_ptr()), ws.numel(), ops._stream()), "mphip_g3d_forward")
         return y
 
+    def profile(self, enable: bool = True) -> None:
+        """HIP events around every launch of the dominant conv (bench.py's `roofline`), on the stream it is launched on."""
+        _lib.check(self.lib.mphip_hot_slice_plan_profile(self._handle, int(bool(enable))), "mphip_hot_slice_plan_profile")
+
+    def profile_read(self, kind: int = 0):
+        """(sum of launch durations in ms, launches) since the last read; kind 0 = full launches, 1 = the demand-driven one."""
+        tot, cnt = ctypes.c_double(0.0), ctypes.c_int(0)
+        _lib.check(self.lib.mphip_hot_slice_plan_profile_read(self._handle, kind, ctypes.byref(tot), ctypes.byref(cnt)),
+                   "mphip_hot_slice_plan_profile_read")
+        return float(tot.value), int(cnt.value)
+
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
             with torch.cuda.device(self.device):
