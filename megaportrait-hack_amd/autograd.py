@@ -38,13 +38,15 @@ class Conv3dFn(torch.autograd.Function):
 
     @staticmethod
     @_fwd
-    def forward(ctx, x, weight, bias, conv, fwd_pack):
+    def forward(ctx, x, weight, bias, conv, fwd_pack, roi=None):
         ctx.conv = conv
         ctx.has_bias = bias is not None
         # weight is saved too (not only read from the module in backward): autograd's version check then catches an
         # in-place weight update between forward and backward
         ctx.save_for_backward(x, weight)
-        y = ops.conv3d(x, fwd_pack)
+        # roi: the boxes of voxels the ONLY consumer (the final warp) reads — the forward is evaluated there and nowhere else
+        # (ops.conv3d_roi); the backward is unchanged: that consumer's gradient is exactly zero outside its boxes
+        y = ops.conv3d(x, fwd_pack) if roi is None else ops.conv3d_roi(x, fwd_pack, roi)
         ctx.x_range = ops.tensor_range(x)   # the f16x3 operand scale the forward used for x: bwd-weight reuses it
         return y
 
@@ -62,7 +64,7 @@ class Conv3dFn(torch.autograd.Function):
             dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale)
         if ctx.needs_input_grad[1]:
             dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
-        return dx, dw, db, None, None
+        return dx, dw, db, None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
@@ -140,8 +142,8 @@ class UpsampleTrilinearFn(torch.autograd.Function):
         return ops.upsample_trilinear_bwd(dout.contiguous(), ctx.scale), None
 
 
-def conv3d(x, conv, fwd_pack):
-    return Conv3dFn.apply(x, conv.weight, conv.bias, conv, fwd_pack)
+def conv3d(x, conv, fwd_pack, roi=None):
+    return Conv3dFn.apply(x, conv.weight, conv.bias, conv, fwd_pack, roi)
 
 
 def groupnorm(x, gn, residual=None, relu=False, tanh=False):

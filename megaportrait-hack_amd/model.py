@@ -355,7 +355,9 @@ class G3d(nn.Module):
         )
         self.final_conv = nn.Conv3d(96, 96, kernel_size=3, padding=1)
 
-    def forward(self, x, _after_first_conv=None):
+    def forward(self, x, _after_first_conv=None, _final_roi=None):
+        """`_final_roi`: sample boxes of the warp that is the ONLY reader of the result (GbaseHotSlice under autograd): final_conv
+        is evaluated on the tiles they touch, the rest of the returned tensor is uninitialised (ops.conv3d_roi)."""
         x = _f32(x)
         train = ag.needs_grad(self, x)
         up = ag.UpsampleTrilinear2Fn.apply if train else ops.upsample_trilinear2
@@ -369,7 +371,7 @@ class G3d(nn.Module):
         x = up(u[2](x))
         x = up(u[4](x))
         if train:
-            return ag.conv3d(x, self.final_conv, _packs.get(self.final_conv))
+            return ag.conv3d(x, self.final_conv, _packs.get(self.final_conv), roi=_final_roi)
         return ops.conv3d(x, _packs.get(self.final_conv))
 
 
@@ -529,11 +531,20 @@ class _HotSliceRunner:
         vc = apply_warping_field(vs, w_s2c)
         if check_shape:
             assert vc.shape[1:] == (96, 16, 64, 64), f"Expected vc shape (_, 96, 16, 64, 64), got {vc.shape}"
-        vc2d = self.G3d(vc, _after_first_conv=issue_c2d if (side is not None and not early) else None)
+        roi = None
+        if train and not self.full_final_conv and isinstance(self.G3d, G3d):
+            # training: the final warp reads (and sends gradient to) only the voxels inside its sample boxes — final_conv's
+            # forward is evaluated there (the C-side plan does the same at inference); backward kernels unchanged
+            c2d["w"] = self.warp_generator_c2d(Rd, td, zd, es)
+            with torch.no_grad():
+                roi = ops.warp_sample_box(ops.warp_coords(c2d["w"].detach(), *vc.shape[2:]))
+        vc2d = self.G3d(vc, _after_first_conv=issue_c2d if (side is not None and not early) else None, **({"_final_roi": roi} if roi is not None else {}))
         if side is not None:
             w_c2d = c2d["w"]
             main.wait_stream(side)
             w_c2d.record_stream(main)
+        elif "w" in c2d:
+            w_c2d = c2d["w"]
         else:
             w_c2d = self.warp_generator_c2d(Rd, td, zd, es)
         # apply_warping_field + torch.sum(dim=2) (model.py:1167-1171) in one kernel (K3)

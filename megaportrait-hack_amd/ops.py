@@ -226,6 +226,46 @@ def warp_volume_dsum(v: torch.Tensor, field: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def warp_coords(field: torch.Tensor, d: int, h: int, w: int) -> torch.Tensor:
+    """K2/K3's coordinate pass alone: field [B,3,fD,fH,fW] -> clipped sample positions [B,d,h,w,3] (x,y,z)."""
+    field = _req(field, "warp_field")
+    b = field.shape[0]
+    dev = field.device
+    coords = torch.empty((b, d, h, w, 3), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().mphip_warp_coords(_ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)), _ptr(linspace_table(w, dev)),
+                                             _ptr(coords), b, d, h, w, field.shape[2], field.shape[3], field.shape[4], _stream()), "mphip_warp_coords")
+    return coords
+
+
+def warp_sample_box(coords: torch.Tensor) -> torch.Tensor:
+    """Per frame the box of source voxels the samples touch: int32 [B,8] = {lx, ly, lz, ex, ey, ez, -, -} (include/mphip.h
+    "demand-driven evaluation")."""
+    coords = _req(coords, "coords")
+    b, d, h, w, _ = coords.shape
+    box = torch.empty((b, 8), dtype=torch.int32, device=coords.device)
+    _lib.check(_lib.load().mphip_warp_sample_box(_ptr(coords), _ptr(box), b, d, h, w, _stream()), "mphip_warp_sample_box")
+    return box
+
+
+def conv3d_roi(x: torch.Tensor, pc: "PackedConv", box: torch.Tensor, x_range: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3d evaluated only on the output tiles a sample box touches (mphip_conv3d_fwd_roi).  Every other voxel of the result
+    is UNINITIALISED: the only legitimate consumer is the gather the boxes were computed for."""
+    x = _req(x, "x")
+    n, ci, d, h, w = x.shape
+    lib = _lib.load()
+    prec = _default_precision
+    if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc.co, d, h, w, pc.k, prec):
+        prec = 0
+    wp = pc.packed(prec)
+    xr = _range_for(x, x_range) if prec == 1 else None
+    ws_bytes = lib.mphip_conv3d_roi_workspace_bytes(n, ci, pc.co, d, h, w, pc.k, prec)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x.device) if ws_bytes else None
+    y = torch.empty((n, pc.co, d, h, w), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphip_conv3d_fwd_roi(_ptr(x), _ptr(xr), _ptr(wp), _ptr(pc.bias), _ptr(y), _ptr(box), 0, n, ci, pc.co, d, h, w, pc.k, prec,
+                                        _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_fwd_roi")
+    return y
+
+
 # ------------------------------------------------------------------ K4 / K5
 # Conv precision: 0 = exact fp32 MFMA; 1 = "f16x3" (split-f16, 3 MFMAs per product, fp32-class
 # accuracy, ~3x faster).  "auto" uses f16x3 wherever the kernel supports the shape (all 3x3x3 convs
