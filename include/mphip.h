@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 4
+#define MPHIP_ABI_VERSION 5
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -335,6 +335,14 @@ int mphip_upsample_trilinear2_roi(const float *x, float *y, const int *roi, int 
                                   int tH, int tW, void *stream);
 int mphip_warp_volume_dsum_coords(const float *v, const float *coords, float *out, int B, int C, int D, int H, int W, int shared,
                                   void *stream);
+/* Training: the gather's gradient wrt its input volume is exactly zero outside the same boxes (mphip_warp_volume_bwd), so the
+ * backward of the producing conv can be restricted too: bwd-data zero-fills dx and computes only the tiles the boxes grown by one
+ * voxel touch (workspace: mphip_conv3d_roi_workspace_bytes with Ci/Co of dy/dx); bwd-weight skips the voxel tiles outside the boxes. */
+int mphip_conv3d_bwd_data_roi(const float *dy, const void *wt_packed, float *dx, const float *dy_scale, const int *roi, int N, int Ci,
+                              int Co, int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes, void *stream);
+int mphip_conv3d_bwd_weight_roi(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw,
+                                const int *dy_boxes, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ one-call entries: the hot slice and G3d as plans
  * Replace the single calls of the reference: Gbase.forward's slice (model.py:1151-1171: WarpGeneratorS2C ->

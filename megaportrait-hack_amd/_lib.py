@@ -81,6 +81,8 @@ SIGNATURES = {
     "mphip_conv3d_roi_granule": (_i, [_i] * 8 + [_p]),
     "mphip_conv3d_roi_workspace_bytes": (_sz, [_i] * 8),
     "mphip_conv3d_fwd_roi": (_i, [_p] * 6 + [_i] * 9 + [_p, _sz, _p]),
+    "mphip_conv3d_bwd_data_roi": (_i, [_p] * 5 + [_i] * 8 + [_p, _sz, _p]),
+    "mphip_conv3d_bwd_weight_roi": (_i, [_p] * 6 + [_i] * 8 + [_p, _sz, _p]),
     "mphip_upsample_trilinear2_roi": (_i, [_p, _p, _p] + [_i] * 9 + [_p]),
     "mphip_warp_volume_dsum_coords": (_i, [_p, _p, _p] + [_i] * 6 + [_p]),
     "mphip_hot_slice_plan_create": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),

@@ -45,8 +45,9 @@ class Conv3dFn(torch.autograd.Function):
         # in-place weight update between forward and backward
         ctx.save_for_backward(x, weight)
         # roi: the boxes of voxels the ONLY consumer (the final warp) reads — the forward is evaluated there and nowhere else
-        # (ops.conv3d_roi); the backward is unchanged: that consumer's gradient is exactly zero outside its boxes
+        # (ops.conv3d_roi); the backward is restricted the same way (see backward)
         y = ops.conv3d(x, fwd_pack) if roi is None else ops.conv3d_roi(x, fwd_pack, roi)
+        ctx.roi = roi
         ctx.x_range = ops.tensor_range(x)   # the f16x3 operand scale the forward used for x: bwd-weight reuses it
         return y
 
@@ -60,10 +61,12 @@ class Conv3dFn(torch.autograd.Function):
         k = conv.weight.shape[2]
         dx = dw = None
         db, scale = ops.grad_prep(dy, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+        # ctx.roi: the forward was demand-driven for a gather — that gather's gradient dy is exactly zero outside the same boxes
+        # (mphip_warp_volume_bwd zero-fills, then writes the cells the samples touch), so both products are restricted to them
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale)
+            dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale, roi=ctx.roi)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
+            dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range, roi=ctx.roi).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
         return dx, dw, db, None, None, None
 
 

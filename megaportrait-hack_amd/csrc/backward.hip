@@ -629,9 +629,26 @@ extern "C" size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co,
     return (size_t)bw_splits(ntiles, bxy) * Co * Ci * k * k * k * sizeof(float);
 }
 
+static int bwd_weight_impl(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co, int D,
+                           int H, int W, int k, int precision, void *workspace, size_t workspace_bytes, void *stream, const int *dy_boxes);
+
 extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N,
                                        int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                                        size_t workspace_bytes, void *stream) {
+    return bwd_weight_impl(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, precision, workspace, workspace_bytes, stream, nullptr);
+}
+
+// dW when dy is zero outside per-frame boxes {lx,ly,lz,ex,ey,ez,-,-} (the gradient of a gather): voxel tiles outside them are skipped
+// by the f16x3 3x3x3 kernel (other kernels ignore the hint and read everything: same result).
+extern "C" int mphip_conv3d_bwd_weight_roi(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw,
+                                           const int *dy_boxes, int N, int Ci, int Co, int D, int H, int W, int k, int precision,
+                                           void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(dy_boxes, "conv3d_bwd_weight_roi: null box list");
+    return bwd_weight_impl(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, precision, workspace, workspace_bytes, stream, dy_boxes);
+}
+
+static int bwd_weight_impl(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N, int Ci, int Co, int D,
+                           int H, int W, int k, int precision, void *workspace, size_t workspace_bytes, void *stream, const int *dy_boxes) {
     MPHIP_REQUIRE(x && dy && dw, "conv3d_bwd_weight: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0 && (k == 1 || k == 3), "conv3d_bwd_weight: bad dims");
     MPHIP_REQUIRE(mphip_conv3d_bwd_weight_supported(N, Ci, Co, D, H, W, k, precision),
@@ -675,7 +692,8 @@ extern "C" int mphip_conv3d_bwd_weight(const float *x, const float *x_range, con
             if (rc0) return rc0;
             x_range = (const float *)workspace;
         }
-        return bwd_weight_f16x3_launch(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, (char *)workspace + BW_RANGE_BYTES, s);
+        return bwd_weight_f16x3_launch(x, x_range, dy, dy_scale, dw, N, Ci, Co, D, H, W, k, (char *)workspace + BW_RANGE_BYTES, s,
+                                       k == 3 ? dy_boxes : nullptr);
     }
     const long ntiles = (long)N * D * ((H + 7) / 8) * ((W + 7) / 8);
     const int ci_tiles = (Ci + 31) / 32, co_tiles = (Co + 95) / 96;

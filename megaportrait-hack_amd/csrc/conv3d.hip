@@ -563,7 +563,7 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
 
 static int conv3d_run(const float *x, const float *in_affine, int in_relu, const float *x_range, const void *w_packed, const float *bias, float *y,
                       float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
-                      size_t workspace_bytes, void *stream, const int *roi = nullptr, int roi_frames = 0) {
+                      size_t workspace_bytes, void *stream, const int *roi = nullptr, int roi_frames = 0, int roi_dilate = 0) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
     MPHIP_REQUIRE(k == 1 || k == 3, "conv3d_fwd: kernel size %d not supported (1 or 3)", k);
@@ -634,7 +634,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
             }
             tile_list = (int *)((char *)workspace + workspace_bytes - list_bytes);
         }
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list);
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list, roi_dilate);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -743,6 +743,22 @@ extern "C" int mphip_conv3d_gnin_gn_fwd(const float *x, const float *in_affine, 
                   gn_groups);
     return conv3d_run(x, in_affine, in_relu, x_range, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k,
                       precision, workspace, workspace_bytes, stream);
+}
+
+// bwd-data of a conv whose output gradient dy is zero outside per-frame boxes (the gradient of a gather, mphip_warp_volume_bwd):
+// dx is zero outside the boxes grown by one voxel — dx is zero-filled and only the tiles those grown boxes touch are computed.
+extern "C" int mphip_conv3d_bwd_data_roi(const float *dy, const void *wt_packed, float *dx, const float *dy_scale, const int *roi, int N,
+                                         int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
+                                         size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(roi && dx, "conv3d_bwd_data_roi: null pointer");
+    MPHIP_REQUIRE(precision == 0 || dy_scale, "conv3d_bwd_data_roi: the f16x3 kernel needs the gradient scale of mphip_grad_prep");
+    int dims[3];
+    // (a split-K launch reduces its slabs over EVERY voxel — garbage outside the listed tiles, where dx must be zero: such
+    //  shapes, small volumes only, take the full evaluation)
+    const bool tiled = mphip_conv3d_roi_granule(N, Ci, Co, D, H, W, k, precision, dims) != 0 && f16x3_plan(N, Ci, Co, D, H, W, true).splits == 1;
+    if (tiled) zero_fill(dx, (size_t)N * Co * D * H * W * sizeof(float), (hipStream_t)stream);   // (16-byte multiple: W % 8 == 0 on this path)
+    return conv3d_run(dy, nullptr, 0, precision == 1 ? dy_scale : nullptr, wt_packed, nullptr, dx, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k,
+                      precision, workspace, workspace_bytes, stream, tiled ? roi : nullptr, 0, 1);
 }
 
 // bwd-data of a conv = the forward conv of dy with the flipped / transposed weight (packed by the caller from

@@ -67,7 +67,8 @@ __device__ __forceinline__ void halo_row_frags(const _Float16 *row, half8 f[3]) 
 __global__ void __launch_bounds__(512)
 conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gscale,
                              const float *__restrict__ x_range,
-                             float *__restrict__ slabs, int N, int Ci, int Co, int D, int H, int W, int tiles_per_split) {
+                             float *__restrict__ slabs, int N, int Ci, int Co, int D, int H, int W, int tiles_per_split,
+                             const int *__restrict__ dy_boxes) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[2 * BF_A_PART + 2 * BF_X_PART];
     _Float16 *const As = smem;                  // [part][co 96][BF_AP]
     _Float16 *const Xs = smem + 2 * BF_A_PART;  // [part][ci 32][plane 4][row 10][BF_XROW]
@@ -106,6 +107,10 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
         const int td = r_ % tiles_d;
         const int n = r_ / tiles_d;
         const int d0 = td * 2, h0 = th * 8, w0 = tw * 8;
+        if (dy_boxes) {   // dY is zero outside its frame's box {lx,ly,lz,ex,ey,ez} (the gradient of a gather): such tiles add nothing
+            const int *b = dy_boxes + n * 8;
+            if (!(w0 < b[0] + b[3] && w0 + 8 > b[0] && h0 < b[1] + b[4] && h0 + 8 > b[1] && d0 < b[2] + b[5] && d0 + 2 > b[2])) continue;
+        }
         __syncthreads();  // the previous tile is fully consumed
 #ifdef BF_ABL_NOSTAGE
         if (tile == t_begin)
@@ -479,7 +484,7 @@ size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int
 }
 
 int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N, int Ci,
-                            int Co, int D, int H, int W, int k, void *workspace, hipStream_t s) {
+                            int Co, int D, int H, int W, int k, void *workspace, hipStream_t s, const int *dy_boxes) {
     int splits, tps;
     if (k == 1) {
         bwf_k1_plan(N, Ci, Co, D * H * W, splits, tps);
@@ -493,7 +498,7 @@ int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *d
     bwf_plan(N, Ci, Co, D, H, W, splits, tps);
     dim3 grid(((Ci + 31) / 32) * ((Co + 95) / 96), 1, splits);
     hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, x_range, (float *)workspace, N, Ci, Co, D, H, W,
-                       tps);
+                       tps, dy_boxes);
     const size_t ncc = (size_t)Co * Ci;
     hipLaunchKernelGGL(slab_reduce_f16x3_kernel, dim3(cdiv(ncc, 64)), dim3(256), 0, s, (const float *)workspace, dw, ncc, splits);
     return check_launch("conv3d_bwd_weight(f16x3)");

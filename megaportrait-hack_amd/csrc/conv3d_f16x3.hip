@@ -66,6 +66,11 @@ __device__ unsigned long long g_f16x3_prof[8];
 #define PROF_FLUSH
 #endif
 
+#ifdef MPHIP_ABL_LOMASK  /* dev (energy probe): low mantissa bits of the lo halves zeroed — do the cross-term MFMAs draw less power? */
+#define F16X3_LO_MASK(lv_) { unsigned u_ = __builtin_bit_cast(unsigned, lv_) & (MPHIP_ABL_LOMASK); lv_ = __builtin_bit_cast(half2v, u_); }
+#else
+#define F16X3_LO_MASK(lv_)
+#endif
 #ifdef MPHIP_NO_SAT_GUARD  /* dev: same-box A/B of the range guard's cost */
 #define F16X3_SAT_COUNT(a_, b_)
 #else
@@ -160,6 +165,9 @@ f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const
             const float v = transposed ? tile[ci * pitch + co * 27 + (26 - tap)] : tile[co * pitch + ci * 27 + tap];
             _Float16 h, l;
             split_f16(v * scale, h, l);
+#ifdef MPHIP_ABL_LOMASK
+            l = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, l) & (unsigned short)(MPHIP_ABL_LOMASK)));
+#endif
             hi[e] = h; lo[e] = l;
         }
         const size_t slab = ((size_t)cot * nchunks + chunk) * F16X3_NG + g;
@@ -313,6 +321,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
         split_f16(v0_ * x_scale, h0_, l0_);                                                       \
         split_f16(v1_ * x_scale, h1_, l1_);                                                       \
         half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                                \
+        F16X3_LO_MASK(lv_)                                                                        \
         *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                             \
         *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                                    \
     }
@@ -608,7 +617,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 // > 0: the single frame serves that many boxes.  One workgroup; the order of the ids is irrelevant (tiles are independent).
 __global__ void __launch_bounds__(1024)
 roi_tile_list_kernel(const int *__restrict__ roi, int roi_frames, int tiles_total, int D, int H, int W, int TD, int TH, int TW,
-                     int *__restrict__ list) {
+                     int dilate, int *__restrict__ list) {
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -622,8 +631,9 @@ roi_tile_list_kernel(const int *__restrict__ roi, int roi_frames, int tiles_tota
         const int first = roi_frames > 0 ? 0 : n, count = roi_frames > 0 ? roi_frames : 1;
         bool need = false;
         for (int f = first; f < first + count && !need; ++f) {
-            const int *b = roi + f * 8;
-            need = w0 < b[0] + b[3] && w0 + TW > b[0] && h0 < b[1] + b[4] && h0 + TH > b[1] && d0 < b[2] + b[5] && d0 + TD > b[2];
+            const int *b = roi + f * 8;   // (dilate: the box grown by that many voxels on every side — bwd-data of a box of gradients)
+            need = w0 < b[0] + b[3] + dilate && w0 + TW > b[0] - dilate && h0 < b[1] + b[4] + dilate && h0 + TH > b[1] - dilate &&
+                   d0 < b[2] + b[5] + dilate && d0 + TD > b[2] - dilate;
         }
         if (need) list[1 + atomicAdd(&cnt, 1)] = t;
     }
@@ -823,6 +833,8 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     int sp = 1;
     if (tiles * cot < 256)
         while (tiles * cot * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
+    static const char *force_sp = getenv("MPHIP_F16X3_SPLITS");   // dev: planner sweep (tools/sweep_conv_plans.py)
+    if (force_sp && atoi(force_sp) > 0 && nchunks / atoi(force_sp) >= 1) sp = atoi(force_sp);
     p.splits = sp;
     p.chunks_per_split = (nchunks + sp - 1) / sp;
     p.grid = dim3((unsigned)tiles, Co / F16X3_COT, sp);
@@ -867,7 +879,7 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s, const int *roi,
-                 int roi_frames, int *tile_list) {
+                 int roi_frames, int *tile_list, int roi_dilate) {
     if (in_affine && Ci > 768) {
         set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
         return MPHIP_EINVAL;
@@ -879,7 +891,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
         int dims[3];
         f16x3_tile_dims(p, dims);
         hipLaunchKernelGGL(roi_tile_list_kernel, dim3(1), dim3(1024), 0, s, roi, roi_frames, (int)p.grid.x, D, H, W, dims[0], dims[1], dims[2],
-                           tile_list);
+                           roi_dilate, tile_list);
         roi = tile_list;
     }
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for

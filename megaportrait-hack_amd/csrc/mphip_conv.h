@@ -32,7 +32,7 @@ int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int k, int trans
 // frame; > 0: the conv's frames... single frame serves that many boxes)
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s,
-                 const int *roi = nullptr, int roi_frames = 0, int *tile_list = nullptr /* 1 + plan.grid.x ints when roi */);
+                 const int *roi = nullptr, int roi_frames = 0, int *tile_list = nullptr /* 1 + plan.grid.x ints when roi */, int roi_dilate = 0);
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]);
 
 
@@ -40,7 +40,7 @@ void f16x3_tile_dims(const F16x3Plan &p, int dims[3]);
 bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
 size_t bwd_weight_f16x3_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k);
 int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *dy, const float *dy_scale, float *dw, int N, int Ci,
-                            int Co, int D, int H, int W, int k, void *workspace, hipStream_t s);
+                            int Co, int D, int H, int W, int k, void *workspace, hipStream_t s, const int *dy_boxes = nullptr);
 
 // norm.hip: GroupNorm statistics of x [N,C,S] -> stats [N*G][2] (workspace sized by groupnorm_ws_bytes)
 size_t groupnorm_ws_bytes(int N, int C, int S, int G);

@@ -196,9 +196,8 @@ __global__ void __launch_bounds__(256) transpose_kernel(const float *__restrict_
         if (bx + i < cols && by + tx < rows) out[(size_t)(bx + i) * rows + by + tx] = tile[tx][i];
 }
 
-int g_precision_mode = 1;   // set per forward from the plan (host-side, single-threaded per call)
-int precision_for(int n, int ci, int co, int d, int h, int w, int k) {
-    if (g_precision_mode == 0) return 0;                                // exact fp32 MFMA everywhere
+int precision_for(const Ctx &c, int n, int ci, int co, int d, int h, int w, int k) {
+    if (c.p->precision == 0) return 0;                                  // exact fp32 MFMA everywhere
     return mphip_conv3d_supported(n, ci, co, d, h, w, k, 1) ? 1 : 0;   // "auto": f16x3 wherever the kernel covers the shape
 }
 
@@ -253,7 +252,7 @@ const float *range_for(Ctx &c, T5 &x) {   // ops._range_for: the producer's desc
 // ops.conv3d: finished tensor (+ the statistics of the GroupNorm that follows when gn_groups)
 ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
     const int n = x.n, d = x.d, h = x.h, w = x.w;
-    const int prec = precision_for(n, cw.ci, cw.co, d, h, w, cw.k);
+    const int prec = precision_for(c, n, cw.ci, cw.co, d, h, w, cw.k);
     const void *wp = packed(c, cw, prec);
     const float *xr = prec == 1 ? range_for(c, x) : nullptr;
     const size_t ws_bytes = gn_groups ? mphip_conv3d_gn_workspace_bytes(n, cw.ci, cw.co, d, h, w, cw.k, prec, gn_groups)
@@ -285,7 +284,7 @@ ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
 // ops.conv3d_split: split-K slabs are kept for the GroupNorm kernels when the tensor is small
 ConvOut conv3d_split(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
     const int n = x.n, d = x.d, h = x.h, w = x.w;
-    const int prec = precision_for(n, cw.ci, cw.co, d, h, w, cw.k);
+    const int prec = precision_for(c, n, cw.ci, cw.co, d, h, w, cw.k);
     const int splits = mphip_conv3d_splits(n, cw.ci, cw.co, d, h, w, cw.k, prec);
     const size_t elems = (size_t)n * cw.co * d * h * w;
     if (splits > 1 && elems > SPLIT_CHAIN_MAX_ELEMS) return conv3d(c, x, cw, gn_groups);
@@ -355,8 +354,8 @@ T5 groupnorm_small(Ctx &c, ConvOut &x, const Norm &nm, int groups, const ConvOut
     return y;
 }
 
-bool gn_in_conv_ok(const ConvOut &y, const ConvW &pc2) {
-    if (g_precision_mode != 1 || pc2.k != 3 || pc2.ci > 768) return false;
+bool gn_in_conv_ok(const Ctx &c, const ConvOut &y, const ConvW &pc2) {
+    if (c.p->precision != 1 || pc2.k != 3 || pc2.ci > 768) return false;
     return mphip_conv3d_supported(y.t.n, pc2.ci, pc2.co, y.t.d, y.t.h, y.t.w, pc2.k, 1) != 0;
 }
 
@@ -407,7 +406,7 @@ T5 resblock_ada(Ctx &c, ResBlockAda &b, T5 &x, int ud, int uh, int uw) {
         give(c, a);
     } else {
         ensure_stats(c, y, 32);
-        if (y.splits == 1 && gn_in_conv_ok(y, b.conv2)) {
+        if (y.splits == 1 && gn_in_conv_ok(c, y, b.conv2)) {
             y2 = conv3d_gn_in(c, y, b.n1, 32, b.conv2, 32);
             give(c, y);
         } else {
@@ -478,7 +477,7 @@ T5 resblock(Ctx &c, ResBlock &b, T5 &x, bool pool_after, Hook hook) {
     hook();
     ensure_stats(c, y, 32);
     ConvOut y2;
-    if (y.splits == 1 && gn_in_conv_ok(y, b.conv2)) {
+    if (y.splits == 1 && gn_in_conv_ok(c, y, b.conv2)) {
         y2 = conv3d_gn_in(c, y, b.gn1, 32, b.conv2, 32);   // GN1 + ReLU folded into conv2's input staging
         give(c, y);
     } else {
@@ -534,10 +533,10 @@ T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook, Tail tail) {
     t = resblock(c, p->up[2], t, false, none);
     ConvW &cw = p->final_conv;
     Roi roi = tail();
-    if (roi.on) roi.on = mphip_conv3d_roi_granule(t.n, cw.ci, cw.co, 2 * t.d, 2 * t.h, 2 * t.w, cw.k, precision_for(t.n, cw.ci, cw.co, 2 * t.d, 2 * t.h, 2 * t.w, cw.k), roi.tile) != 0;
+    if (roi.on) roi.on = mphip_conv3d_roi_granule(t.n, cw.ci, cw.co, 2 * t.d, 2 * t.h, 2 * t.w, cw.k, precision_for(c, t.n, cw.ci, cw.co, 2 * t.d, 2 * t.h, 2 * t.w, cw.k), roi.tile) != 0;
     t = upsample2(c, t, &roi);
     // final_conv: ops.conv3d (finished tensor); demand-driven: only the tiles the final warp reads
-    const int prec = precision_for(t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k);
+    const int prec = precision_for(c, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k);
     const void *wp = packed(c, cw, prec);
     const float *xr = prec == 1 ? range_for(c, t) : nullptr;
     const size_t ws_bytes = roi.on ? mphip_conv3d_roi_workspace_bytes(t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec)
@@ -562,7 +561,6 @@ T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook, Tail tail) {
 int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const float *ts, const float *zs, const float *Rd, const float *td,
               const float *zd, float *out, int B, void *workspace, size_t workspace_bytes, hipStream_t s, bool dry, size_t *need) {
     const bool overlap = p->overlap && !dry;
-    g_precision_mode = p->precision;
     // the side stream's arena sits behind the main one: sizes from the dry pass
     size_t side_bytes = 0, main_bytes = 0;
     if (!dry) {
@@ -645,7 +643,6 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
 
 int run_g3d(Plan *p, const float *x, const float *x_range, bool have_range, float *y, int B, void *workspace, size_t workspace_bytes, hipStream_t s,
             bool dry) {
-    g_precision_mode = p->precision;
     if (!dry) {
         run_g3d(p, nullptr, nullptr, have_range, nullptr, B, nullptr, 0, nullptr, true);
         if (workspace_bytes < p->main_arena.peak || !workspace) {

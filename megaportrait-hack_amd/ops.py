@@ -744,8 +744,10 @@ def grad_prep(dy: torch.Tensor, want_bias: bool = True):
     return db, scale
 
 
-def conv3d_bwd_data(dy: torch.Tensor, pc_t: "PackedConv", dy_scale: torch.Tensor, precision: Optional[int] = None) -> torch.Tensor:
-    """dx of y = conv3d(x, W): the forward kernels on the flipped/transposed weight `pc_t` (conv_bwd_data_weight)."""
+def conv3d_bwd_data(dy: torch.Tensor, pc_t: "PackedConv", dy_scale: torch.Tensor, precision: Optional[int] = None,
+                    roi: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx of y = conv3d(x, W): the forward kernels on the flipped/transposed weight `pc_t` (conv_bwd_data_weight).
+    roi: dy is zero outside these per-frame boxes (the gradient of a gather) -> only the tiles around them are computed."""
     dy = _req(dy, "dy")
     n, ci, d, h, w = dy.shape
     if ci != pc_t.ci:
@@ -755,16 +757,22 @@ def conv3d_bwd_data(dy: torch.Tensor, pc_t: "PackedConv", dy_scale: torch.Tensor
     if prec != 0 and not lib.mphip_conv3d_supported(n, ci, pc_t.co, d, h, w, pc_t.k, prec):
         prec = 0
     wp = pc_t.packed(prec)
+    dx = torch.empty((n, pc_t.co, d, h, w), dtype=torch.float32, device=dy.device)
+    if roi is not None:
+        ws_bytes = lib.mphip_conv3d_roi_workspace_bytes(n, ci, pc_t.co, d, h, w, pc_t.k, prec)
+        ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=dy.device) if ws_bytes else None
+        _lib.check(lib.mphip_conv3d_bwd_data_roi(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(dy_scale), _ptr(roi), n, ci, pc_t.co, d, h, w, pc_t.k, prec,
+                                                 _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_bwd_data_roi")
+        return dx
     ws_bytes = lib.mphip_conv3d_workspace_bytes(n, ci, pc_t.co, d, h, w, pc_t.k, prec)
     ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=dy.device) if ws_bytes else None
-    dx = torch.empty((n, pc_t.co, d, h, w), dtype=torch.float32, device=dy.device)
     _lib.check(lib.mphip_conv3d_bwd_data(_ptr(dy), _ptr(wp), _ptr(dx), _ptr(dy_scale), n, ci, pc_t.co, d, h, w, pc_t.k, prec,
                                          _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_bwd_data")
     return dx
 
 
 def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, dy_scale: Optional[torch.Tensor] = None,
-                      precision: Optional[int] = None, x_range: Optional[torch.Tensor] = None) -> torch.Tensor:
+                      precision: Optional[int] = None, x_range: Optional[torch.Tensor] = None, roi: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dW [Co,Ci,k,k,k] of y = conv3d(x, W, b, padding=k//2) given dy.  precision 1 (f16x3) needs dy_scale (grad_prep)."""
     x, dy = _req(x, "x"), _req(dy, "dy")
     n, ci, d, h, w = x.shape
@@ -781,6 +789,10 @@ def conv3d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, k: int, dy_scale: Optio
     ws = torch.empty((ws_bytes + 3) // 4, dtype=torch.float32, device=x.device)
     dw = torch.empty((co, ci, k, k, k), dtype=torch.float32, device=x.device)
     xr = (x_range if x_range is not None else tensor_range(x)) if prec == 1 else None   # None: the library measures x itself
+    if roi is not None:   # dy is zero outside these per-frame boxes: the voxel tiles outside them are skipped
+        _lib.check(lib.mphip_conv3d_bwd_weight_roi(_ptr(x), _ptr(xr), _ptr(dy), _ptr(dy_scale), _ptr(dw), _ptr(roi), n, ci, co, d, h, w, k, prec,
+                                                   _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_bwd_weight_roi")
+        return dw
     _lib.check(lib.mphip_conv3d_bwd_weight(_ptr(x), _ptr(xr), _ptr(dy), _ptr(dy_scale), _ptr(dw), n, ci, co, d, h, w, k, prec,
                                            _ptr(ws), ws_bytes, _stream()), "mphip_conv3d_bwd_weight")
     return dw

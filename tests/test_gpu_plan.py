@@ -255,3 +255,30 @@ def test_demand_driven_plan_never_reads_what_it_did_not_compute(dev, M):
         ref = hot._run_python(check_shape=False, **inp)
     assert torch.isfinite(got).all()
     assert torch.equal(got, want) and torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 8, 16, 32), (1, 96, 16, 64, 64)])
+def test_demand_driven_conv_backward_equals_the_full_backward(dev, shape):
+    """When dy is zero outside per-frame boxes (the gradient of a gather), mphip_conv3d_bwd_data_roi / _bwd_weight_roi give what
+    the full kernels give on that dy: dx bit for bit (zero-filled outside the grown boxes), dW to rounding (same products, the
+    all-zero tiles are skipped)."""
+    from megaportrait_hack_amd import ops
+
+    n, c, d, h, w = shape
+    gen = torch.Generator().manual_seed(9)
+    conv = torch.nn.Conv3d(c, 96, 3, padding=1).to(dev)
+    x = torch.randn(n, c, d, h, w, generator=gen).to(dev)
+    boxes = _rand_boxes(n, d, h, w, gen)
+    dy = torch.zeros(n, 96, d, h, w)
+    for i, (lx, ly, lz, ex, ey, ez, _, _) in enumerate(boxes.tolist()):
+        dy[i, :, lz:lz + ez, ly:ly + ey, lx:lx + ex] = torch.randn(96, ez, ey, ex, generator=gen) * 1e-3
+    dy, boxes = dy.to(dev), boxes.to(dev)
+    pc_t = ops.PackedConv(conv.weight.detach(), None, transposed=True)
+    _, scale = ops.grad_prep(dy, want_bias=False)
+    dx_full = ops.conv3d_bwd_data(dy, pc_t, scale)
+    dx_roi = ops.conv3d_bwd_data(dy, pc_t, scale, roi=boxes)
+    assert torch.equal(dx_roi, dx_full)
+    rng = ops.absmax_range(x)
+    dw_full = ops.conv3d_bwd_weight(x, dy, 3, scale, x_range=rng)
+    dw_roi = ops.conv3d_bwd_weight(x, dy, 3, scale, x_range=rng, roi=boxes)
+    assert torch.equal(dw_roi, dw_full)
