@@ -330,6 +330,9 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
 // gathered from LDS.  Any other tile — a field that really travels through the volume — is only MARKED here (todo[tile] = 1)
 // and done by warp_gather_columns_kernel / warp_gather_direct_kernel below: keeping that path out of this kernel keeps it lean (registers: the
 // staged path lost 25 % when both lived in one kernel).
+// (r03: a [voxel][channel] image with four channels per ds_read_b128 tap — K3's gather8x4, 2 LDS reads per output value instead of
+//  8 — measured 82 vs 77 us for the whole op at B=8, same box: LDS issue is not what bounds this kernel; removed.  A plain fill of
+//  the same 201 MB runs at 7.6 TB/s on this chip (tools/probe_write_bw.py), the gather writes at 3.8.)
 constexpr int K2_TH = 32, K2_TW = 32;
 constexpr int K2_DIRECT_SPLIT = 4;  // channel groups of the direct gather (warp_gather_direct_body)
 constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a 32 x 32 tile up to which the column walk is used
