@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 5
+#define MPHIP_ABI_VERSION 6
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -309,6 +309,15 @@ int mphip_warp_field_compose_bwd(const float *dw, const float *base_tbl, float *
                                  int eH, int eW, int G, void *workspace, size_t workspace_bytes, void *stream);
 int mphip_rt_theta_bwd(const float *rot, const float *tr, const float *dtheta, float *drot, float *dtr, int B,
                        int invert, void *stream);
+
+/* K1 + K2/K3's coordinate pass in one launch, and the gathers on given coordinates: the composed warp field [B,3,G,G,G] is read
+ * exactly once in the reference's flow (by the warp it feeds, model.py:965-973 -> 1154, 1016-1022 -> 1167), which needs only 2*D of
+ * its G depth planes — mphip_warp_field_coords evaluates the same expressions at those planes: bit-identical coordinates
+ * [B,D,G,G,3], no field in HBM.  mphip_warp_volume_coords = K2's gather passes on them (workspace: mphip_warp_workspace_bytes). */
+int mphip_warp_field_coords(const float *theta, const float *em, const float *base_tbl, const float *lin_d, const float *lin_h,
+                            const float *lin_w, float *coords, int B, int eD, int eH, int eW, int G, int D, void *stream);
+int mphip_warp_volume_coords(const float *v, const float *coords, float *out, float *out_range, int B, int C, int D, int H, int W,
+                             void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------ demand-driven evaluation of a gather's producer
  * G3d's last conv feeds apply_warping_field + torch.sum(dim=2) (model.py:1160 -> 1167-1171): a gather whose sample positions

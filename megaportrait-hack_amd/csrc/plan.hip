@@ -456,17 +456,27 @@ T5 flowfield(Ctx &c, FlowFieldW &ff, const float *gamma, const float *z, const f
     return em;
 }
 
-// _WarpGenerator.forward (model.py:927-1024) -> warp field [B,3,G,G,G]
-T5 warp_generator(Ctx &c, Generator &g, const float *R, const float *t, const float *z, const float *e, int B) {
+// _WarpGenerator.forward (model.py:927-1024) followed by the coordinate pass of the warp its field feeds (model.py:1036-1058):
+// -> clipped sample positions [B,D,H,W,3].  When the volume's H, W equal the field's grid (64: the reference's size) the field
+// itself is never written: compose + resize + coordinate chain run as one kernel on the 2*D planes the resize touches.
+Buf generator_coords(Ctx &c, Generator &g, const float *R, const float *t, const float *z, const float *e, int B) {
+    Plan *p = c.p;
     T5 em = flowfield(c, g.ff, g.gamma, z, e, B);
     Buf theta = take(c, (size_t)B * 12 * sizeof(float));
     RUN(c, mphip_rt_theta(R, t, theta.p, B, g.invert, c.s));
-    const int G = c.p->G;
-    T5 wf = new_t5(c, B, 3, G, G, G, false);
-    RUN(c, mphip_warp_field_compose(theta.p, em.data.p, c.p->aff_base, wf.data.p, nullptr, nullptr, B, em.d, em.h, em.w, G, c.s));
+    const int G = p->G;
+    Buf coords = take(c, (size_t)B * p->D * p->H * p->W * 3 * sizeof(float));
+    if (p->H == G && p->W == G) {
+        RUN(c, mphip_warp_field_coords(theta.p, em.data.p, p->aff_base, p->lin_d, p->lin_h, p->lin_w, coords.p, B, em.d, em.h, em.w, G, p->D, c.s));
+    } else {
+        T5 wf = new_t5(c, B, 3, G, G, G, false);
+        RUN(c, mphip_warp_field_compose(theta.p, em.data.p, p->aff_base, wf.data.p, nullptr, nullptr, B, em.d, em.h, em.w, G, c.s));
+        RUN(c, mphip_warp_coords(wf.data.p, p->lin_d, p->lin_h, p->lin_w, coords.p, B, p->D, p->H, p->W, G, G, G, c.s));
+        give(c, wf);
+    }
     give(c, theta);
     give(c, em);
-    return wf;
+    return coords;
 }
 
 // ResBlock3D._forward, inference branch (model.py:500-528); consumes x.  `hook`: called right after conv1 was launched.
@@ -587,16 +597,12 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
         }
     }
     // side stream: C2D field, then K3's coordinate pass and the per-frame box of voxels it will read (demand-driven final_conv)
-    T5 w_c2d;
     Buf coords, box;
     bool c2d_issued = false;
     auto issue_c2d = [&] {
         if (c2d_issued) return;
         c2d_issued = true;
-        w_c2d = warp_generator(cs, p->c2d, Rd, td, zd, es, B);
-        coords = take(cs, (size_t)B * p->D * p->H * p->W * 3 * sizeof(float));
-        RUN(cs, mphip_warp_coords(w_c2d.data.p, p->lin_d, p->lin_h, p->lin_w, coords.p, B, p->D, p->H, p->W, p->G, p->G, p->G, cs.s));
-        give(cs, w_c2d);
+        coords = generator_coords(cs, p->c2d, Rd, td, zd, es, B);
         if (p->demand) {
             box = take(cs, (size_t)B * 8 * sizeof(int));
             RUN(cs, mphip_warp_sample_box(coords.p, (int *)box.p, B, p->D, p->H, p->W, cs.s));
@@ -608,16 +614,15 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
     // chains of tiny kernels run side by side while the GPU is otherwise idle.  With the full tail the old order stands:
     // critical path first, the C2D generator's ~25 launches behind G3d's first conv.
     if (p->demand && overlap) issue_c2d();
-    T5 w_s2c = warp_generator(cm, p->s2c, Rs, ts, zs, es, B);
+    Buf c_s2c = generator_coords(cm, p->s2c, Rs, ts, zs, es, B);
     T5 vc = new_t5(cm, B, p->C, p->D, p->H, p->W, true);
     {
-        const size_t wsb = mphip_warp_workspace_bytes(B, p->D, p->H, p->W);
+        const size_t wsb = mphip_warp_workspace_bytes(B, p->D, p->H, p->W);   // (covers the per-tile marks of the gather passes)
         Buf ws = take(cm, wsb);
-        RUN(cm, mphip_warp_volume(vs, w_s2c.data.p, p->lin_d, p->lin_h, p->lin_w, vc.data.p, nullptr, nullptr, vc.range.p, B, p->C, p->D, p->H, p->W,
-                                  p->G, p->G, p->G, ws.p, wsb, s));
+        RUN(cm, mphip_warp_volume_coords(vs, c_s2c.p, vc.data.p, vc.range.p, B, p->C, p->D, p->H, p->W, ws.p, wsb, s));
         give(cm, ws);
     }
-    give(cm, w_s2c);
+    give(cm, c_s2c);
     int join_rc = MPHIP_OK;
     auto tail = [&]() -> Roi {   // the boxes are needed from here on: join the side stream before G3d's last upsample
         if (overlap && (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)) {

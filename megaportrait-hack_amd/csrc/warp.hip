@@ -70,6 +70,53 @@ __device__ __forceinline__ Coord3 sample_coord(const float *__restrict__ field, 
     return c;
 }
 
+// K1 + the coordinate pass in one kernel (r03): the warp field [B,3,G,G,G] a generator composes is read exactly once, by the
+// coordinate pass of the warp it feeds, which only needs the 2 x D of its G depth planes the align_corners=True resize touches.
+// One thread per (b,d,h,w) of the (D,G,G) volume evaluates warp_field_compose_kernel's expression at the two source planes and
+// warp_coords_kernel<INPLANE>'s chain on them — the same operations in the same order: bit-identical coordinates, without the
+// 2 x 25 MB round trip and one launch less on the latency-bound chain.
+__device__ __forceinline__ float compose_value(const float *__restrict__ th /* theta[b][j] */, const float *__restrict__ emj, float x, float y,
+                                               float z, int eH, int eW, const SrcIdx &sd, const SrcIdx &sh, const SrcIdx &sw) {
+    float acc = x * th[0];
+    acc = fmaf(y, th[1], acc);
+    acc = fmaf(z, th[2], acc);
+    acc = fmaf(1.0f, th[3], acc);
+    return acc + trilerp(emj, eH, eW, sd, sh, sw);
+}
+
+__global__ void __launch_bounds__(256)
+warp_field_coords_kernel(const float *__restrict__ theta, const float *__restrict__ em, const float *__restrict__ base,
+                         const float *__restrict__ lin_d, const float *__restrict__ lin_h, const float *__restrict__ lin_w,
+                         float *__restrict__ coords, int B, int eD, int eH, int eW, int G, int D) {
+    MPHIP_LATENCY_KERNEL_PRIO();
+    const size_t n = (size_t)B * D * G * G;
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const int w = (int)(t % G);
+    size_t r = t / G;
+    const int h = (int)(r % G);
+    r /= G;
+    const int d = (int)(r % D);
+    const int b = (int)(r / D);
+    const SrcIdx sd = src_index<true>(d, G, D);   // the field's depth planes this output slice blends (warp_coords_kernel<true>)
+    const float x = base[w], y = base[h];
+    const SrcIdx eh = src_index<false>(h, eH, G), ew = src_index<false>(w, eW, G);
+    const SrcIdx e0 = src_index<false>(sd.i0, eD, G), e1 = src_index<false>(sd.i1, eD, G);
+    const float z0 = base[sd.i0], z1 = base[sd.i1];
+    float f[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const float *th = theta + ((size_t)b * 3 + j) * 4;
+        const float *emj = em + ((size_t)b * 3 + j) * eD * eH * eW;
+        const float f0 = compose_value(th, emj, x, y, z0, eH, eW, e0, eh, ew);
+        const float f1 = compose_value(th, emj, x, y, z1, eH, eW, e1, eh, ew);
+        f[j] = lerp2(sd.l0, f0, sd.l1, f1);
+    }
+    coords[t * 3] = coord_axis(lin_w[w], f[0], (float)(G - 1));
+    coords[t * 3 + 1] = coord_axis(lin_h[h], f[1], (float)(G - 1));
+    coords[t * 3 + 2] = coord_axis(lin_d[d], f[2], (float)(D - 1));
+}
+
 // 8-tap trilinear gather set-up for one voxel: base offset of the (z0,y0,x0) corner, the deltas
 // to the +1 corners (0 when that corner is outside: ATen skips it, its weight is 0 there), and
 // the 8 corner weights in ATen's accumulation order tnw,tne,tsw,tse,bnw,bne,bsw,bse.
@@ -688,6 +735,9 @@ static int launch_coords(const float *field, const float *lin_d, const float *li
     return check_launch("warp_coords");
 }
 
+static int warp_volume_gather(const float *v, const float *coords, float *out, float *out_range, int *todo, int B, int C, int D, int H, int W,
+                              hipStream_t s);
+
 extern "C" int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
                                  const float *lin_w, float *out, float *coords_out, int32_t *idx_out, float *out_range, int B,
                                  int C, int D, int H, int W, int fD, int fH, int fW, void *workspace, size_t workspace_bytes,
@@ -705,6 +755,13 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     hipStream_t s = (hipStream_t)stream;
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
+    return warp_volume_gather(v, coords, out, out_range, todo, B, C, D, H, W, s);
+}
+
+// the gather pass(es) of K2 on given coordinates; todo: one int per 32x32 tile
+static int warp_volume_gather(const float *v, const float *coords, float *out, float *out_range, int *todo, int B, int C, int D, int H, int W,
+                              hipStream_t s) {
+    int rc;
     const size_t nblocks = k2_tiles(B, D, H, W);
     if (out_range && (W % 4 != 0 || nblocks > RANGE_MAX_PARTS)) {
         // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
@@ -749,6 +806,33 @@ static int warp_volume_dsum_impl(const char *name, const float *v, size_t v_fram
     hipLaunchKernelGGL(warp_gather_dsum_kernel<CPB>, dim3((unsigned)((size_t)B * tiles * cdiv(C, CPB))), dim3(256), 0, s, v,
                        coords, out, B, C, D, H, W, v_frame_stride);
     return check_launch(name);
+}
+
+// K1 + the coordinate pass fused (warp_field_coords_kernel): theta [B,3,4], em [B,3,eD,eH,eW] -> coords [B,D,G,G,3] of the warp of a
+// (D,G,G) volume by the composed field — bit-identical to mphip_warp_field_compose + mphip_warp_coords, the field never exists.
+extern "C" int mphip_warp_field_coords(const float *theta, const float *em, const float *base_tbl, const float *lin_d, const float *lin_h,
+                                       const float *lin_w, float *coords, int B, int eD, int eH, int eW, int G, int D, void *stream) {
+    MPHIP_REQUIRE(theta && em && base_tbl && lin_d && lin_h && lin_w && coords, "warp_field_coords: null pointer");
+    MPHIP_REQUIRE(B > 0 && eD > 0 && eH > 0 && eW > 0 && G > 0 && D > 0, "warp_field_coords: bad dims");
+    const size_t n = (size_t)B * D * G * G;
+    hipLaunchKernelGGL(warp_field_coords_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, theta, em, base_tbl, lin_d, lin_h, lin_w,
+                       coords, B, eD, eH, eW, G, D);
+    return check_launch("warp_field_coords");
+}
+
+// K2 on given coordinates (mphip_warp_coords / mphip_warp_field_coords); workspace: one int per 32x32 tile
+// (mphip_warp_workspace_bytes covers it).
+extern "C" int mphip_warp_volume_coords(const float *v, const float *coords, float *out, float *out_range, int B, int C, int D, int H, int W,
+                                        void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(v && coords && out, "warp_volume_coords: null pointer");
+    MPHIP_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "warp_volume_coords: bad dims");
+    MPHIP_REQUIRE((size_t)D * H * W < (1u << 30), "warp_volume_coords: volume too large for 32-bit tap offsets");
+    const size_t need = ((k2_tiles(B, D, H, W) * sizeof(int) + 15) / 16) * 16;
+    if (!workspace || workspace_bytes < need) {
+        set_error("warp_volume_coords: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    return warp_volume_gather(v, coords, out, out_range, (int *)workspace, B, C, D, H, W, (hipStream_t)stream);
 }
 
 // K3 with the coordinate pass already done (mphip_warp_coords): lets a caller look at the sample positions BEFORE the volume is

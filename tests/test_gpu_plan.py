@@ -282,3 +282,26 @@ def test_demand_driven_conv_backward_equals_the_full_backward(dev, shape):
     dw_full = ops.conv3d_bwd_weight(x, dy, 3, scale, x_range=rng)
     dw_roi = ops.conv3d_bwd_weight(x, dy, 3, scale, x_range=rng, roi=boxes)
     assert torch.equal(dw_roi, dw_full)
+
+
+@pytest.mark.parametrize("D", [16, 8, 4])
+def test_fused_field_coords_equal_compose_plus_coords_bitwise(dev, D):
+    """mphip_warp_field_coords (K1 + the coordinate pass in one kernel, no field in HBM) gives exactly the coordinates of
+    mphip_warp_field_compose -> mphip_warp_coords — the index contract (bit-exact flow-field index computation) is unchanged."""
+    import ctypes
+
+    from megaportrait_hack_amd import _lib, ops
+
+    lib = _lib.load()
+    P = ctypes.c_void_p
+    B, G = 3, 64
+    theta = (R.seeded_tensor((B, 3, 4), 71) * 0.8).to(dev)
+    em = R.seeded_tensor((B, 3, 16, 16, 16), 72).abs().to(dev)
+    field = ops.warp_field_compose(theta, em, G)
+    want = ops.warp_coords(field, D, G, G)
+    got = torch.full_like(want, float("nan"))
+    _lib.check(lib.mphip_warp_field_coords(P(theta.data_ptr()), P(em.data_ptr()), P(ops.affine_base_table(G, dev).data_ptr()),
+                                           P(ops.linspace_table(D, dev).data_ptr()), P(ops.linspace_table(G, dev).data_ptr()),
+                                           P(ops.linspace_table(G, dev).data_ptr()), P(got.data_ptr()), B, 16, 16, 16, G, D,
+                                           P(torch.cuda.current_stream().cuda_stream)), "mphip_warp_field_coords")
+    assert torch.equal(got, want)
