@@ -394,89 +394,109 @@ ConvOut as_convout(const T5 &x) {   // a plain tensor in ConvOut clothing (not o
     return o;   // (give() ignores it)
 }
 
+// The generator chains are written over L "lanes" (L = 1: one generator on one stream; L = 2: WarpGeneratorS2C on the caller's
+// stream and WarpGeneratorC2D on the side stream, advanced in LOCKSTEP — every step is enqueued for lane 0, then for lane 1).
+// Lockstep is a host-order requirement: the ROCm runtime holds launches that wait on a not-yet-complete cross-stream event — and
+// everything issued after them — in software, and feeds them to the hardware queues one by one (~6 us each) once the event
+// completes.  Issued one chain after the other, ~30 held launches kept the second chain out of its queue for 160-230 us at the
+// start of every step (profiles/r03_timeline_plan_sidefirst.txt); interleaved, both ~0.3 ms chains of tiny latency-bound
+// kernels run side by side from the first microsecond and are done before G3d's first conv takes every register of the chip.
+struct GenLane {
+    Ctx *c;
+    Generator *g;
+    const float *R, *t, *z, *e;
+};
+
 // ResBlock3D_Adaptive._forward, inference branch (model.py:369-408); consumes x
-T5 resblock_ada(Ctx &c, ResBlockAda &b, T5 &x, int ud, int uh, int uw) {
-    ConvOut y = conv3d_split(c, x, b.conv1, 32);
-    const bool tiny = groupnorm_fused_ok(y, 32);
-    ConvOut y2;
+template <int L>
+void resblock_ada(GenLane (&ln)[L], int blk, T5 (&x)[L], int ud, int uh, int uw) {
+    ConvOut y[L], y2[L], res[L];
+    T5 a[L], out[L];
+    ResBlockAda *b[L];
+    for (int l = 0; l < L; ++l) b[l] = &ln[l].g->ff.rb[blk];
+    for (int l = 0; l < L; ++l) y[l] = conv3d_split(*ln[l].c, x[l], b[l]->conv1, 32);
+    const bool tiny = groupnorm_fused_ok(y[0], 32);   // (shape decisions are the same on every lane: same batch, same layer)
     if (tiny) {
-        T5 a = groupnorm_small(c, y, b.n1, 32, nullptr, true, false, 1, 1, 1);
-        give(c, y);
-        y2 = conv3d_split(c, a, b.conv2, 0);
-        give(c, a);
+        for (int l = 0; l < L; ++l) { a[l] = groupnorm_small(*ln[l].c, y[l], b[l]->n1, 32, nullptr, true, false, 1, 1, 1); give(*ln[l].c, y[l]); }
+        for (int l = 0; l < L; ++l) { y2[l] = conv3d_split(*ln[l].c, a[l], b[l]->conv2, 0); give(*ln[l].c, a[l]); }
     } else {
-        ensure_stats(c, y, 32);
-        if (y.splits == 1 && gn_in_conv_ok(c, y, b.conv2)) {
-            y2 = conv3d_gn_in(c, y, b.n1, 32, b.conv2, 32);
-            give(c, y);
+        for (int l = 0; l < L; ++l) ensure_stats(*ln[l].c, y[l], 32);
+        if (y[0].splits == 1 && gn_in_conv_ok(*ln[0].c, y[0], b[0]->conv2)) {
+            for (int l = 0; l < L; ++l) { y2[l] = conv3d_gn_in(*ln[l].c, y[l], b[l]->n1, 32, b[l]->conv2, 32); give(*ln[l].c, y[l]); }
         } else {
-            T5 a = groupnorm_apply(c, y, b.n1, 32, nullptr, true, false, false, 1, 1, 1);
-            give(c, y);
-            y2 = conv3d_split(c, a, b.conv2, 32);
-            give(c, a);
+            for (int l = 0; l < L; ++l) { a[l] = groupnorm_apply(*ln[l].c, y[l], b[l]->n1, 32, nullptr, true, false, false, 1, 1, 1); give(*ln[l].c, y[l]); }
+            for (int l = 0; l < L; ++l) { y2[l] = conv3d_split(*ln[l].c, a[l], b[l]->conv2, 32); give(*ln[l].c, a[l]); }
         }
     }
-    ConvOut res = b.identity ? as_convout(x) : conv3d_split(c, x, b.res, 0);
-    T5 out;
+    for (int l = 0; l < L; ++l) res[l] = b[l]->identity ? as_convout(x[l]) : conv3d_split(*ln[l].c, x[l], b[l]->res, 0);
     if (tiny) {
-        out = groupnorm_small(c, y2, b.n2, 32, &res, true, false, ud, uh, uw);
+        for (int l = 0; l < L; ++l) out[l] = groupnorm_small(*ln[l].c, y2[l], b[l]->n2, 32, &res[l], true, false, ud, uh, uw);
     } else {
-        ensure_stats(c, y2, 32);
-        out = groupnorm_apply(c, y2, b.n2, 32, &res, true, false, false, ud, uh, uw);
+        for (int l = 0; l < L; ++l) ensure_stats(*ln[l].c, y2[l], 32);
+        for (int l = 0; l < L; ++l) out[l] = groupnorm_apply(*ln[l].c, y2[l], b[l]->n2, 32, &res[l], true, false, false, ud, uh, uw);
     }
-    give(c, y2);
-    if (!b.identity) give(c, res);
-    give(c, x);
-    return out;
+    for (int l = 0; l < L; ++l) {
+        give(*ln[l].c, y2[l]);
+        if (!b[l]->identity) give(*ln[l].c, res[l]);
+        give(*ln[l].c, x[l]);
+        x[l] = out[l];
+    }
 }
 
-// FlowField.forward_from_codes (model.py:945-957 + 415-471): (z, e) [B,512] -> em [B,3,16,16,16]
-T5 flowfield(Ctx &c, FlowFieldW &ff, const float *gamma, const float *z, const float *e, int B) {
+// _WarpGenerator.forward (model.py:927-1024: FlowField((z+e) @ Gamma), compute_rt_warp, compose) followed by the coordinate pass of
+// the warp its field feeds (model.py:1036-1058) -> clipped sample positions [B,D,H,W,3].  When the volume's H, W equal the
+// field's grid (64: the reference's size) the field itself is never written: compose + resize + coordinate chain run as one
+// kernel on the 2*D planes the resize touches (mphip_warp_field_coords).
+template <int L>
+void generator_coords(GenLane (&ln)[L], int B, Buf (&coords)[L]) {
     static const int UPS[4][3] = {{2, 2, 2}, {2, 2, 2}, {1, 2, 2}, {1, 2, 2}};
-    if (!c.dry && !ff.kn_fresh) {
-        // conv1x1.weight [2048][512] -> [K=512][N=2048], then Gamma @ that: (z+e)@Gamma followed by the 1x1 conv is one linear map
-        hipLaunchKernelGGL(transpose_kernel, dim3(512 / 32, 2048 / 32), dim3(256), 0, c.s, ff.w1x1, ff.w1x1_kn, 2048, 512);
-        if (c.rc == MPHIP_OK) c.rc = check_launch("hot_slice(transpose conv1x1)");
-        RUN(c, mphip_small_gemm(gamma, nullptr, ff.w1x1_kn, nullptr, ff.w_head, 512, 2048, 512, 512, 1, 2048, 1, c.s));
-        ff.kn_fresh = true;
-    }
-    T5 x = new_t5(c, B, 512, 4, 1, 1, false);   // [B,2048] viewed as [B,512,4,1,1] (model.py:425)
-    RUN(c, mphip_add_matmul(z, e, ff.w_head, ff.b1x1, x.data.p, B, 512, 2048, 0, c.s));
-    for (int i = 0; i < 4; ++i) x = resblock_ada(c, ff.rb[i], x, UPS[i][0], UPS[i][1], UPS[i][2]);
-    ConvOut y = conv3d_split(c, x, ff.conv_out, 0);
-    give(c, x);
-    T5 em;
-    if (groupnorm_fused_ok(y, 1)) {
-        em = groupnorm_small(c, y, ff.gn, 1, nullptr, true, true, 1, 1, 1);
-    } else {
-        ensure_stats(c, y, 1);
-        em = groupnorm_apply(c, y, ff.gn, 1, nullptr, true, true, false, 1, 1, 1);
-    }
-    give(c, y);
-    return em;
-}
-
-// _WarpGenerator.forward (model.py:927-1024) followed by the coordinate pass of the warp its field feeds (model.py:1036-1058):
-// -> clipped sample positions [B,D,H,W,3].  When the volume's H, W equal the field's grid (64: the reference's size) the field
-// itself is never written: compose + resize + coordinate chain run as one kernel on the 2*D planes the resize touches.
-Buf generator_coords(Ctx &c, Generator &g, const float *R, const float *t, const float *z, const float *e, int B) {
-    Plan *p = c.p;
-    T5 em = flowfield(c, g.ff, g.gamma, z, e, B);
-    Buf theta = take(c, (size_t)B * 12 * sizeof(float));
-    RUN(c, mphip_rt_theta(R, t, theta.p, B, g.invert, c.s));
+    Plan *p = ln[0].c->p;
     const int G = p->G;
-    Buf coords = take(c, (size_t)B * p->D * p->H * p->W * 3 * sizeof(float));
-    if (p->H == G && p->W == G) {
-        RUN(c, mphip_warp_field_coords(theta.p, em.data.p, p->aff_base, p->lin_d, p->lin_h, p->lin_w, coords.p, B, em.d, em.h, em.w, G, p->D, c.s));
-    } else {
-        T5 wf = new_t5(c, B, 3, G, G, G, false);
-        RUN(c, mphip_warp_field_compose(theta.p, em.data.p, p->aff_base, wf.data.p, nullptr, nullptr, B, em.d, em.h, em.w, G, c.s));
-        RUN(c, mphip_warp_coords(wf.data.p, p->lin_d, p->lin_h, p->lin_w, coords.p, B, p->D, p->H, p->W, G, G, G, c.s));
-        give(c, wf);
+    T5 x[L], em[L];
+    ConvOut y[L];
+    Buf theta[L];
+    for (int l = 0; l < L; ++l) {
+        Ctx &c = *ln[l].c;
+        FlowFieldW &ff = ln[l].g->ff;
+        if (!c.dry && !ff.kn_fresh) {
+            // conv1x1.weight [2048][512] -> [K=512][N=2048], then Gamma @ that: (z+e)@Gamma followed by the 1x1 conv is one linear map
+            hipLaunchKernelGGL(transpose_kernel, dim3(512 / 32, 2048 / 32), dim3(256), 0, c.s, ff.w1x1, ff.w1x1_kn, 2048, 512);
+            if (c.rc == MPHIP_OK) c.rc = check_launch("hot_slice(transpose conv1x1)");
+            RUN(c, mphip_small_gemm(ln[l].g->gamma, nullptr, ff.w1x1_kn, nullptr, ff.w_head, 512, 2048, 512, 512, 1, 2048, 1, c.s));
+            ff.kn_fresh = true;
+        }
+        x[l] = new_t5(c, B, 512, 4, 1, 1, false);   // [B,2048] viewed as [B,512,4,1,1] (model.py:425)
+        RUN(c, mphip_add_matmul(ln[l].z, ln[l].e, ff.w_head, ff.b1x1, x[l].data.p, B, 512, 2048, 0, c.s));
     }
-    give(c, theta);
-    give(c, em);
-    return coords;
+    for (int i = 0; i < 4; ++i) resblock_ada<L>(ln, i, x, UPS[i][0], UPS[i][1], UPS[i][2]);
+    for (int l = 0; l < L; ++l) { y[l] = conv3d_split(*ln[l].c, x[l], ln[l].g->ff.conv_out, 0); give(*ln[l].c, x[l]); }
+    if (groupnorm_fused_ok(y[0], 1)) {
+        for (int l = 0; l < L; ++l) em[l] = groupnorm_small(*ln[l].c, y[l], ln[l].g->ff.gn, 1, nullptr, true, true, 1, 1, 1);
+    } else {
+        for (int l = 0; l < L; ++l) ensure_stats(*ln[l].c, y[l], 1);
+        for (int l = 0; l < L; ++l) em[l] = groupnorm_apply(*ln[l].c, y[l], ln[l].g->ff.gn, 1, nullptr, true, true, false, 1, 1, 1);
+    }
+    for (int l = 0; l < L; ++l) give(*ln[l].c, y[l]);
+    for (int l = 0; l < L; ++l) {
+        Ctx &c = *ln[l].c;
+        theta[l] = take(c, (size_t)B * 12 * sizeof(float));
+        RUN(c, mphip_rt_theta(ln[l].R, ln[l].t, theta[l].p, B, ln[l].g->invert, c.s));
+    }
+    for (int l = 0; l < L; ++l) {
+        Ctx &c = *ln[l].c;
+        coords[l] = take(c, (size_t)B * p->D * p->H * p->W * 3 * sizeof(float));
+        if (p->H == G && p->W == G) {
+            RUN(c, mphip_warp_field_coords(theta[l].p, em[l].data.p, p->aff_base, p->lin_d, p->lin_h, p->lin_w, coords[l].p, B, em[l].d, em[l].h, em[l].w,
+                                           G, p->D, c.s));
+        } else {
+            T5 wf = new_t5(c, B, 3, G, G, G, false);
+            RUN(c, mphip_warp_field_compose(theta[l].p, em[l].data.p, p->aff_base, wf.data.p, nullptr, nullptr, B, em[l].d, em[l].h, em[l].w, G, c.s));
+            RUN(c, mphip_warp_coords(wf.data.p, p->lin_d, p->lin_h, p->lin_w, coords[l].p, B, p->D, p->H, p->W, G, G, G, c.s));
+            give(c, wf);
+        }
+        give(c, theta[l]);
+        give(c, em[l]);
+    }
 }
 
 // ResBlock3D._forward, inference branch (model.py:500-528); consumes x.  `hook`: called right after conv1 was launched.
@@ -596,25 +616,41 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
             return MPHIP_ELAUNCH;
         }
     }
-    // side stream: C2D field, then K3's coordinate pass and the per-frame box of voxels it will read (demand-driven final_conv)
-    Buf coords, box;
+    // the two generators.  Demand-driven tail: the C2D boxes must exist before G3d's LAST upsample, so the C2D chain cannot hide
+    // under final_conv any more (G3d's persistent conv workgroups own every register of a CU: a side-stream kernel only runs in
+    // the gaps between conv launches) — it runs beside the equally latency-bound S2C chain, in lockstep (see GenLane).  With the
+    // full tail the old order stands: critical path first, the C2D generator's ~25 launches behind G3d's first conv.
+    Buf coords, box, c_s2c;
     bool c2d_issued = false;
-    auto issue_c2d = [&] {
-        if (c2d_issued) return;
-        c2d_issued = true;
-        coords = generator_coords(cs, p->c2d, Rd, td, zd, es, B);
+    auto finish_c2d = [&] {   // the per-frame box of voxels K3 will read (demand-driven final_conv)
         if (p->demand) {
             box = take(cs, (size_t)B * 8 * sizeof(int));
             RUN(cs, mphip_warp_sample_box(coords.p, (int *)box.p, B, p->D, p->H, p->W, cs.s));
         }
     };
-    // Demand-driven tail: the boxes must exist before G3d's LAST upsample, so the C2D chain can no longer hide under final_conv
-    // (G3d's persistent conv workgroups own every register of a CU: a side-stream kernel only runs in the gaps between conv
-    // launches).  It is issued FIRST, next to the equally latency-bound S2C chain on the caller's stream — the two ~0.3 ms
-    // chains of tiny kernels run side by side while the GPU is otherwise idle.  With the full tail the old order stands:
-    // critical path first, the C2D generator's ~25 launches behind G3d's first conv.
-    if (p->demand && overlap) issue_c2d();
-    Buf c_s2c = generator_coords(cm, p->s2c, Rs, ts, zs, es, B);
+    auto issue_c2d = [&] {
+        if (c2d_issued) return;
+        c2d_issued = true;
+        GenLane one[1] = {{&cs, &p->c2d, Rd, td, zd, es}};
+        Buf out1[1];
+        generator_coords<1>(one, B, out1);
+        coords = out1[0];
+        finish_c2d();
+    };
+    if (p->demand && overlap) {
+        GenLane two[2] = {{&cm, &p->s2c, Rs, ts, zs, es}, {&cs, &p->c2d, Rd, td, zd, es}};
+        Buf out2[2];
+        generator_coords<2>(two, B, out2);
+        c_s2c = out2[0];
+        coords = out2[1];
+        c2d_issued = true;
+        finish_c2d();
+    } else {
+        GenLane one[1] = {{&cm, &p->s2c, Rs, ts, zs, es}};
+        Buf out1[1];
+        generator_coords<1>(one, B, out1);
+        c_s2c = out1[0];
+    }
     T5 vc = new_t5(cm, B, p->C, p->D, p->H, p->W, true);
     {
         const size_t wsb = mphip_warp_workspace_bytes(B, p->D, p->H, p->W);   // (covers the per-tile marks of the gather passes)

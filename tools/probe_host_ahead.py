@@ -1,10 +1,9 @@
-"""dev: N steps of the hot slice through the C-side plan (for rocprofv3 traces): run_plan_steps.py [B] [steps]"""
-import sys, os
+"""dev: is the host ahead of the GPU in the plan's steady state?  Host time per forward call without synchronisation."""
+import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from megaportrait_hack_amd import model as M
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+B = 8
 dev = torch.device("cuda:0")
 torch.manual_seed(20240501)
 hot = M.GbaseHotSlice().to(dev).eval()
@@ -13,10 +12,18 @@ inp = dict(vs=torch.randn(B, 96, 16, 64, 64, generator=g), es=torch.randn(B, 512
            zd=torch.randn(B, 512, generator=g), Rs=(torch.rand(B, 3, generator=g) * 60 - 30), Rd=(torch.rand(B, 3, generator=g) * 60 - 30),
            ts=torch.randn(B, 3, generator=g) * 0.1, td=torch.randn(B, 3, generator=g) * 0.1)
 inp = {k: v.to(dev) for k, v in inp.items()}
-use_stream = len(sys.argv) > 3 and sys.argv[3] == "stream"
-st = torch.cuda.Stream() if use_stream else torch.cuda.current_stream()
-with torch.no_grad(), torch.cuda.stream(st):
-    for _ in range(steps):
+with torch.no_grad():
+    for _ in range(5):
+        hot(**inp)
+    torch.cuda.synchronize()
+    ts = []
+    t_all = time.perf_counter()
+    for _ in range(20):
+        t0 = time.perf_counter()
         out = hot(**inp)
-torch.cuda.synchronize()
-print("ok", float(out.abs().mean()))
+        ts.append((time.perf_counter() - t0) * 1e3)
+    t_issue = (time.perf_counter() - t_all) * 1e3
+    torch.cuda.synchronize()
+    t_total = (time.perf_counter() - t_all) * 1e3
+print("host ms per call:", " ".join(f"{t:.2f}" for t in ts))
+print(f"issue of 20 steps took {t_issue:.1f} ms, GPU finished after {t_total:.1f} ms")
