@@ -11,6 +11,7 @@
 // The launches are the SAME kernels in the SAME order as the Python inference path (model.py `_HotSliceRunner._run`): the
 // results are bitwise identical, which is how tests/test_gpu_plan.py pins it.  Inference only (training keeps the
 // autograd Functions).  Host code; the only kernel here transposes the FlowField 1x1 conv weight.
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -610,11 +611,22 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
     p->side_arena.reset(dry ? nullptr : (char *)workspace + main_bytes, dry ? 0 : side_bytes, dry);
     Ctx cm{p, &p->main_arena, s, dry};
     Ctx cs{p, &p->side_arena, overlap ? p->side : s, dry};
-    if (overlap) {   // fork: inputs produced on the caller's stream are visible to the side stream
-        if (hipEventRecord(p->ev_fork, s) != hipSuccess || hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) {
+    // fork: inputs produced on the caller's stream are visible to the side stream.  The event is RECORDED here; the side stream's
+    // wait on it is issued later (fork_wait), after the caller-stream launches that should not queue up behind it (see GenLane)
+    static const int order = getenv("MPHIP_PLAN_CHAIN_ORDER") ? atoi(getenv("MPHIP_PLAN_CHAIN_ORDER")) : 0;   // dev A/B: 0 lockstep (default), 1 S2C chain first, then wait + C2D chain (measured equal within 0.5 %)
+    bool fork_waited = false;
+    auto fork_wait = [&]() -> bool {
+        if (!overlap || fork_waited) return true;
+        fork_waited = true;
+        if (hipStreamWaitEvent(p->side, p->ev_fork, 0) != hipSuccess) {
             set_error("hot_slice_forward: stream fork failed: %s", hipGetErrorString(hipGetLastError()));
-            return MPHIP_ELAUNCH;
+            return false;
         }
+        return true;
+    };
+    if (overlap && hipEventRecord(p->ev_fork, s) != hipSuccess) {
+        set_error("hot_slice_forward: stream fork failed: %s", hipGetErrorString(hipGetLastError()));
+        return MPHIP_ELAUNCH;
     }
     // the two generators.  Demand-driven tail: the C2D boxes must exist before G3d's LAST upsample, so the C2D chain cannot hide
     // under final_conv any more (G3d's persistent conv workgroups own every register of a CU: a side-stream kernel only runs in
@@ -631,13 +643,23 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
     auto issue_c2d = [&] {
         if (c2d_issued) return;
         c2d_issued = true;
+        if (!fork_wait()) { cs.rc = MPHIP_ELAUNCH; return; }
         GenLane one[1] = {{&cs, &p->c2d, Rd, td, zd, es}};
         Buf out1[1];
         generator_coords<1>(one, B, out1);
         coords = out1[0];
         finish_c2d();
     };
-    if (p->demand && overlap) {
+    if (p->demand && overlap && order == 1) {
+        // the caller-stream chain first — its launches reach their hardware queue ahead of time, nothing in front of them waits —
+        // THEN the side stream's wait and chain, which the runtime feeds in from the moment the step starts
+        GenLane one[1] = {{&cm, &p->s2c, Rs, ts, zs, es}};
+        Buf out1[1];
+        generator_coords<1>(one, B, out1);
+        c_s2c = out1[0];
+        issue_c2d();
+    } else if (p->demand && overlap) {
+        if (!fork_wait()) return MPHIP_ELAUNCH;
         GenLane two[2] = {{&cm, &p->s2c, Rs, ts, zs, es}, {&cs, &p->c2d, Rd, td, zd, es}};
         Buf out2[2];
         generator_coords<2>(two, B, out2);
