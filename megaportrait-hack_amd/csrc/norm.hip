@@ -437,12 +437,9 @@ __device__ __forceinline__ SrcIdx src_index_scaled(int dst, int in, float scale)
 // every output is the same nested W->H->D lerp as the scalar form, so results stay bit-identical.
 __global__ void __launch_bounds__(256)
 upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, int D, int H, int W, float sD, float sH,
-                           float sW, size_t nbricks, const int *__restrict__ roi, int roi_frames, int C, int gD, int gH, int gW,
-                           int groups) {
-  // groups: 256-brick groups per workgroup (1 for the full upsample; 16 for the demand-driven one, where almost every brick
-  // only runs the box test — 12288 workgroups that exit at once cost 70 us of dispatch, 768 that loop cost a tenth)
-  for (int grp = 0; grp < groups; ++grp) {
-    size_t t = ((size_t)blockIdx.x * groups + grp) * blockDim.x + threadIdx.x;
+                           float sW, size_t nbricks) {
+  {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbricks) return;
     const int oH = 2 * H, oW = 2 * W;
     const int bw = W / 2;  // bricks per output row (2W / 4)
@@ -452,20 +449,6 @@ upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, i
     r /= H;
     int kd = (int)(r % D);      // output slices 2kd, 2kd+1
     size_t plane = r / D;
-    if (roi) {
-        // demand-driven (mphip_upsample_trilinear2_roi): only bricks inside the halo of a conv tile (gD x gH x gW output voxels)
-        // that one of the consumer's sample boxes touches are produced — what mphip_conv3d_fwd_roi will read
-        const int first = roi_frames > 0 ? 0 : (int)(plane / C), count = roi_frames > 0 ? roi_frames : 1;
-        bool need = false;
-        for (int f = first; f < first + count && !need; ++f) {
-            const int *b = roi + f * 8;
-            const int wl = (b[0] / gW) * gW - 1, wh = ((b[0] + b[3] - 1) / gW + 1) * gW;   // inclusive range incl. the 1-voxel conv halo
-            const int hl = (b[1] / gH) * gH - 1, hh = ((b[1] + b[4] - 1) / gH + 1) * gH;
-            const int dl = (b[2] / gD) * gD - 1, dh = ((b[2] + b[5] - 1) / gD + 1) * gD;
-            need = 4 * kw + 3 >= wl && 4 * kw <= wh && 2 * kh + 1 >= hl && 2 * kh <= hh && 2 * kd + 1 >= dl && 2 * kd <= dh;
-        }
-        if (!need) continue;
-    }
     const float *p = x + plane * D * H * W;
     SrcIdx sd[2], sh[2], sw[4];
 #pragma unroll
@@ -528,6 +511,67 @@ upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, i
         }
     }
   }
+}
+
+// Demand-driven x2 upsample (mphip_upsample_trilinear2_roi): one workgroup per channel plane walks ONLY the bricks inside the
+// region its frame's sample box needs (the box's conv tiles grown by the 1-voxel conv halo) — a ~5^3 box is ~100 of a plane's
+// 4096 bricks.  (The first version tested every brick of the full launch: 47-74 us of dispatch and index math for 1 % useful work.)
+__global__ void __launch_bounds__(256)
+upsample_trilinear2_roi_kernel(const float *__restrict__ x, float *__restrict__ y, int D, int H, int W, float sD, float sH, float sW,
+                               const int *__restrict__ roi, int roi_frames, int C, int gD, int gH, int gW) {
+    const size_t plane = blockIdx.x;
+    const int first = roi_frames > 0 ? 0 : (int)(plane / C), count = roi_frames > 0 ? roi_frames : 1;
+    // needed output region of this plane: the union of the boxes' regions (its bounding region: a superset is harmless)
+    int wl = 1 << 30, wh = -1, hl = 1 << 30, hh = -1, dl = 1 << 30, dh = -1;
+    for (int f = first; f < first + count; ++f) {
+        const int *b = roi + f * 8;
+        wl = min(wl, (b[0] / gW) * gW - 1); wh = max(wh, ((b[0] + b[3] - 1) / gW + 1) * gW);
+        hl = min(hl, (b[1] / gH) * gH - 1); hh = max(hh, ((b[1] + b[4] - 1) / gH + 1) * gH);
+        dl = min(dl, (b[2] / gD) * gD - 1); dh = max(dh, ((b[2] + b[5] - 1) / gD + 1) * gD);
+    }
+    // -> brick ranges (a brick = output slices 2kd..2kd+1, rows 2kh..2kh+1, columns 4kw..4kw+3)
+    const int kw0 = max(wl, 0) / 4, kw1 = min(wh, 2 * W - 1) / 4, kh0 = max(hl, 0) / 2, kh1 = min(hh, 2 * H - 1) / 2;
+    const int kd0 = max(dl, 0) / 2, kd1 = min(dh, 2 * D - 1) / 2;
+    const int nw = kw1 - kw0 + 1, nh = kh1 - kh0 + 1, nd = kd1 - kd0 + 1;
+    if (nw <= 0 || nh <= 0 || nd <= 0) return;
+    const float *p = x + plane * D * H * W;
+    const int oH = 2 * H, oW = 2 * W;
+    for (int t = threadIdx.x; t < nw * nh * nd; t += 256) {
+        const int kw = kw0 + t % nw, kh = kh0 + (t / nw) % nh, kd = kd0 + t / (nw * nh);
+        SrcIdx sd[2], sh[2], sw[4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            sd[i] = src_index_scaled(2 * kd + i, D, sD);
+            sh[i] = src_index_scaled(2 * kh + i, H, sH);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) sw[i] = src_index_scaled(4 * kw + i, W, sW);
+        // one output at a time, the nested W -> H -> D lerp of the scalar form (bit-identical to the brick kernel's separable
+        // evaluation: the same operand pairs in the same order)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jh = 0; jh < 2; ++jh) {
+                float o[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float hv[2][2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b2 = 0; b2 < 2; ++b2) {
+                            const int sdi = a ? sd[i].i1 : sd[i].i0, shi = b2 ? sh[jh].i1 : sh[jh].i0;
+                            const float *row = p + ((size_t)sdi * H + shi) * W;
+                            hv[a][b2] = lerp2(sw[c].l0, row[sw[c].i0], sw[c].l1, row[sw[c].i1]);
+                        }
+                    const float d0v = lerp2(sh[jh].l0, hv[0][0], sh[jh].l1, hv[0][1]);
+                    const float d1v = lerp2(sh[jh].l0, hv[1][0], sh[jh].l1, hv[1][1]);
+                    o[c] = lerp2(sd[i].l0, d0v, sd[i].l1, d1v);
+                }
+                float *dst = y + ((plane * 2 * D + 2 * kd + i) * oH + 2 * kh + jh) * (size_t)oW + 4 * kw;
+                *reinterpret_cast<float4 *>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            }
+    }
 }
 
 // generic (odd W) fallback: one output per thread
@@ -909,7 +953,7 @@ extern "C" int mphip_upsample_trilinear2(const float *x, float *y, int NC, int D
         // (an LDS-staged variant of this kernel — 7 coalesced staging loads per thread instead of 36 scalar ones — measured
         //  +-0 on the 201 MB upsample, r03: the kernel is bound by its write stream, not by load issue)
         hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 16, 256)), dim3(256), 0, (hipStream_t)stream, x, y, D,
-                           H, W, sD, sH, sW, total / 16, (const int *)nullptr, 0, 1, 1, 1, 1, 1);
+                           H, W, sD, sH, sW, total / 16);
     } else {
         hipLaunchKernelGGL(upsample_trilinear2_scalar_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y,
                            D, H, W, total);
@@ -928,8 +972,9 @@ extern "C" int mphip_upsample_trilinear2_roi(const float *x, float *y, const int
     const float sD = 2 * D > 1 ? (float)(D - 1) / (float)(2 * D - 1) : 0.0f;
     const float sH = 2 * H > 1 ? (float)(H - 1) / (float)(2 * H - 1) : 0.0f;
     const float sW = 2 * W > 1 ? (float)(W - 1) / (float)(2 * W - 1) : 0.0f;
-    hipLaunchKernelGGL(upsample_trilinear2_kernel, dim3(cdiv(total / 16, 256 * 16)), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W, sD, sH, sW,
-                       total / 16, roi, roi_frames, C, tD, tH, tW, 16);
+    (void)total;
+    hipLaunchKernelGGL(upsample_trilinear2_roi_kernel, dim3((unsigned)((size_t)N * C)), dim3(256), 0, (hipStream_t)stream, x, y, D, H, W, sD, sH,
+                       sW, roi, roi_frames, C, tD, tH, tW);
     return check_launch("upsample_trilinear2_roi");
 }
 
