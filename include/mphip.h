@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 6
+#define MPHIP_ABI_VERSION 7
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -149,6 +149,14 @@ int mphip_conv3d_gn_fwd(const float *x, const float *x_range, const void *w_pack
 int mphip_groupnorm_affine_table(const float *stats, const float *gamma, const float *beta, const float *w2,
                                  const float *b2, float *table, float *out_range, int N, int C, int S, int G,
                                  void *stream);
+/* conv + statistics + the affine table / range bound of the norm that follows, in one call (saves the table launch per block) */
+int mphip_conv3d_gn_table_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, float *gn_stats,
+                              const float *gamma, const float *beta, const float *w2, const float *b2, float *table, float *table_range,
+                              int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups, float gn_eps,
+                              void *workspace, size_t workspace_bytes, void *stream);
+/* measurement: the next conv launch on this thread is bracketed by these two HIP events (hipEvent_t), recorded on the launch stream
+ * right before / after the conv kernel itself */
+void mphip_conv3d_time_next_launch(void *event_begin, void *event_end);
 int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,
                           const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,
                           int precision, void *workspace, size_t workspace_bytes, void *stream);

@@ -37,6 +37,8 @@ SIGNATURES = {
     "mphip_conv3d_fwd": (_i, [_p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_conv3d_gn_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i, _i, _i]),
     "mphip_conv3d_gn_fwd": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _i, ctypes.c_float, _p, _sz, _p]),
+    "mphip_conv3d_gn_table_fwd": (_i, [_p] * 12 + [_i] * 9 + [ctypes.c_float, _p, _sz, _p]),
+    "mphip_conv3d_time_next_launch": (None, [_p, _p]),
     "mphip_groupnorm_affine_table": (_i, [_p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _p]),
     "mphip_conv3d_gnin_gn_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _p] + [_i] * 9 + [ctypes.c_float, _p, _sz, _p]),
     "mphip_conv3d_gnin_fwd": (_i, [_p, _p, _p, _i, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),

@@ -561,9 +561,18 @@ static void dispatch_mt(const ConvPlan &p, const float *x, const float *wp, cons
     }
 }
 
+// Measurement hook (bench.py through the plan): the NEXT conv launch on this thread is bracketed by the two HIP events, recorded on
+// the launch stream right before and right after the conv kernel itself (before the split-K reduce / GroupNorm statistics).
+static thread_local hipEvent_t g_time_e0 = nullptr, g_time_e1 = nullptr;
+extern "C" void mphip_conv3d_time_next_launch(void *e0, void *e1) {
+    g_time_e0 = (hipEvent_t)e0;
+    g_time_e1 = (hipEvent_t)e1;
+}
+
 static int conv3d_run(const float *x, const float *in_affine, int in_relu, const float *x_range, const void *w_packed, const float *bias, float *y,
                       float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
-                      size_t workspace_bytes, void *stream, const int *roi = nullptr, int roi_frames = 0, int roi_dilate = 0) {
+                      size_t workspace_bytes, void *stream, const int *roi = nullptr, int roi_frames = 0, int roi_dilate = 0,
+                      const GnTable *gn_table = nullptr) {
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
     MPHIP_REQUIRE(k == 1 || k == 3, "conv3d_fwd: kernel size %d not supported (1 or 3)", k);
@@ -622,6 +631,9 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     }
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
+    hipEvent_t te0 = g_time_e0, te1 = g_time_e1;
+    g_time_e0 = g_time_e1 = nullptr;
+    if (te0) (void)hipEventRecord(te0, s);
     if (precision == 1 && k == 1) {
         rc = f16x3_launch_k1(x, w_packed, bias, dst, N, Ci, Co, D * H * W, x_range, s);
     } else if (precision == 1) {
@@ -647,6 +659,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         else dispatch_mt<1>(p, x, wf, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
         rc = check_launch("conv3d_fwd");
     }
+    if (te1) (void)hipEventRecord(te1, s);
     if (rc) return rc;
     const int S = D * H * W;
     if (splits > 1 && !keep_split) {
@@ -657,7 +670,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         rc = check_launch("conv3d_fwd(splitk_reduce)");
         if (rc) return rc;
     }
-    if (gn_stats) rc = groupnorm_stats_launch(y, gn_stats, N, Co, S, gn_groups, gn_eps, gn_ws, s);
+    if (gn_stats) rc = groupnorm_stats_launch(y, gn_stats, N, Co, S, gn_groups, gn_eps, gn_ws, s, gn_table);
     return rc;
 }
 
@@ -723,6 +736,21 @@ extern "C" int mphip_conv3d_gn_fwd(const float *x, const float *x_range, const v
                   gn_groups);
     return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream);
+}
+
+// conv + the statistics of the GroupNorm that follows + that norm's affine table and range bound (what mphip_groupnorm_affine_table
+// writes), all in the one call: the norm is then folded into the NEXT conv with mphip_conv3d_gnin_*_fwd(table, table_range).
+extern "C" int mphip_conv3d_gn_table_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, float *gn_stats,
+                                         const float *gamma, const float *beta, const float *w2, const float *b2, float *table,
+                                         float *table_range, int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups,
+                                         float gn_eps, void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(gn_stats && gamma && beta && table && table_range, "conv3d_gn_table_fwd: null pointer");
+    MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "conv3d_gn_table_fwd: w2/b2 must both be set or both NULL");
+    MPHIP_REQUIRE(gn_groups > 0 && Co > 0 && Co % gn_groups == 0, "conv3d_gn_table_fwd: Co=%d not divisible into %d groups", Co, gn_groups);
+    GnTable t;
+    t.gamma = gamma; t.beta = beta; t.w2 = w2; t.b2 = b2; t.table = table; t.range = table_range;
+    return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, gn_stats, gn_groups, gn_eps, false, N, Ci, Co, D, H, W, k, precision, workspace,
+                      workspace_bytes, stream, nullptr, 0, 0, &t);
 }
 
 extern "C" int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,

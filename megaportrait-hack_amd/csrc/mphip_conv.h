@@ -43,8 +43,17 @@ int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *d
                             int Co, int D, int H, int W, int k, void *workspace, hipStream_t s, const int *dy_boxes = nullptr);
 
 // norm.hip: GroupNorm statistics of x [N,C,S] -> stats [N*G][2] (workspace sized by groupnorm_ws_bytes)
+// GnTable (optional): the statistics kernels also write what mphip_groupnorm_affine_table would — table[n][c] = (scale, shift) of the
+// norm folded into the NEXT conv's staging and the data-independent range descriptor of the normalised tensor — with the same
+// arithmetic, saving that launch on the dependent chain (one per residual block).
+struct GnTable {
+    const float *gamma = nullptr, *beta = nullptr, *w2 = nullptr, *b2 = nullptr;
+    float *table = nullptr, *range = nullptr;
+    int C = 0, cpg = 0;
+    float sqrt_ng = 0.0f;
+};
 size_t groupnorm_ws_bytes(int N, int C, int S, int G);
 int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, int G, float eps, void *workspace,
-                           hipStream_t s);
+                           hipStream_t s, const GnTable *tbl = nullptr);
 
 }  // namespace mphip

@@ -59,8 +59,27 @@ gn_partial_kernel(const float *__restrict__ x, double *__restrict__ partial, siz
 // Single-launch variant for groups of <= GN_DIRECT_MAX floats (every tensor below the two largest
 // G3d levels): one workgroup walks the whole (sample,group) span and writes (mean, rstd) itself.
 constexpr int GN_DIRECT_CHUNKS = 4;
+
+// one (scale, shift) entry of the affine table and its contribution to the bound (gn_affine_table_kernel's arithmetic, shared so that
+// the fused and the separate form give the same bits)
+__device__ __forceinline__ unsigned gn_table_entry(const GnTable &t, int n, int c, float mean, float rstd) {
+    float scale = rstd * t.gamma[c];
+    float shift = t.beta[c] - mean * scale;
+    float amp = t.gamma[c], off = t.beta[c];
+    if (t.w2) {
+        scale = scale * t.w2[c];
+        shift = shift * t.w2[c] + t.b2[c];
+        amp = amp * t.w2[c];
+        off = off * t.w2[c] + t.b2[c];
+    }
+    const int i = n * t.C + c;
+    t.table[i * 2] = scale;
+    t.table[i * 2 + 1] = shift;
+    return range_bits((t.sqrt_ng * fabsf(amp) + fabsf(off)) * 1.0001f);
+}
+
 __global__ void __launch_bounds__(256)
-gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, size_t cnt, float eps) {
+gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, size_t cnt, float eps, GnTable tbl) {
     const int grp = blockIdx.x;
     const float *p = x + (size_t)grp * cnt;
     double ds = 0.0, dss = 0.0;
@@ -94,14 +113,22 @@ gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, s
         red[wave * 2 + 1] = dss;
     }
     __syncthreads();
+    __shared__ float mr_[2];
     if (threadIdx.x == 0) {
         double a = (red[0] + red[2]) + (red[4] + red[6]);
         double b = (red[1] + red[3]) + (red[5] + red[7]);
         double mean = a / (double)cnt;
         double var = b / (double)cnt - mean * mean;
         if (var < 0.0) var = 0.0;
-        stats[grp * 2] = (float)mean;
-        stats[grp * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        stats[grp * 2] = mr_[0] = (float)mean;
+        stats[grp * 2 + 1] = mr_[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (tbl.table) {   // (workgroup-uniform) this group's channels of the affine table + its share of the range bound
+        __syncthreads();
+        const int groups = tbl.C / tbl.cpg, n = grp / groups, g = grp % groups;
+        unsigned mbits = 0;
+        if ((int)threadIdx.x < tbl.cpg) mbits = gn_table_entry(tbl, n, g * tbl.cpg + threadIdx.x, mr_[0], mr_[1]);
+        if (tbl.range) range_note_block(mbits, tbl.range, blockIdx.x, gridDim.x);
     }
 }
 
@@ -148,19 +175,27 @@ gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, cons
 
 // Stage 2: (mean, rstd) per (sample,group); biased variance, eps inside the sqrt.
 __global__ void gn_finalize_kernel(const double *__restrict__ partial, float *__restrict__ stats, int ngroups,
-                                   int chunks, double cnt, float eps) {
+                                   int chunks, double cnt, float eps, GnTable tbl) {
     int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= ngroups) return;
-    double s = 0.0, ss = 0.0;
-    for (int c = 0; c < chunks; ++c) {
-        s += partial[((size_t)g * chunks + c) * 2];
-        ss += partial[((size_t)g * chunks + c) * 2 + 1];
+    unsigned mbits = 0;
+    if (g < ngroups) {
+        double s = 0.0, ss = 0.0;
+        for (int c = 0; c < chunks; ++c) {
+            s += partial[((size_t)g * chunks + c) * 2];
+            ss += partial[((size_t)g * chunks + c) * 2 + 1];
+        }
+        double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+        stats[g * 2] = mf;
+        stats[g * 2 + 1] = rf;
+        if (tbl.table) {
+            const int groups = tbl.C / tbl.cpg, n = g / groups, gg = g % groups;
+            for (int k = 0; k < tbl.cpg; ++k) mbits = max(mbits, gn_table_entry(tbl, n, gg * tbl.cpg + k, mf, rf));
+        }
     }
-    double mean = s / cnt;
-    double var = ss / cnt - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[g * 2] = (float)mean;
-    stats[g * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (tbl.table && tbl.range) range_note_block(mbits, tbl.range, blockIdx.x, gridDim.x);   // (every thread of the block arrives)
 }
 
 struct GnParams {
@@ -775,6 +810,10 @@ extern "C" int mphip_rt_theta(const float *rot, const float *tr, float *theta, i
     return check_launch("rt_theta");
 }
 
+__global__ void gn_affine_table_kernel(const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                       const float *__restrict__ w2, const float *__restrict__ b2, float *__restrict__ table,
+                                       float *__restrict__ range, int N, int C, int cpg, float sqrt_ng);
+
 namespace mphip {
 size_t groupnorm_ws_bytes(int N, int C, int S, int G) {
     if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return 0;
@@ -784,16 +823,26 @@ size_t groupnorm_ws_bytes(int N, int C, int S, int G) {
 }
 
 int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, int G, float eps, void *workspace,
-                           hipStream_t s) {
+                           hipStream_t s, const GnTable *tbl) {
     size_t cnt = (size_t)(C / G) * S;
     int chunks = (int)((cnt + GN_CHUNK - 1) / GN_CHUNK);
-    if (chunks <= GN_DIRECT_CHUNKS) {
-        hipLaunchKernelGGL(gn_stats_direct_kernel, dim3(N * G), dim3(256), 0, s, x, stats, cnt, eps);
-        return check_launch("groupnorm_stats");
+    GnTable t;   // (table == nullptr: statistics only)
+    if (tbl && (N * G <= (int)RANGE_MAX_PARTS) && C / G <= 256) {
+        t = *tbl;
+        t.C = C;
+        t.cpg = C / G;
+        t.sqrt_ng = sqrtf((float)(C / G) * (float)S);
     }
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N * G), dim3(256), 0, s, x, (double *)workspace, cnt, chunks);
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const double *)workspace, stats,
-                       N * G, chunks, (double)cnt, eps);
+    if (chunks <= GN_DIRECT_CHUNKS) {
+        hipLaunchKernelGGL(gn_stats_direct_kernel, dim3(N * G), dim3(256), 0, s, x, stats, cnt, eps, t);
+    } else {
+        hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, N * G), dim3(256), 0, s, x, (double *)workspace, cnt, chunks);
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3(cdiv(N * G, 256)), dim3(256), 0, s, (const double *)workspace, stats,
+                           N * G, chunks, (double)cnt, eps, t);
+    }
+    if (tbl && !t.table)   // (shape outside the fused form: the separate table launch)
+        hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, stats, tbl->gamma, tbl->beta, tbl->w2, tbl->b2,
+                           tbl->table, tbl->range, N, C, C / G, sqrtf((float)(C / G) * (float)S));
     return check_launch("groupnorm_stats");
 }
 }  // namespace mphip

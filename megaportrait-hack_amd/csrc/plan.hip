@@ -96,6 +96,7 @@ struct ConvOut {   // ops.ConvOut: finished tensor (splits == 1) or split-K part
     const float *bias = nullptr;
     Buf stats;
     int stats_groups = 0;
+    Buf table, table_range;   // the following norm's affine table + range bound, when the conv launch produced them
 };
 
 struct Norm { const float *gw = nullptr, *gb = nullptr, *w2 = nullptr, *b2 = nullptr; };   // group_norm.{weight,bias} (+ AdaptiveGroupNorm's)
@@ -175,7 +176,7 @@ void give(Ctx &c, Buf &b) {
     b = Buf();
 }
 void give(Ctx &c, T5 &t) { give(c, t.data); give(c, t.range); }
-void give(Ctx &c, ConvOut &o) { give(c, o.t); give(c, o.stats); }
+void give(Ctx &c, ConvOut &o) { give(c, o.t); give(c, o.stats); give(c, o.table); give(c, o.table_range); }
 
 T5 new_t5(Ctx &c, int n, int ch, int d, int h, int w, bool with_range) {
     T5 t;
@@ -224,20 +225,17 @@ const void *packed(Ctx &c, ConvW &cw, int prec) {
     return cw.pk[prec];
 }
 
-bool prof_begin(Ctx &c, const ConvW &cw, int d, int h, int w, int kind) {
+// measurement: bracket the NEXT conv launch (the conv kernel itself) with a pair of events of the given kind
+void prof_arm(Ctx &c, const ConvW &cw, int d, int h, int w, int kind) {
     Plan *p = c.p;
-    if (c.dry || !p->profile || cw.ci != 96 || cw.co != 96 || cw.k != 3 || d != p->D || h != p->H || w != p->W) return false;
+    if (c.dry || !p->profile || cw.ci != 96 || cw.co != 96 || cw.k != 3 || d != p->D || h != p->H || w != p->W) return;
     if (p->prof_used[kind] + 2 > p->prof_ev[kind].size())
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) return false;
+            if (hipEventCreate(&e) != hipSuccess) return;
             p->prof_ev[kind].push_back(e);
         }
-    return hipEventRecord(p->prof_ev[kind][p->prof_used[kind]], c.s) == hipSuccess;
-}
-void prof_end(Ctx &c, int kind) {
-    Plan *p = c.p;
-    (void)hipEventRecord(p->prof_ev[kind][p->prof_used[kind] + 1], c.s);
+    mphip_conv3d_time_next_launch(p->prof_ev[kind][p->prof_used[kind]], p->prof_ev[kind][p->prof_used[kind] + 1]);
     p->prof_used[kind] += 2;
 }
 
@@ -250,8 +248,11 @@ const float *range_for(Ctx &c, T5 &x) {   // ops._range_for: the producer's desc
     return x.range.p;
 }
 
-// ops.conv3d: finished tensor (+ the statistics of the GroupNorm that follows when gn_groups)
-ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
+bool gn_in_conv_ok(const Ctx &c, int n, int d, int h, int w, const ConvW &pc2);
+
+// ops.conv3d: finished tensor (+ the statistics of the GroupNorm that follows when gn_groups; + that norm's affine table when it
+// will be folded into `next`'s staging: nm / next given)
+ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups, const Norm *nm = nullptr, const ConvW *next = nullptr) {
     const int n = x.n, d = x.d, h = x.h, w = x.w;
     const int prec = precision_for(c, n, cw.ci, cw.co, d, h, w, cw.k);
     const void *wp = packed(c, cw, prec);
@@ -262,19 +263,19 @@ ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
     if (ws_bytes) ws = take(c, ws_bytes);
     ConvOut o;
     o.t = new_t5(c, n, cw.co, d, h, w, false);
+    prof_arm(c, cw, d, h, w, 0);
     if (gn_groups) {
         o.stats = take(c, (size_t)n * gn_groups * 2 * sizeof(float));
         o.stats_groups = gn_groups;
-        // (timed without the statistics pass: conv launch alone, then the GroupNorm statistics of its output)
-        const bool timed = prof_begin(c, cw, d, h, w, 0);
-        if (timed) {
-            RUN(c, mphip_conv3d_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, n, cw.ci, cw.co, d, h, w, cw.k, prec, ws.p, ws_bytes, c.s));
-            prof_end(c, 0);
-            const size_t gb = mphip_groupnorm_workspace_bytes(n, cw.co, d * h * w, gn_groups);
-            RUN(c, mphip_groupnorm_stats(o.t.data.p, o.stats.p, n, cw.co, d * h * w, gn_groups, GN_EPS, (char *)ws.p + (ws_bytes - gb), gb, c.s));
-        } else
-        RUN(c, mphip_conv3d_gn_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, o.stats.p, n, cw.ci, cw.co, d, h, w, cw.k, prec, gn_groups, GN_EPS,
-                                   ws.p, ws_bytes, c.s));
+        if (nm && next && gn_in_conv_ok(c, n, d, h, w, *next)) {
+            o.table = take(c, (size_t)n * cw.co * 2 * sizeof(float));
+            o.table_range = take(c, MPHIP_RANGE_FLOATS * sizeof(float));
+            RUN(c, mphip_conv3d_gn_table_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, o.stats.p, nm->gw, nm->gb, nm->w2, nm->b2, o.table.p, o.table_range.p, n,
+                                             cw.ci, cw.co, d, h, w, cw.k, prec, gn_groups, GN_EPS, ws.p, ws_bytes, c.s));
+        } else {
+            RUN(c, mphip_conv3d_gn_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, o.stats.p, n, cw.ci, cw.co, d, h, w, cw.k, prec, gn_groups, GN_EPS,
+                                       ws.p, ws_bytes, c.s));
+        }
     } else {
         RUN(c, mphip_conv3d_fwd(x.data.p, xr, wp, cw.b, o.t.data.p, n, cw.ci, cw.co, d, h, w, cw.k, prec, ws.p, ws_bytes, c.s));
     }
@@ -283,13 +284,13 @@ ConvOut conv3d(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
 }
 
 // ops.conv3d_split: split-K slabs are kept for the GroupNorm kernels when the tensor is small
-ConvOut conv3d_split(Ctx &c, T5 &x, ConvW &cw, int gn_groups) {
+ConvOut conv3d_split(Ctx &c, T5 &x, ConvW &cw, int gn_groups, const Norm *nm = nullptr, const ConvW *next = nullptr) {
     const int n = x.n, d = x.d, h = x.h, w = x.w;
     const int prec = precision_for(c, n, cw.ci, cw.co, d, h, w, cw.k);
     const int splits = mphip_conv3d_splits(n, cw.ci, cw.co, d, h, w, cw.k, prec);
     const size_t elems = (size_t)n * cw.co * d * h * w;
-    if (splits > 1 && elems > SPLIT_CHAIN_MAX_ELEMS) return conv3d(c, x, cw, gn_groups);
-    if (gn_groups && splits == 1 && prec == 1) return conv3d(c, x, cw, gn_groups);
+    if (splits > 1 && elems > SPLIT_CHAIN_MAX_ELEMS) return conv3d(c, x, cw, gn_groups, nm, next);
+    if (gn_groups && splits == 1 && prec == 1) return conv3d(c, x, cw, gn_groups, nm, next);
     const void *wp = packed(c, cw, prec);
     const float *xr = prec == 1 ? range_for(c, x) : nullptr;
     ConvOut o;
@@ -355,17 +356,21 @@ T5 groupnorm_small(Ctx &c, ConvOut &x, const Norm &nm, int groups, const ConvOut
     return y;
 }
 
-bool gn_in_conv_ok(const Ctx &c, const ConvOut &y, const ConvW &pc2) {
+bool gn_in_conv_ok(const Ctx &c, int n, int d, int h, int w, const ConvW &pc2) {
     if (c.p->precision != 1 || pc2.k != 3 || pc2.ci > 768) return false;
-    return mphip_conv3d_supported(y.t.n, pc2.ci, pc2.co, y.t.d, y.t.h, y.t.w, pc2.k, 1) != 0;
+    return mphip_conv3d_supported(n, pc2.ci, pc2.co, d, h, w, pc2.k, 1) != 0;
 }
+bool gn_in_conv_ok(const Ctx &c, const ConvOut &y, const ConvW &pc2) { return gn_in_conv_ok(c, y.t.n, y.t.d, y.t.h, y.t.w, pc2); }
 
 // ops.conv3d_gn_in: conv(relu(GN(x))) with the norm folded into the conv's staging; also the statistics of its own output
 ConvOut conv3d_gn_in(Ctx &c, ConvOut &y, const Norm &nm, int groups, ConvW &pc2, int out_gn_groups) {
     const int n = y.t.n, ci = y.t.c, d = y.t.d, h = y.t.h, w = y.t.w;
-    Buf table = take(c, (size_t)n * ci * 2 * sizeof(float));
-    Buf xr = take(c, MPHIP_RANGE_FLOATS * sizeof(float));
-    RUN(c, mphip_groupnorm_affine_table(y.stats.p, nm.gw, nm.gb, nm.w2, nm.b2, table.p, xr.p, n, ci, d * h * w, groups, c.s));
+    const bool have = y.table.off != (size_t)-1;   // the producing conv launch already wrote the table and the bound
+    Buf table = have ? y.table : take(c, (size_t)n * ci * 2 * sizeof(float));
+    Buf xr = have ? y.table_range : take(c, MPHIP_RANGE_FLOATS * sizeof(float));
+    y.table = Buf();
+    y.table_range = Buf();
+    if (!have) RUN(c, mphip_groupnorm_affine_table(y.stats.p, nm.gw, nm.gb, nm.w2, nm.b2, table.p, xr.p, n, ci, d * h * w, groups, c.s));
     const void *wp = packed(c, pc2, 1);
     const size_t ws_bytes = mphip_conv3d_gn_workspace_bytes(n, ci, pc2.co, d, h, w, pc2.k, 1, out_gn_groups);
     Buf ws = take(c, ws_bytes);
@@ -373,12 +378,7 @@ ConvOut conv3d_gn_in(Ctx &c, ConvOut &y, const Norm &nm, int groups, ConvW &pc2,
     o.t = new_t5(c, n, pc2.co, d, h, w, false);
     o.stats = take(c, (size_t)n * out_gn_groups * 2 * sizeof(float));
     o.stats_groups = out_gn_groups;
-    if (prof_begin(c, pc2, d, h, w, 0)) {   // (measurement: the conv launch alone between the events, then the statistics of its output)
-        RUN(c, mphip_conv3d_gnin_fwd(y.t.data.p, table.p, xr.p, 1, wp, pc2.b, o.t.data.p, n, ci, pc2.co, d, h, w, pc2.k, 1, ws.p, ws_bytes, c.s));
-        prof_end(c, 0);
-        const size_t gb = mphip_groupnorm_workspace_bytes(n, pc2.co, d * h * w, out_gn_groups);
-        RUN(c, mphip_groupnorm_stats(o.t.data.p, o.stats.p, n, pc2.co, d * h * w, out_gn_groups, GN_EPS, (char *)ws.p + (ws_bytes - gb), gb, c.s));
-    } else
+    prof_arm(c, pc2, d, h, w, 0);
     RUN(c, mphip_conv3d_gnin_gn_fwd(y.t.data.p, table.p, xr.p, 1, wp, pc2.b, o.t.data.p, o.stats.p, n, ci, pc2.co, d, h, w, pc2.k, 1, out_gn_groups,
                                     GN_EPS, ws.p, ws_bytes, c.s));
     give(c, ws);
@@ -415,7 +415,7 @@ void resblock_ada(GenLane (&ln)[L], int blk, T5 (&x)[L], int ud, int uh, int uw)
     T5 a[L], out[L];
     ResBlockAda *b[L];
     for (int l = 0; l < L; ++l) b[l] = &ln[l].g->ff.rb[blk];
-    for (int l = 0; l < L; ++l) y[l] = conv3d_split(*ln[l].c, x[l], b[l]->conv1, 32);
+    for (int l = 0; l < L; ++l) y[l] = conv3d_split(*ln[l].c, x[l], b[l]->conv1, 32, &b[l]->n1, &b[l]->conv2);
     const bool tiny = groupnorm_fused_ok(y[0], 32);   // (shape decisions are the same on every lane: same batch, same layer)
     if (tiny) {
         for (int l = 0; l < L; ++l) { a[l] = groupnorm_small(*ln[l].c, y[l], b[l]->n1, 32, nullptr, true, false, 1, 1, 1); give(*ln[l].c, y[l]); }
@@ -504,7 +504,7 @@ void generator_coords(GenLane (&ln)[L], int B, Buf (&coords)[L]) {
 template <typename Hook>
 T5 resblock(Ctx &c, ResBlock &b, T5 &x, bool pool_after, Hook hook) {
     ConvOut identity = b.identity ? as_convout(x) : conv3d_split(c, x, b.shortcut, 0);
-    ConvOut y = conv3d_split(c, x, b.conv1, 32);
+    ConvOut y = conv3d_split(c, x, b.conv1, 32, &b.gn1, &b.conv2);   // (+ gn1's affine table when it will be folded into conv2)
     hook();
     ensure_stats(c, y, 32);
     ConvOut y2;
@@ -577,12 +577,11 @@ T5 g3d(Ctx &c, T5 &x, bool external_out, float *out, Hook hook, Tail tail) {
     T5 y;
     y.n = t.n; y.c = cw.co; y.d = t.d; y.h = t.h; y.w = t.w;
     if (external_out) y.data.p = out; else y.data = take(c, y.numel() * sizeof(float));
-    const bool timed = prof_begin(c, cw, t.d, t.h, t.w, roi.on ? 1 : 0);
+    prof_arm(c, cw, t.d, t.h, t.w, roi.on ? 1 : 0);
     if (roi.on)
         RUN(c, mphip_conv3d_fwd_roi(t.data.p, xr, wp, cw.b, y.data.p, roi.box, 0, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
     else
         RUN(c, mphip_conv3d_fwd(t.data.p, xr, wp, cw.b, y.data.p, t.n, cw.ci, cw.co, t.d, t.h, t.w, cw.k, prec, ws.p, ws_bytes, c.s));
-    if (timed) prof_end(c, roi.on ? 1 : 0);
     give(c, ws);
     give(c, t);
     return y;
