@@ -1,4 +1,8 @@
-cd /root/repo
-python -m pytest tests/test_gpu_plan.py -x -q -m gpu 2>&1 | grep -E "passed|failed|Error" | tail -3
-python tools/bench_plan.py 2>&1 | grep -v amdgpu
-python bench.py --no-extras --no-cpu-baseline --steps 40 --warmup 5 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline']['launch_ms'], d['roofline']['launches_timed'], d['roofline']['demand_driven_launch']['launch_ms'])"
+cd $GRAFT_REPO_ROOT
+out=gpurun_out/r03_b1; mkdir -p $out
+export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d $out/kt -- python tools/run_plan_steps.py 8 30 > $out/log8.txt 2>&1
+db=$(find $out/kt -name "*.db" | head -1)
+python tools/lane_timeline.py $db 4.6 > $out/timeline_b8_k1.txt
+rm -rf $out/kt
+grep -E "k1_f16x3|gather_kernel<1" $out/timeline_b8_k1.txt | head -12

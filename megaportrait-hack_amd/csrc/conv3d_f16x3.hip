@@ -699,7 +699,13 @@ __global__ void f16x3_pack_k1_kernel(const float *__restrict__ w, _Float16 *__re
     }
 }
 
-__global__ void __launch_bounds__(256)
+// KS = 1: four waves per workgroup, each with its own 64-voxel tile and the whole channel loop (large launches: the loop is
+// covered by other waves).  KS > 1: the KS waves of a workgroup share ONE tile and split the channel chunks between them
+// (contiguous ranges), then fold their accumulators through LDS in wave order — the small launches (<= one wave per SIMD on the
+// chip) were a serial chain of nchunks dependent global-load round trips (12-48 x ~1.2 us: 28-41 us for 1-2 GFLOP).
+// Either way the loads of chunk c+1 are issued before the MFMAs of chunk c (two register sets).
+template <int KS>
+__global__ void __launch_bounds__(KS == 1 ? 256 : 64 * KS) __attribute__((amdgpu_waves_per_eu(2)))
 conv3d_k1_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int DHW, unsigned x_bytes,
                        const float *__restrict__ x_range) {
@@ -708,10 +714,12 @@ conv3d_k1_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     if (x_range) range_scale_block(x_range, x_scale, x_unscale);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 31, kg = lane >> 5;
-    const long v0 = ((long)blockIdx.x * 4 + wave) * (NT * 32);      // this wave's 64 voxels (DHW % 64 == 0: one sample)
-    if (v0 >= (long)N * DHW) return;                                 // wave-uniform
+    const long v0 = (KS == 1 ? (long)blockIdx.x * 4 + wave : (long)blockIdx.x) * (NT * 32);   // this wave's 64 voxels (DHW % 64 == 0: one sample)
+    if (v0 >= (long)N * DHW) return;                                 // wave-uniform (KS > 1: workgroup-uniform)
     const int n = (int)(v0 / DHW), r0 = (int)(v0 - (long)n * DHW);
     const int cot = blockIdx.y, nchunks = Ci / F16X3_KC;
+    const int cps = (nchunks + KS - 1) / KS;
+    const int c_begin = KS == 1 ? 0 : wave * cps, c_end = KS == 1 ? nchunks : min(nchunks, c_begin + cps);
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
     const unsigned vbase = (unsigned)((((long)n * Ci + kg * 8) * DHW + r0 + j) * 4);   // (n, ci = kg*8, voxel j of tile 0)
     const unsigned cstride = (unsigned)DHW * 4u;
@@ -726,56 +734,88 @@ conv3d_k1_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
             for (int q = 0; q < 16; ++q) acc[m][t][q] = 0.0f;
 
     unsigned sat_ = 0;
-    for (int c = 0; c < nchunks; ++c) {
-        float xv[NT][8];
-        const unsigned soff = (unsigned)((long)c * F16X3_KC * DHW * 4);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xv[t][e] = buf_load_f(rsrc, vbase + (unsigned)t * 128u + (unsigned)e * cstride, soff);
-        half8 ah[MT], al[MT];
-        const _Float16 *ws = wl + (size_t)c * K1_SLAB_HALFS;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
-            ah[m] = *reinterpret_cast<const half8 *>(ws + m * 32 * 8);
-            al[m] = *reinterpret_cast<const half8 *>(ws + K1_SLAB_HALFS / 2 + m * 32 * 8);
-        }
-        half8 bh[NT], bl[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                _Float16 h, l;
-                const float sv = xv[t][e] * x_scale;
-                sat_ += !(fabsf(sv) <= F16_CLAMP);
-                split_f16(sv, h, l);
-                bh[t][e] = h;
-                bl[t][e] = l;
-            }
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[t], acc[m][t], 0, 0, 0);
+    float xv[2][NT][8];
+    half8 ah[2][MT], al[2][MT];
+#define K1_LOAD(set, c_)                                                                                              \
+    {                                                                                                                 \
+        const unsigned soff_ = (unsigned)((long)(c_) * F16X3_KC * DHW * 4);                                           \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e)                                                             \
+                xv[set][t][e] = buf_load_f(rsrc, vbase + (unsigned)t * 128u + (unsigned)e * cstride, soff_);          \
+        const _Float16 *ws_ = wl + (size_t)(c_) * K1_SLAB_HALFS;                                                      \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) {                                                              \
+            ah[set][m] = *reinterpret_cast<const half8 *>(ws_ + m * 32 * 8);                                          \
+            al[set][m] = *reinterpret_cast<const half8 *>(ws_ + K1_SLAB_HALFS / 2 + m * 32 * 8);                      \
+        }                                                                                                             \
     }
+#define K1_MFMA(set)                                                                                                  \
+    {                                                                                                                 \
+        half8 bh[NT], bl[NT];                                                                                         \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                \
+            _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                                           \
+                _Float16 h, l;                                                                                        \
+                const float sv = xv[set][t][e] * x_scale;                                                             \
+                sat_ += !(fabsf(sv) <= F16_CLAMP);                                                                    \
+                split_f16(sv, h, l);                                                                                  \
+                bh[t][e] = h;                                                                                         \
+                bl[t][e] = l;                                                                                         \
+            }                                                                                                         \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[set][m], bh[t], acc[m][t], 0, 0, 0);            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][m], bl[t], acc[m][t], 0, 0, 0);            \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                            \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[set][m], bh[t], acc[m][t], 0, 0, 0);            \
+    }
+    if (c_begin < c_end) K1_LOAD(0, c_begin)
+    for (int c = c_begin; c < c_end; c += 2) {
+        if (c + 1 < c_end) K1_LOAD(1, c + 1)
+        K1_MFMA(0)
+        if (c + 1 < c_end) {
+            if (c + 2 < c_end) K1_LOAD(0, c + 2)
+            K1_MFMA(1)
+        }
+    }
+#undef K1_LOAD
+#undef K1_MFMA
     const float unscale = whdr[0] * x_unscale;
     const int co0 = cot * F16X3_COT;
+    if (KS == 1) {
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
+        for (int m = 0; m < MT; ++m) {
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
-            const float bv = bias ? bias[co] : 0.0f;
-            float *dv = y + ((size_t)n * Co + co) * DHW + r0 + j;
+            for (int reg = 0; reg < 16; ++reg) {
+                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                const float bv = bias ? bias[co] : 0.0f;
+                float *dv = y + ((size_t)n * Co + co) * DHW + r0 + j;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) dv[t * 32] = acc[m][t][reg] * unscale + bv;
+                for (int t = 0; t < NT; ++t) dv[t * 32] = acc[m][t][reg] * unscale + bv;
+            }
+        }
+    } else {
+        // fold the KS partial accumulators: per row tile m every wave parks its 32 registers in LDS; wave w then sums (in wave
+        // order: deterministic) and stores the registers w, w + KS, ...
+        __shared__ float red[KS > 1 ? KS : 1][NT * 16 * 64];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) red[wave][(t * 16 + reg) * 64 + lane] = acc[m][t][reg];
+            __syncthreads();
+            for (int q = wave; q < NT * 16; q += KS) {
+                const int t = q >> 4, reg = q & 15;
+                float sum = red[0][q * 64 + lane];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) sum += red[k][q * 64 + lane];
+                const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                const float bv = bias ? bias[co] : 0.0f;
+                y[((size_t)n * Co + co) * DHW + r0 + j + t * 32] = sum * unscale + bv;
+            }
+            __syncthreads();
         }
     }
     if (__builtin_amdgcn_ballot_w64(sat_ != 0) != 0) {  // never taken in normal operation (non-finite operands)
@@ -786,10 +826,25 @@ conv3d_k1_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
     }
 }
 
+// waves sharing a tile (1 = none): small launches split the channel loop 4 or 8 ways
+static int f16x3_k1_ksplit(int N, int Ci, int Co, int DHW) {
+    const char *force = getenv("MPHIP_F16X3_K1_KS");   // dev: same-box A/B
+    if (force && (atoi(force) == 1 || atoi(force) == 4 || atoi(force) == 8)) return atoi(force);
+    const long wave_tiles = (long)N * DHW / 64 * (Co / F16X3_COT);
+    const int nchunks = Ci / F16X3_KC;
+    if (wave_tiles >= 1024 || nchunks < 8) return 1;   // (measured at B=8: 192->96 @8x32x32, 1024 wave tiles: 26 us unsplit, 31 us split 4)
+    return (wave_tiles <= 512 && nchunks >= 16) ? 8 : 4;
+}
+
+static long f16x3_k1_min_voxels() {
+    const char *e = getenv("MPHIP_F16X3_K1_MIN");   // dev: threshold A/B
+    return e ? atol(e) : 1024;
+}
+
 bool f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k) {
     if (k == 1)   // the k=1 GEMM kernel: whole 64-voxel wave tiles inside one sample, and enough of them to beat the split-K
                   // fp32 gather kernel (measured: 1024 voxels 29 vs 32 us at B=8, but slower below — B=1 went 1.93 -> 2.11 ms)
-        return Ci % F16X3_KC == 0 && Co % F16X3_COT == 0 && ((long)D * H * W) % 64 == 0 && (long)N * D * H * W >= 2048 &&
+        return Ci % F16X3_KC == 0 && Co % F16X3_COT == 0 && ((long)D * H * W) % 64 == 0 && (long)N * D * H * W >= f16x3_k1_min_voxels() &&
                (size_t)N * Ci * D * H * W * 4 < 0x80000000ull;
     return k == 3 && Ci % F16X3_KC == 0 && Co % F16X3_COT == 0 && H % 8 == 0 && W % 8 == 0 && D % 2 == 0 &&
            (size_t)N * Ci * D * H * W * 4 < 0x80000000ull;
@@ -810,7 +865,7 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     // weight stream per MFMA) — whenever that still gives every CU a workgroup (the persistent grid needs no second one;
     // measured at B=8: 192->192 @8x32x32 0.371 vs 0.420 ms, 96->192 0.181 vs 0.194 ms; below one workgroup per CU
     // the smaller tile wins: 192->96 0.203 vs 0.214 ms).
-    static const char *force = getenv("MPHIP_F16X3_TILE");
+    const char *force = getenv("MPHIP_F16X3_TILE");   // dev knobs, read per call (tools/sweep_conv_plans.py flips them in-process)
     const int cot = Co / F16X3_COT;
     const long tiles1 = (p.td == 4 && W % 16 == 0) ? (long)N * (D / 4) * (H / 8) * (W / 16) : 0;
     p.variant = (tiles1 * cot >= 256) ? 1 : 0;
@@ -834,8 +889,8 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     int sp = 1;
     if (tiles * cot < 256)
         while (tiles * cot * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
-    static const char *force_sp = getenv("MPHIP_F16X3_SPLITS");   // dev: planner sweep (tools/sweep_conv_plans.py)
-    if (force_sp && atoi(force_sp) > 0 && nchunks / atoi(force_sp) >= 1) sp = atoi(force_sp);
+    const char *force_sp = getenv("MPHIP_F16X3_SPLITS");   // dev: planner sweep (tools/sweep_conv_plans.py)
+    if (force_sp && atoi(force_sp) > 0 && nchunks % atoi(force_sp) == 0) sp = atoi(force_sp);   // (whole chunks per split only)
     p.splits = sp;
     p.chunks_per_split = (nchunks + sp - 1) / sp;
     p.grid = dim3((unsigned)tiles, Co / F16X3_COT, sp);
@@ -873,8 +928,16 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * DHW * 4);
     const long waves = (long)N * DHW / 64;
-    hipLaunchKernelGGL(conv3d_k1_f16x3_kernel, dim3((unsigned)((waves + 3) / 4), Co / F16X3_COT), dim3(256), 0, s, x, slabs, hdr, bias,
-                       dst, N, Ci, Co, DHW, xb, x_range);
+    const int ks = f16x3_k1_ksplit(N, Ci, Co, DHW);
+    if (ks == 8)
+        hipLaunchKernelGGL(conv3d_k1_f16x3_kernel<8>, dim3((unsigned)waves, Co / F16X3_COT), dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci,
+                           Co, DHW, xb, x_range);
+    else if (ks == 4)
+        hipLaunchKernelGGL(conv3d_k1_f16x3_kernel<4>, dim3((unsigned)waves, Co / F16X3_COT), dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci,
+                           Co, DHW, xb, x_range);
+    else
+        hipLaunchKernelGGL(conv3d_k1_f16x3_kernel<1>, dim3((unsigned)((waves + 3) / 4), Co / F16X3_COT), dim3(256), 0, s, x, slabs, hdr, bias,
+                           dst, N, Ci, Co, DHW, xb, x_range);
     return check_launch("conv3d_fwd(f16x3, k=1)");
 }
 
