@@ -885,10 +885,23 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     if (roi && p.td == 4 && !force) p.variant = 0;
     const long tiles = (p.variant == 1 || p.variant == 3) ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
-    // split-K only when the launch cannot give every CU a workgroup: each split adds a slab write + a reduce pass
+    // split-K only when the launch cannot give every CU a workgroup (each split adds a slab write + a reduce pass): the largest
+    // whole-chunk split that still fits the chip in ONE round of resident workgroups (one per CU; two for the 4-wave (2,8,8) kernel).
+    // r03 sweep (tools/sweep_conv_plans.py): a second round costs more than it hides (B=8, 384->192 @4x16x16: 256 workgroups 98 us,
+    // 512 106 us), and below that one chunk per workgroup beats three (B=1, 768->384 @2x8x8: 16 splits 41 us, 48 splits 24 us — the
+    // launch is one workgroup's serial chain of chunks).
     int sp = 1;
-    if (tiles * cot < 256)
-        while (tiles * cot * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
+    {
+        const long base = tiles * cot, slots = (p.variant == 0 && p.td == 2) ? 512 : 256;
+        static const char *old_rule = getenv("MPHIP_F16X3_OLD_SPLITS");   // dev: same-box A/B against the r02 rule
+        if (old_rule) {
+            if (base < 256)
+                while (base * sp < 512 && nchunks / (sp * 2) >= 3) sp *= 2;
+        } else if (base < slots) {
+            for (int dv = 2; dv <= nchunks; ++dv)
+                if (nchunks % dv == 0 && base * dv <= slots) sp = dv;
+        }
+    }
     const char *force_sp = getenv("MPHIP_F16X3_SPLITS");   // dev: planner sweep (tools/sweep_conv_plans.py)
     if (force_sp && atoi(force_sp) > 0 && nchunks % atoi(force_sp) == 0) sp = atoi(force_sp);   // (whole chunks per split only)
     p.splits = sp;

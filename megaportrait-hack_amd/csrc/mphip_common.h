@@ -150,15 +150,14 @@ int absmax_range_launch(const float *x, size_t n, float *range, hipStream_t s);
 // 32-way split costs 4 memory round trips instead of 32.
 __device__ __forceinline__ float sum_slabs(const float *__restrict__ x, int splits, size_t slab, size_t o) {
     float v = x[o];
-    int z = 1;
-    for (; z + 8 <= splits; z += 8) {
+    for (int z = 1; z < splits; z += 8) {   // (a short last batch is predicated, not a serial tail: 8 and 16 splits are 1 + 7 and 1 + 8 + 7)
         float t[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) t[k] = x[(size_t)(z + k) * slab + o];
+        for (int k = 0; k < 8; ++k) t[k] = z + k < splits ? x[(size_t)(z + k) * slab + o] : 0.0f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) v += t[k];
+        for (int k = 0; k < 8; ++k)
+            if (z + k < splits) v += t[k];
     }
-    for (; z < splits; ++z) v += x[(size_t)z * slab + o];
     return v;
 }
 

@@ -134,7 +134,7 @@ gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, s
 
 // Statistics of a conv output that is still in split-K form: value(i) = bias[c] + sum_z slab[z][i]
 // (z ascending, the order mphip_conv3d_fwd's reduce uses).  Small tensors only: one workgroup per group.
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, const float *__restrict__ bias,
                       float *__restrict__ stats, int C, int cpg, int S, float eps) {
     const int grp = blockIdx.x;
@@ -143,7 +143,7 @@ gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, cons
     double ds = 0.0, dss = 0.0;
     {   // flat over the (channel, voxel) span so tiny S (FlowField's 4x1x1 level) still uses every lane
         float s = 0.0f, ss = 0.0f;
-        for (size_t e = threadIdx.x; e < cnt; e += 256) {
+        for (size_t e = threadIdx.x; e < cnt; e += blockDim.x) {
             const size_t o = base + e;
             float v = sum_slabs(x, splits, slab, o);
             if (bias) v += bias[c0 + (int)(e / S)];
@@ -155,16 +155,19 @@ gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, cons
     }
     ds = wave_sum(ds);
     dss = wave_sum(dss);
-    __shared__ double red[8];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ double red[32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, nwaves = blockDim.x >> 6;   // 4 or 16 waves
     if (lane == 0) {
         red[wave * 2] = ds;
         red[wave * 2 + 1] = dss;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double a = (red[0] + red[2]) + (red[4] + red[6]);
-        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        double a = 0.0, b = 0.0;
+        for (int w = 0; w < nwaves; w += 4) {   // (groups of four waves, the 4-wave launch's own fold)
+            a += (red[w * 2] + red[w * 2 + 2]) + (red[w * 2 + 4] + red[w * 2 + 6]);
+            b += (red[w * 2 + 1] + red[w * 2 + 3]) + (red[w * 2 + 5] + red[w * 2 + 7]);
+        }
         double mean = a / (double)cnt;
         double var = b / (double)cnt - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -939,7 +942,8 @@ extern "C" int mphip_groupnorm_stats_split(const float *x, int x_splits, const f
     MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0 && x_splits >= 1, "groupnorm_stats_split: bad dims");
     MPHIP_REQUIRE((size_t)(C / G) * S <= (size_t)GN_DIRECT_CHUNKS * GN_CHUNK,
                   "groupnorm_stats_split: group span too large for the single-launch path (reduce first)");
-    hipLaunchKernelGGL(gn_stats_split_kernel, dim3(N * G), dim3(256), 0, (hipStream_t)stream, x, x_splits,
+    // one workgroup per (sample, group): long spans get 16 waves (a thread's elements are a serial chain of slab round trips)
+    hipLaunchKernelGGL(gn_stats_split_kernel, dim3(N * G), dim3((size_t)(C / G) * S >= 2048 ? 1024 : 256), 0, (hipStream_t)stream, x, x_splits,
                        (size_t)N * C * S, x_bias, stats, C, C / G, S, eps);
     return check_launch("groupnorm_stats_split");
 }

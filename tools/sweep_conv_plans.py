@@ -32,10 +32,11 @@ for B in [int(a) for a in sys.argv[1:]] or [8]:
         x = torch.randn(B, ci, d, h, w, device=dev)
         pc = ops.PackedConv(torch.randn(co, ci, 3, 3, 3, device=dev) * 0.02, torch.randn(co, device=dev))
         os.environ.pop("MPHIP_F16X3_TILE", None); os.environ.pop("MPHIP_F16X3_SPLITS", None)
+        time_one(x, pc)
         base = time_one(x, pc)
         res = []
         for tile in ("0", "1"):
-            for sp in ("1", "2", "4", "8", "16", "24", "48"):
+            for sp in ("1", "2", "3", "4", "6", "8", "12", "16", "24", "48"):
                 os.environ["MPHIP_F16X3_TILE"] = tile
                 os.environ["MPHIP_F16X3_SPLITS"] = sp
                 res.append((time_one(x, pc), f"t{tile}s{sp}"))
