@@ -509,6 +509,20 @@ static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int
 constexpr size_t RANGE_BYTES = ((MPHIP_RANGE_FLOATS * sizeof(float) + 255) / 256) * 256;  // descriptor + padding: keeps what follows aligned
 
 static size_t conv_ws_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision, bool roi);
+// GroupNorm statistics from the f16x3 3x3x3 kernel's epilogue (unsplit launches): bytes of its per-(tile, wave, channel) partials, 0 = the
+// separate statistics pass is used
+static size_t gn_epilogue_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision, F16x3Plan *plan_out = nullptr) {
+    static const bool off = getenv("MPHIP_GN_EPILOGUE") && getenv("MPHIP_GN_EPILOGUE")[0] == '0';   // dev: same-box A/B
+    if (off || precision != 1 || k != 3 || !mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    const F16x3Plan fp = f16x3_plan(N, Ci, Co, D, H, W, false);
+    if (fp.splits != 1) return 0;
+    if (plan_out) *plan_out = fp;
+    return (size_t)fp.grid.x * f16x3_tile_waves(fp) * Co * 2 * sizeof(float) + 256;   // (+ the accumulator unscale behind the partials)
+}
+static size_t conv_gn_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups) {
+    const size_t a = groupnorm_ws_bytes(N, Co, D * H * W, gn_groups), b = gn_epilogue_bytes(N, Ci, Co, D, H, W, k, precision);
+    return a > b ? a : b;
+}
 extern "C" size_t mphip_conv3d_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
     return conv_ws_bytes(N, Ci, Co, D, H, W, k, precision, false);
 }
@@ -616,8 +630,8 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     workspace = workspace ? (char *)workspace + range_bytes : nullptr;
     workspace_bytes = workspace_bytes > range_bytes ? workspace_bytes - range_bytes : 0;
     const size_t slab_bytes = (splits > 1 && !keep_split) ? (size_t)splits * n_out * sizeof(float) : 0;
-    // (statistics in the f16x3 kernel's epilogue were tried and measured 1.2 % slower end to end: DESIGN.md §3)
-    const size_t gn_bytes = gn_stats ? groupnorm_ws_bytes(N, Co, D * H * W, gn_groups) : 0;
+    const size_t gn_bytes = gn_stats ? conv_gn_bytes(N, Ci, Co, D, H, W, k, precision, gn_groups) : 0;
+    const bool gn_in_epilogue = gn_stats && !roi && !keep_split && gn_epilogue_bytes(N, Ci, Co, D, H, W, k, precision) > 0;
     if (slab_bytes + gn_bytes > 0) {
         if (!workspace || workspace_bytes < slab_bytes + gn_bytes) {
             set_error("conv3d_fwd: workspace %zu bytes < required %zu", workspace_bytes, slab_bytes + gn_bytes);
@@ -646,7 +660,8 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
             }
             tile_list = (int *)((char *)workspace + workspace_bytes - list_bytes);
         }
-        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list, roi_dilate);
+        rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list, roi_dilate,
+                          gn_in_epilogue ? (float *)gn_ws : nullptr);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -670,7 +685,10 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         rc = check_launch("conv3d_fwd(splitk_reduce)");
         if (rc) return rc;
     }
-    if (gn_stats) rc = groupnorm_stats_launch(y, gn_stats, N, Co, S, gn_groups, gn_eps, gn_ws, s, gn_table);
+    if (gn_stats && gn_in_epilogue)
+        rc = groupnorm_stats_from_tiles((const float *)gn_ws, bias, gn_stats, N, Co, S, gn_groups, gn_eps, (int)fp.grid.x / N, f16x3_tile_waves(fp), s, gn_table);
+    else if (gn_stats)
+        rc = groupnorm_stats_launch(y, gn_stats, N, Co, S, gn_groups, gn_eps, gn_ws, s, gn_table);
     return rc;
 }
 
@@ -725,7 +743,7 @@ extern "C" int mphip_conv3d_fwd_split(const float *x, const float *x_range, cons
 extern "C" size_t mphip_conv3d_gn_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision,
                                                   int gn_groups) {
     if (gn_groups <= 0 || Co % gn_groups) return 0;
-    return mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, k, precision) + groupnorm_ws_bytes(N, Co, D * H * W, gn_groups);
+    return mphip_conv3d_workspace_bytes(N, Ci, Co, D, H, W, k, precision) + conv_gn_bytes(N, Ci, Co, D, H, W, k, precision, gn_groups);
 }
 
 extern "C" int mphip_conv3d_gn_fwd(const float *x, const float *x_range, const void *w_packed, const float *bias, float *y, float *gn_stats,

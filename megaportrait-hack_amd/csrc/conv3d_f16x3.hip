@@ -190,7 +190,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
                      const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                      int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
                      const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware,
-                     const int *__restrict__ roi, int roi_frames) {
+                     const int *__restrict__ roi, int roi_frames, float *__restrict__ gn_part) {
     constexpr int MT = 3, KC = F16X3_KC;
     // operand scale of the input tensor: from its range descriptor (activations: max|x| noted by the producing kernel or
     // mphip_absmax_range; gradients: mphip_grad_prep) — per tensor, a power of two
@@ -400,6 +400,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     int wb = 0;
   for (int tj = j_first; tj < ntiles; tj += (int)gridDim.x) {
     const int en = n, ed0 = d0, eh0 = h0, ew0 = w0;  // this tile's coordinates (the staging variables move on to the next tile)
+    const int etile = tile_at(tj);
     const bool has_next = tj + (int)gridDim.x < ntiles;
     asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps per-tile-invariant index math / bias loads from being hoisted into registers
     f32x16 acc[MT][NT];
@@ -577,6 +578,54 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
     const float unscale = whdr[0] * x_unscale;
     const int co0 = cot * F16X3_COT;
+    if (gn_part) {
+        // GroupNorm statistics of THIS conv's output without a pass over it: per-channel (sum, sum of squares) of the values about to
+        // be stored, as raw accumulators (the finalize kernel applies unscale and the bias in double), over the wave's 32*NT voxels -> gn_part[co][tile][wave][2]; gn_tile_finalize_kernel (norm.hip) folds a frame's
+        // tiles in double.  A register holds one channel at 32 voxel lanes (x 2 channel halves): registers 2p / 2p+1 trade 16-lane
+        // rows (v_permlane16_swap: one add halves the pair), then four rotate-adds inside a row — 6 VALU ops per channel and
+        // quantity (r02's version shuffled every register through the LDS crossbar, 960 ds_bpermute per tile and wave: -1.2 %).
+        const size_t gn_rows = (size_t)tiles_total * NWAVES;   // channel-major [Co][tile * NWAVES + wave][2]: the finalize kernel reads rows of it
+        float *gp = gn_part + ((size_t)co0 * gn_rows + (size_t)etile * NWAVES + wave) * 2;
+        if (etile == 0 && tid == 0) gn_part[(size_t)tiles_total * NWAVES * Co * 2] = unscale;   // (behind the partials; same value from every co tile)
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            float s2[8], q2[8];
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {
+                float sv[2], qv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int reg = 2 * pr + h;
+                    sv[h] = acc[m][0][reg];   // raw accumulators: the finalize kernel applies the operand unscale (a power of two) too
+                    qv[h] = acc[m][0][reg] * acc[m][0][reg];
+#pragma unroll
+                    for (int t = 1; t < NT; ++t) {
+                        sv[h] += acc[m][t][reg];
+                        qv[h] = __builtin_fmaf(acc[m][t][reg], acc[m][t][reg], qv[h]);
+                    }
+                }
+                typedef unsigned u2_ __attribute__((ext_vector_type(2)));
+                const u2_ rs = __builtin_amdgcn_permlane16_swap(__float_as_uint(sv[0]), __float_as_uint(sv[1]), false, false);
+                const u2_ rq = __builtin_amdgcn_permlane16_swap(__float_as_uint(qv[0]), __float_as_uint(qv[1]), false, false);
+                s2[pr] = __uint_as_float(rs[0]) + __uint_as_float(rs[1]);   // rows 0/2: register 2p over voxel pairs, rows 1/3: register 2p+1
+                q2[pr] = __uint_as_float(rq[0]) + __uint_as_float(rq[1]);
+#define F16X3_ROW_ADD(v_, ctrl_) v_ += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), ctrl_, 0xf, 0xf, false));
+                F16X3_ROW_ADD(s2[pr], 0x128) F16X3_ROW_ADD(q2[pr], 0x128)   // row_ror:8, :4, :2, :1 -> lane 0 of a row: the row's sum
+                F16X3_ROW_ADD(s2[pr], 0x124) F16X3_ROW_ADD(q2[pr], 0x124)
+                F16X3_ROW_ADD(s2[pr], 0x122) F16X3_ROW_ADD(q2[pr], 0x122)
+                F16X3_ROW_ADD(s2[pr], 0x121) F16X3_ROW_ADD(q2[pr], 0x121)
+#undef F16X3_ROW_ADD
+            }
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int pr = 0; pr < 8; ++pr) {
+                    const int reg = 2 * pr + ((lane >> 4) & 1);
+                    const int col = m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg;
+                    *reinterpret_cast<float2 *>(gp + (size_t)col * gn_rows * 2) = make_float2(s2[pr], q2[pr]);
+                }
+            }
+        }
+    }
     float bv[MT][16];
 #pragma unroll
     for (int m = 0; m < MT; ++m)
@@ -646,9 +695,10 @@ __global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_e
 conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                        int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames) {
+                       const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames,
+                       float *__restrict__ gn_part) {
     conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
-                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames);
+                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames, gn_part);
 }
 
 // One wave per SIMD with up to 512 registers: a wave owns 96 output channels x 128 voxels (12 accumulator tiles), so every
@@ -659,9 +709,10 @@ __global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_e
 conv3d_k3_f16x3_wide_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                             const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                             int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                            const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames) {
+                            const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames,
+                       float *__restrict__ gn_part) {
     conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
-                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames);
+                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames, gn_part);
 }
 
 // ---- k = 1: the 1x1x1 shortcut convs of G3d (model.py:510) on the same split-f16 arithmetic ---------------------------------
@@ -910,6 +961,10 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     return p;
 }
 
+int f16x3_tile_waves(const F16x3Plan &p) {   // waves per workgroup of the kernel variant f16x3_launch picks
+    return (p.variant == 2 || p.variant == 3) ? 4 : (p.variant == 1 || p.td == 4) ? 8 : 4;
+}
+
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]) {   // output tile (d,h,w) of the kernel variant f16x3_launch picks
     dims[0] = (p.variant == 1 || p.variant == 2 || p.variant == 3) ? 4 : p.td;
     dims[1] = 8;
@@ -956,7 +1011,7 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s, const int *roi,
-                 int roi_frames, int *tile_list, int roi_dilate) {
+                 int roi_frames, int *tile_list, int roi_dilate, float *gn_part) {
     if (in_affine && Ci > 768) {
         set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
         return MPHIP_EINVAL;
@@ -985,19 +1040,19 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
     if (p.variant == 3)
         hipLaunchKernelGGL((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
     else if (p.variant == 2)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
     else if (p.variant == 1)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
+                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
     else if (p.td == 4)
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
     else
         hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames);
+                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
     return check_launch("conv3d_fwd(f16x3)");
 }
 

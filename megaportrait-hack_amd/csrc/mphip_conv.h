@@ -32,8 +32,10 @@ int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int k, int trans
 // frame; > 0: the conv's frames... single frame serves that many boxes)
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s,
-                 const int *roi = nullptr, int roi_frames = 0, int *tile_list = nullptr /* 1 + plan.grid.x ints when roi */, int roi_dilate = 0);
+                 const int *roi = nullptr, int roi_frames = 0, int *tile_list = nullptr /* 1 + plan.grid.x ints when roi */, int roi_dilate = 0,
+                 float *gn_part = nullptr /* [Co][plan.grid.x][f16x3_tile_waves][2]: per-wave (sum, sumsq) of the output, splits == 1 only */);
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]);
+int f16x3_tile_waves(const F16x3Plan &p);
 
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)
@@ -55,5 +57,8 @@ struct GnTable {
 size_t groupnorm_ws_bytes(int N, int C, int S, int G);
 int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, int G, float eps, void *workspace,
                            hipStream_t s, const GnTable *tbl = nullptr);
+// ... from the per-(tile, wave, channel) partial sums (of value - bias) an f16x3 conv launch left in part [C][N*tiles_per_frame][waves][2]
+int groupnorm_stats_from_tiles(const float *part, const float *bias, float *stats, int N, int C, int S, int G, float eps, int tiles_per_frame,
+                               int waves, hipStream_t s, const GnTable *tbl = nullptr);
 
 }  // namespace mphip

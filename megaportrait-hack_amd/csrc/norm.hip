@@ -818,6 +818,59 @@ __global__ void gn_affine_table_kernel(const float *__restrict__ stats, const fl
                                        float *__restrict__ range, int N, int C, int cpg, float sqrt_ng);
 
 namespace mphip {
+// Statistics of a conv output from the conv's own epilogue partials (conv3d_f16x3.hip): part[C][tile][wave][2] holds (sum, sum of
+// squares) of the raw accumulators ((value - bias) / u, with u stored behind the partials) over the 64-or-so voxels a wave owned, in
+// fp32; a frame's tiles are consecutive.  One workgroup per (sample, group) folds tiles x waves x channels-of-the-group in double and
+// writes (mean, rstd) (+ the affine table entries, as gn_stats_direct_kernel).
+__global__ void __launch_bounds__(256)
+gn_tile_finalize_kernel(const float *__restrict__ part, const float *__restrict__ bias, float *__restrict__ stats, int tiles_per_frame,
+                        int waves, int C, int cpg, double cnt, double vox_per_row, float eps, GnTable tbl) {
+    const int grp = blockIdx.x, groups = C / cpg, n = grp / groups, g = grp % groups;
+    const int rows = tiles_per_frame * waves;   // (tile, wave) rows of this frame
+    const size_t all_rows = (size_t)(gridDim.x / groups) * rows;
+    const double u = (double)part[(size_t)C * all_rows * 2];   // the conv's accumulator -> value factor, stored behind the partials
+    double ds = 0.0, dss = 0.0;
+    for (int c = 0; c < cpg; ++c) {
+        const float2 *p = reinterpret_cast<const float2 *>(part) + (size_t)(g * cpg + c) * all_rows + (size_t)n * rows;
+        const double b = bias ? (double)bias[g * cpg + c] : 0.0;
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = threadIdx.x; r < rows; r += 256) {   // sums of the raw accumulators ((value - bias[c]) / u) over a row's voxels
+            const float2 v = p[r];
+            s1 += (double)v.x;
+            s2 += (double)v.y;
+        }
+        const double nr = (double)((rows - (int)threadIdx.x + 255) / 256) * vox_per_row;   // voxels behind this thread's rows
+        const double sa = u * s1;
+        ds += sa + nr * b;
+        dss += u * u * s2 + 2.0 * b * sa + nr * b * b;
+    }
+    ds = wave_sum(ds);
+    dss = wave_sum(dss);
+    __shared__ double red[8];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) {
+        red[wave * 2] = ds;
+        red[wave * 2 + 1] = dss;
+    }
+    __syncthreads();
+    __shared__ float mr_[2];
+    if (threadIdx.x == 0) {
+        double a = (red[0] + red[2]) + (red[4] + red[6]);
+        double b = (red[1] + red[3]) + (red[5] + red[7]);
+        double mean = a / cnt;
+        double var = b / cnt - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[grp * 2] = mr_[0] = (float)mean;
+        stats[grp * 2 + 1] = mr_[1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    if (tbl.table) {
+        __syncthreads();
+        unsigned mbits = 0;
+        if ((int)threadIdx.x < tbl.cpg) mbits = gn_table_entry(tbl, n, g * tbl.cpg + threadIdx.x, mr_[0], mr_[1]);
+        if (tbl.range) range_note_block(mbits, tbl.range, blockIdx.x, gridDim.x);
+    }
+}
+
 size_t groupnorm_ws_bytes(int N, int C, int S, int G) {
     if (N <= 0 || C <= 0 || S <= 0 || G <= 0 || C % G) return 0;
     size_t cnt = (size_t)(C / G) * S;
@@ -847,6 +900,23 @@ int groupnorm_stats_launch(const float *x, float *stats, int N, int C, int S, in
         hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, stats, tbl->gamma, tbl->beta, tbl->w2, tbl->b2,
                            tbl->table, tbl->range, N, C, C / G, sqrtf((float)(C / G) * (float)S));
     return check_launch("groupnorm_stats");
+}
+
+int groupnorm_stats_from_tiles(const float *part, const float *bias, float *stats, int N, int C, int S, int G, float eps, int tiles_per_frame,
+                               int waves, hipStream_t s, const GnTable *tbl) {
+    GnTable t;
+    if (tbl && (N * G <= (int)RANGE_MAX_PARTS) && C / G <= 256) {
+        t = *tbl;
+        t.C = C;
+        t.cpg = C / G;
+        t.sqrt_ng = sqrtf((float)(C / G) * (float)S);
+    }
+    hipLaunchKernelGGL(gn_tile_finalize_kernel, dim3(N * G), dim3(256), 0, s, part, bias, stats, tiles_per_frame, waves, C, C / G,
+                       (double)(C / G) * (double)S, (double)S / ((double)tiles_per_frame * waves), eps, t);
+    if (tbl && !t.table)
+        hipLaunchKernelGGL(gn_affine_table_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, s, stats, tbl->gamma, tbl->beta, tbl->w2, tbl->b2,
+                           tbl->table, tbl->range, N, C, C / G, sqrtf((float)(C / G) * (float)S));
+    return check_launch("groupnorm_stats(conv tiles)");
 }
 }  // namespace mphip
 
