@@ -42,9 +42,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (BASELINE config 2: 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", type=int, default=0, help="1 = replay the step as one hipGraph, 0 = eager launches (default)")
-    ap.add_argument("--inflight", type=int, default=1,
-                    help="independent batches kept in flight on their own HIP streams (throughput serving loop): the "
-                         "latency-bound head of one step (FlowField generators) overlaps the MFMA-bound body of the previous one")
+    ap.add_argument("--inflight", type=int, default=2,
+                    help="independent batches kept in flight, each on its own HIP stream with its own C-side plan (side stream, "
+                         "events, workspace): the latency-bound head and demand-driven tail of one step (few CUs busy) run beside "
+                         "the other batch's work.  The K timed steps are issued round-robin over the streams; the line's "
+                         "`one_in_flight` leg is the same loop on ONE stream (1 = only that)")
     ap.add_argument("--precision", default=None, choices=["fp32", "f16x3", "auto"],
                     help="conv arithmetic: fp32 = exact fp32 MFMA; f16x3/auto = split-f16 (3 f16 MFMAs per product, fp32-class "
                          "accuracy) where supported (default: MPHIP_CONV_PRECISION or auto)")
@@ -345,8 +347,8 @@ def roofline_hbm(hot, inp, B):
 
 
 def full_final_conv_leg(hot, inp, B, steps=20, warmup=3):
-    """The same step with G3d's last upsample + conv evaluated on EVERY voxel (MPHIP_PLAN_FULL_FINAL_CONV) — what the headline
-    would be without the demand-driven tail; same output bits."""
+    """The same step with G3d's last upsample + conv evaluated on EVERY voxel (MPHIP_PLAN_FULL_FINAL_CONV) — what `one_in_flight`
+    (steps on one stream) would be without the demand-driven tail; same output bits."""
     old = hot.full_final_conv
     hot.full_final_conv = True
     try:
@@ -362,6 +364,26 @@ def full_final_conv_leg(hot, inp, B, steps=20, warmup=3):
     finally:
         hot.full_final_conv = old
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
+
+
+def one_in_flight_leg(hot, inp, B, steps=20, warmup=3):
+    """The same K steps issued on ONE stream, each behind the previous one (r01-r02's headline loop), with the device-side spread of
+    the steps."""
+    with torch.no_grad():
+        for _ in range(warmup):
+            hot(**inp)
+        torch.cuda.synchronize()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            hot(**inp)
+            marks[i + 1].record()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+            "step_ms": {"min": round(ms[0], 3), "median": round(ms[len(ms) // 2], 3), "max": round(ms[-1], 3)}}
 
 
 def fp32_exact(hot, inp, B, steps=10, warmup=2):
@@ -571,13 +593,23 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            out = step(**inp)
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 and not args.graph else None
+        if lanes is None:
+            for _ in range(args.warmup):
+                out = step(**inp)
+        else:   # every lane's stream gets its own plan (side stream, events, packed weights): build and warm them outside the timed region
+            for lane in lanes:
+                lane.wait_stream(torch.cuda.current_stream())
+            for i in range(max(args.warmup, 2 * len(lanes))):
+                with torch.cuda.stream(lanes[i % len(lanes)]):
+                    out = step(**inp)
+            if use_plan:
+                with torch.cuda.stream(lanes[0]):
+                    plan = hot._plan_for(inp["vs"])   # (the dominant-conv events come from lane 0's plan)
         sync_all()
         dom.active = not args.graph
         if use_plan:
             plan.profile(True)
-        lanes = [torch.cuda.Stream(device=dev) for _ in range(max(1, args.inflight))] if args.inflight > 1 and not args.graph else None
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if lanes is None else None
         t0 = time.perf_counter()
         if lanes is None:
@@ -637,7 +669,10 @@ def main():
                                    "96ch 16x64x64 volume), inputs resident in HBM, random-init weights",
                        "frames_per_gpu_per_step": B, "global_batch": world * B, "parallelism": f"dp{world} (frame shards, no collective)",
                        "launch": ("hipGraph replay of the captured step" if args.graph else
-                                  "one call per step into the C-side plan (mphip_hot_slice_forward), eager stream launches" if use_plan else
+                                  ("one call per step into the C-side plan (mphip_hot_slice_forward), eager stream launches"
+                                   + (f"; the K steps are issued round-robin over {len(lanes)} HIP streams, each with its own plan "
+                                      "(independent batches in flight: `one_in_flight` is the same loop on one stream)" if lanes else ""))
+                                  if use_plan else
                                   "eager stream launches, per-op Python schedule"),
                        "final_conv": ("demand-driven: only the tiles the final warp reads (mphip_conv3d_fwd_roi)" if demand else "evaluated everywhere"),
                        "batches_in_flight": 1 if (args.graph or args.inflight < 2) else args.inflight},
@@ -678,6 +713,8 @@ def main():
                 line[key] = fn(*a, **kw)
                 secs[key] = round(time.perf_counter() - t0_, 1)
 
+            if lanes is not None and use_plan:
+                leg("one_in_flight", one_in_flight_leg, hot, inp, B)
             if demand:
                 leg("full_final_conv", full_final_conv_leg, hot, inp, B)
             leg("roofline_hbm", roofline_hbm, hot, inp, B)

@@ -1,13 +1,11 @@
 cd $GRAFT_REPO_ROOT
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_plan.py tests/test_gpu_backward.py -q -x 2>&1 | grep -E "passed|failed|Error|error" | head -5
-for i in 1 2; do
-python tools/bench_plan.py 2>&1 | grep "^B=8"
-MPHIP_GN_EPILOGUE=0 python tools/bench_plan.py 2>&1 | grep "^B=8"
-done
-out=gpurun_out/r03_b1; mkdir -p $out
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $out/kt -- python tools/run_plan_steps.py 8 30 > $out/log8.txt 2>&1
-db=$(find $out/kt -name "*.db" | head -1)
-python tools/lane_timeline.py $db 4.6 > $out/timeline_b8_gnep1.txt
-rm -rf $out/kt
-grep gn_tile_finalize $out/timeline_b8_gnep1.txt | head -8
+( time python bench.py 2>gpurun_out/bench_err.log ) > gpurun_out/r03_bench_default.log 2>&1
+tail -4 gpurun_out/r03_bench_default.log | cut -c1-300
+python - <<'PY'
+import json
+l=[x for x in open('gpurun_out/r03_bench_default.log') if x.startswith('{')][-1]
+d=json.loads(l)
+print(d['value'], d['ms_per_step'], d['config']['batches_in_flight'], d.get('one_in_flight'), d.get('full_final_conv'), d['roofline']['launch_ms'], d['roofline']['frac'])
+print({k:(v.get('value') if isinstance(v,dict) else v) for k,v in d.items() if k in ('train_step','reenact_1x64','end_to_end','end_to_end_autocast_fp16','fp32_exact')})
+print(d.get('leg_seconds'))
+PY

@@ -474,7 +474,10 @@ class _HotSliceRunner:
     def _plan_for(self, vs):
         from . import plan as _plan
 
-        key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators), bool(self.full_final_conv))
+        # one plan per caller stream: a plan owns ONE side stream and one fork/join event pair, so callers that keep several batches in
+        # flight on several streams get independent generator lanes (and their own packed weights: ~230 MB per plan)
+        key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators), bool(self.full_final_conv),
+               torch.cuda.current_stream(vs.device).cuda_stream)
         table = self.__dict__.setdefault("_plans", {})
         pl = table.get(key)
         if pl is None:
