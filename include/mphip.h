@@ -383,7 +383,9 @@ int mphip_conv3d_bwd_weight_roi(const float *x, const float *x_range, const floa
  *   forward: vs [B,96,D,H,W], es/zs/zd [B,512], Rs/Rd [B,3] Euler degrees, ts/td [B,3] -> out [B,96,H,W]; any B (more than
  *          MPHIP_PLAN_MAX_FRAMES_PER_PASS frames run as consecutive passes).  No allocation, no host sync: capturable in a
  *          hipGraph after one warm-up call (the first call of a batch size allocates the packed weights).  Two forwards
- *          of one plan in flight on different streams need different workspaces.
+ *          of one plan in flight on different streams need different workspaces — and share the plan's ONE side stream, so
+ *          their second generator chains run one after the other: a caller that keeps several batches in flight (a serving
+ *          loop; bench.py's default) creates one plan per stream (measured: +7 % with two plans, +2-3 % with one shared).
  *   mphip_g3d_forward: x [B,96,D,H,W] (+ its range descriptor or NULL) -> y [B,96,D,H,W], B <= MPHIP_PLAN_MAX_FRAMES_PER_PASS. */
 typedef struct mphip_hot_slice_plan mphip_hot_slice_plan;
 #define MPHIP_PLAN_G3D_ONLY 1

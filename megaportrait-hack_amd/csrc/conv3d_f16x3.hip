@@ -664,24 +664,9 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 // Demand-driven conv: the ids of the output tiles (TD x TH x TW voxels, id = ((n*tiles_d + td)*tiles_h + th)*tiles_w + tw) that
 // one of the sample boxes {lx,ly,lz,ex,ey,ez,-,-} touches -> list = {count, id, ...}.  roi_frames == 0: box n belongs to frame n;
 // > 0: the single frame serves that many boxes.  One workgroup; the order of the ids is irrelevant (tiles are independent).
-// Workgroups 1.. warm the L2s: the handful of workgroups a demand-driven launch runs each stream the WHOLE packed weight tensor
-// (1 MB for 96->96) through one CU, slab group by slab group, and with two tiles per XCD nearly every group is an L2 miss served at
-// Infinity-Cache / HBM latency (measured 3.5 us per 55 KB group).  Workgroup ids go round-robin over the 8 XCDs, so workgroup 1 + 8*i + x
-// reads the i-th eighth of the weights into XCD x's L2 while workgroup 0 builds the list.
 __global__ void __launch_bounds__(1024)
 roi_tile_list_kernel(const int *__restrict__ roi, int roi_frames, int tiles_total, int D, int H, int W, int TD, int TH, int TW,
-                     int dilate, int *__restrict__ list, const uint4 *__restrict__ warm, size_t warm_vecs) {
-    if (blockIdx.x > 0) {
-        const int xcd_part = (int)(blockIdx.x - 1) / 8, parts = ((int)gridDim.x - 1) / 8;
-        const size_t per = (warm_vecs + parts - 1) / parts, lo = (size_t)xcd_part * per, hi = lo + per < warm_vecs ? lo + per : warm_vecs;
-        unsigned acc = 0;
-        for (size_t i = lo + threadIdx.x; i < hi; i += 1024) {
-            const uint4 v = warm[i];
-            acc ^= v.x ^ v.y ^ v.z ^ v.w;
-        }
-        asm volatile("" ::"v"(acc));   // (the loads are the point)
-        return;
-    }
+                     int dilate, int *__restrict__ list) {
     __shared__ int cnt;
     if (threadIdx.x == 0) cnt = 0;
     __syncthreads();
@@ -1037,10 +1022,10 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     if (roi) {   // demand-driven: boxes -> the list of tiles they touch (1 + tiles ints of caller workspace); the kernel gets the LIST
         int dims[3];
         f16x3_tile_dims(p, dims);
-        static const bool warm_off = getenv("MPHIP_ROI_WARM") && getenv("MPHIP_ROI_WARM")[0] == '0';   // dev: same-box A/B
-        const size_t warm_vecs = (f16x3_packed_bytes(Co, Ci) - 16) / 16;
-        hipLaunchKernelGGL(roi_tile_list_kernel, dim3(warm_off ? 1 : 1 + 8 * 8), dim3(1024), 0, s, roi, roi_frames, (int)p.grid.x, D, H, W, dims[0],
-                           dims[1], dims[2], roi_dilate, tile_list, (const uint4 *)slabs, warm_vecs);
+        // (r03: extra workgroups of this launch pre-reading the packed weights into every XCD's L2 changed nothing — a demand-driven
+        //  tile is one CU's MFMA work, 2592 K-steps x 9 MFMAs per wave, not a chain of L2 misses)
+        hipLaunchKernelGGL(roi_tile_list_kernel, dim3(1), dim3(1024), 0, s, roi, roi_frames, (int)p.grid.x, D, H, W, dims[0], dims[1], dims[2],
+                           roi_dilate, tile_list);
         roi = tile_list;
     }
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
