@@ -25,6 +25,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Two batches in flight = four HIP streams (two callers + their plans' side streams) next to the null stream.  The ROCm runtime
+# multiplexes streams onto 4 hardware queues by default, and a queue is in-order: one lane's side chain then waits behind the other
+# lane's convs (profiles/r03_timeline_two_in_flight.txt).  Eight queues give every stream its own (same box: 3.65 -> 3.55 ms/step).
+# Must be in the environment before the HIP runtime initialises; an explicit setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import torch
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
@@ -675,7 +681,8 @@ def main():
                                   if use_plan else
                                   "eager stream launches, per-op Python schedule"),
                        "final_conv": ("demand-driven: only the tiles the final warp reads (mphip_conv3d_fwd_roi)" if demand else "evaluated everywhere"),
-                       "batches_in_flight": 1 if (args.graph or args.inflight < 2) else args.inflight},
+                       "batches_in_flight": 1 if (args.graph or args.inflight < 2) else args.inflight,
+                       "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "rank0_host_pinning": pinned or None,
             "step_ms": ({"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)}
