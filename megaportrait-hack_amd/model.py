@@ -479,11 +479,17 @@ class _HotSliceRunner:
         key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators), bool(self.full_final_conv),
                torch.cuda.current_stream(vs.device).cuda_stream)
         table = self.__dict__.setdefault("_plans", {})
-        pl = table.get(key)
+        pl = table.pop(key, None)
         if pl is None:
-            pl = table[key] = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators,
-                                                 full_final_conv=self.full_final_conv)
+            pl = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators,
+                                    full_final_conv=self.full_final_conv)
+        table[key] = pl   # (most recently used last)
+        while len(table) > self._MAX_PLANS:   # a caller that keeps making new streams must not keep every plan's packed weights
+            torch.cuda.synchronize(vs.device)
+            table.pop(next(iter(table))).close()
         return pl
+
+    _MAX_PLANS = 6
 
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)

@@ -69,6 +69,36 @@ def test_plan_is_the_default_inference_path(dev, M):
     assert torch.equal(a, b)
 
 
+def test_one_plan_per_caller_stream(dev, M):
+    """A plan owns one side stream and one fork/join event pair, so GbaseHotSlice keeps one plan per caller stream (two batches in
+    flight on two streams = two independent plans: bench.py's default loop).  Same bits on every stream, interleaved calls included;
+    the table is bounded (least recently used plans are closed)."""
+    hot = _hot(M, dev)
+    a = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 7, D=8, H=16, W=16).items()}
+    b = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 8, D=8, H=16, W=16).items()}
+    with torch.no_grad():
+        want_a, want_b = hot.forward_any_size(**a).clone(), hot.forward_any_size(**b).clone()
+        assert len(hot.__dict__["_plans"]) == 1
+        lanes = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        for ln in lanes:
+            ln.wait_stream(torch.cuda.current_stream())
+        outs = []
+        for i in range(8):   # interleaved, nothing waits on anything in between
+            with torch.cuda.stream(lanes[i % 2]):
+                outs.append(hot.forward_any_size(**(a if i % 2 == 0 else b)))
+        torch.cuda.synchronize()
+        assert len(hot.__dict__["_plans"]) == 3
+        for i, o in enumerate(outs):
+            assert torch.equal(o, want_a if i % 2 == 0 else want_b)
+        many = [torch.cuda.Stream(device=dev) for _ in range(hot._MAX_PLANS + 2)]
+        for st in many:
+            st.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(st):
+                assert torch.equal(hot.forward_any_size(**a), want_a)
+        assert len(hot.__dict__["_plans"]) == hot._MAX_PLANS
+        assert torch.equal(hot.forward_any_size(**b), want_b)   # (the default stream's plan was evicted and is rebuilt)
+
+
 def test_plan_honours_the_conv_precision_switch(dev, M):
     """ops.set_conv_precision('fp32') (bench.py's `fp32_exact` leg, MPHIP_CONV_PRECISION) must reach the plan's launches."""
     from megaportrait_hack_amd import ops
