@@ -65,6 +65,9 @@ def parse():
                     help="infer (default) = the graded metric, BASELINE config 2; train = one training step of the hot slice "
                          "(forward + backward + SGD, BASELINE config 3's per-GPU shard: --batch 4) with the RCCL gradient "
                          "all-reduce when --gpus > 1 — a side measurement, separate JSON line")
+    ap.add_argument("--single-stream-plan", action="store_true",
+                    help="dev: plans without a side stream (MPHIP_PLAN_SINGLE_STREAM): both generator chains on the caller's stream, no "
+                         "cross-stream event anywhere in a step")
     ap.add_argument("--dry-launch", action="store_true",
                     help="with --gpus N > 1 and no torchrun environment: print the torch.distributed.run command the "
                          "self-launcher would execute (one JSON line) and exit")
@@ -566,6 +569,8 @@ def main():
 
     dom = DominantKernelTimer((96, 96, 16, 64, 64))
     step = hot
+    if args.single_stream_plan:
+        hot.overlap_generators = False
     use_plan = bool(hot.use_c_plan and not args.graph and not args.per_op)
     if args.full_final_conv:
         hot.full_final_conv = True
