@@ -375,13 +375,15 @@ def full_final_conv_leg(hot, inp, B, steps=20, warmup=3):
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps}
 
 
-def one_in_flight_leg(hot, inp, B, steps=20, warmup=3):
+def one_in_flight_leg(hot, inp, B, steps=20, warmup=3, peak=PEAK_F16_MFMA_TFLOPS):
     """The same K steps issued on ONE stream, each behind the previous one (r01-r02's headline loop), with the device-side spread of
-    the steps."""
+    the steps and the dominant conv's launch time there (no other batch's kernels between its two events)."""
+    plan = hot._plan_for(inp["vs"])
     with torch.no_grad():
         for _ in range(warmup):
             hot(**inp)
         torch.cuda.synchronize()
+        plan.profile(True)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
         t0 = time.perf_counter()
         marks[0].record()
@@ -391,8 +393,14 @@ def one_in_flight_leg(hot, inp, B, steps=20, warmup=3):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
     ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:]))
+    tot, cnt = plan.profile_read(0)
+    plan.profile(False)
+    dom_ms = tot / max(1, cnt)
+    tf = 2.0 * B * 16 * 64 * 64 * 96 * 96 * 27 / (dom_ms * 1e-3) / 1e12 if cnt else None
     return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-            "step_ms": {"min": round(ms[0], 3), "median": round(ms[len(ms) // 2], 3), "max": round(ms[-1], 3)}}
+            "step_ms": {"min": round(ms[0], 3), "median": round(ms[len(ms) // 2], 3), "max": round(ms[-1], 3)},
+            "dominant_conv": ({"launch_ms": round(dom_ms, 4), "launches_timed": cnt, "achieved": round(tf, 2), "unit": "TFLOP/s",
+                               "peak": peak, "frac": round(tf / peak, 4)} if cnt else None)}
 
 
 def fp32_exact(hot, inp, B, steps=10, warmup=2):
@@ -707,7 +715,10 @@ def main():
                                   f"vs the fp32-MFMA peak ({PEAK_F32_MFMA_TFLOPS}) the algorithmic rate is "
                                   f"{round(achieved / PEAK_F32_MFMA_TFLOPS, 2)}x.  The kernel is power-bound: the package sits at its "
                                   "1400 W limit with the clock throttled to ~1.7-2.0 GHz while it runs (profiles/r02_power_probe.txt); the "
-                                  "2500 TFLOP/s peak assumes 2.4 GHz") if f16x3 else
+                                  "2500 TFLOP/s peak assumes 2.4 GHz"
+                                  + ("; with several batches in flight the two events around a launch also see the time the launch "
+                                     "waits for CUs another batch's kernel still holds: `one_in_flight.dominant_conv` is the same "
+                                     "measurement with the steps on one stream" if lanes else "")) if f16x3 else
                                  "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
         }
         if world == 1 and not args.no_extras:
@@ -726,7 +737,7 @@ def main():
                 secs[key] = round(time.perf_counter() - t0_, 1)
 
             if lanes is not None and use_plan:
-                leg("one_in_flight", one_in_flight_leg, hot, inp, B)
+                leg("one_in_flight", one_in_flight_leg, hot, inp, B, peak=peak)
             if demand:
                 leg("full_final_conv", full_final_conv_leg, hot, inp, B)
             leg("roofline_hbm", roofline_hbm, hot, inp, B)

@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-out=gpurun_out/r03_ss; rm -rf $out; mkdir -p $out
-export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d $out/kt -- python bench.py --no-extras --no-cpu-baseline --steps 20 --warmup 5 --single-stream-plan > $out/log.txt 2>&1
-db=$(find $out/kt -name "*.db" | head -1)
-python tools/lane_timeline.py $db 8.0 > $out/timeline_ss2.txt
-rm -rf $out/kt
+for f in 1 2; do
+python bench.py --no-cpu-baseline --extras-budget 1 --steps 40 --warmup 6 --inflight $f 2>gpurun_out/bench_err.log | tail -1 | python -c "
+import sys,json; d=json.loads(sys.stdin.read()); print('inflight', d['config']['batches_in_flight'], d['value'], d['ms_per_step'], 'conv', d['roofline']['launch_ms'], d['roofline']['frac'], d['roofline']['launches_timed'], 'demand', (d['roofline'].get('demand_driven_launch') or {}).get('launch_ms'), 'one_in_flight', (d.get('one_in_flight') or {}).get('dominant_conv'))"
+done
+python -m pytest tests/test_gpu_plan.py -q -x 2>&1 | tail -2

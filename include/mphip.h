@@ -154,8 +154,9 @@ int mphip_conv3d_gn_table_fwd(const float *x, const float *x_range, const void *
                               const float *gamma, const float *beta, const float *w2, const float *b2, float *table, float *table_range,
                               int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups, float gn_eps,
                               void *workspace, size_t workspace_bytes, void *stream);
-/* measurement: the next conv launch on this thread is bracketed by these two HIP events (hipEvent_t), recorded on the launch stream
- * right before / after the conv kernel itself */
+/* measurement: the next conv launch on this thread carries these two HIP events (hipEvent_t).  The f16x3 3x3x3 kernels are launched
+ * with them attached (hipExtLaunchKernelGGL: they take the kernel's own begin / end — time spent waiting for CUs that another stream's
+ * kernel holds is not counted); every other conv kernel has them recorded on the launch stream right before / after it. */
 void mphip_conv3d_time_next_launch(void *event_begin, void *event_end);
 int mphip_conv3d_gnin_fwd(const float *x, const float *in_affine, const float *x_range, int in_relu, const void *w_packed,
                           const float *bias, float *y, int N, int Ci, int Co, int D, int H, int W, int k,

@@ -647,7 +647,8 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     int rc;
     hipEvent_t te0 = g_time_e0, te1 = g_time_e1;
     g_time_e0 = g_time_e1 = nullptr;
-    if (te0) (void)hipEventRecord(te0, s);
+    const bool stamp = te0 && te1 && precision == 1 && k == 3;   // the f16x3 3x3x3 kernels carry the events themselves (kernel begin / end)
+    if (te0 && !stamp) (void)hipEventRecord(te0, s);
     if (precision == 1 && k == 1) {
         rc = f16x3_launch_k1(x, w_packed, bias, dst, N, Ci, Co, D * H * W, x_range, s);
     } else if (precision == 1) {
@@ -661,7 +662,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
             tile_list = (int *)((char *)workspace + workspace_bytes - list_bytes);
         }
         rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list, roi_dilate,
-                          gn_in_epilogue ? (float *)gn_ws : nullptr);
+                          gn_in_epilogue ? (float *)gn_ws : nullptr, stamp ? te0 : nullptr, stamp ? te1 : nullptr);
     } else {
         const float *wf = (const float *)w_packed;
         if (p.tiled == 4)
@@ -674,7 +675,7 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         else dispatch_mt<1>(p, x, wf, bias, dst, N, Ci, Co, D, H, W, (unsigned)x_bytes, s);
         rc = check_launch("conv3d_fwd");
     }
-    if (te1) (void)hipEventRecord(te1, s);
+    if (te1 && !stamp) (void)hipEventRecord(te1, s);
     if (rc) return rc;
     const int S = D * H * W;
     if (splits > 1 && !keep_split) {

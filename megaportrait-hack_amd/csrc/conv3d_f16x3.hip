@@ -22,6 +22,8 @@
 
 #include <algorithm>
 
+#include <hip/hip_ext.h>
+
 #include "mphip_common.h"
 #include "mphip_conv.h"
 
@@ -1011,7 +1013,7 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
 
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_scale, hipStream_t s, const int *roi,
-                 int roi_frames, int *tile_list, int roi_dilate, float *gn_part) {
+                 int roi_frames, int *tile_list, int roi_dilate, float *gn_part, hipEvent_t t0, hipEvent_t t1) {
     if (in_affine && Ci > 768) {
         set_error("conv3d_fwd(f16x3): fused input GroupNorm supports Ci <= 768 (got %d)", Ci);
         return MPHIP_EINVAL;
@@ -1040,21 +1042,23 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');  // dev switch for same-box A/B
     // (two-slab groups for the 512-voxel tile — 5 instead of 9 barriers per chunk, 147 KB of LDS — were tried: the
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
-    if (p.variant == 3)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
-    else if (p.variant == 2)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
-    else if (p.variant == 1)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co,
-                           D, H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
-    else if (p.td == 4)
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
-    else
-        hipLaunchKernelGGL((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D,
-                           H, W, p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);
+    // (t0, t1: the measurement hook's events ride on the kernel command itself — hipExtLaunchKernelGGL stamps them with the kernel's own
+    //  begin / end, so what another stream's kernel makes this launch WAIT for CUs is not counted as its duration)
+#define F16X3_LAUNCH(kern_, block_)                                                                                              \
+    {                                                                                                                            \
+        if (t0 && t1)                                                                                                            \
+            hipExtLaunchKernelGGL(kern_, grid, dim3(block_), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W,      \
+                                  p.chunks_per_split, xb, in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part); \
+        else                                                                                                                     \
+            hipLaunchKernelGGL(kern_, grid, dim3(block_), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, p.chunks_per_split, xb, \
+                               in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);                      \
+    }
+    if (p.variant == 3) F16X3_LAUNCH((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), 256)
+    else if (p.variant == 2) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), 256)
+    else if (p.variant == 1) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), 512)
+    else if (p.td == 4) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), 512)
+    else F16X3_LAUNCH((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), 256)
+#undef F16X3_LAUNCH
     return check_launch("conv3d_fwd(f16x3)");
 }
 

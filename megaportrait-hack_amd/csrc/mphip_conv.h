@@ -33,7 +33,8 @@ int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int k, int trans
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,
                  int Co, int D, int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s,
                  const int *roi = nullptr, int roi_frames = 0, int *tile_list = nullptr /* 1 + plan.grid.x ints when roi */, int roi_dilate = 0,
-                 float *gn_part = nullptr /* [Co][plan.grid.x][f16x3_tile_waves][2]: per-wave (sum, sumsq) of the output, splits == 1 only */);
+                 float *gn_part = nullptr /* [Co][plan.grid.x][f16x3_tile_waves][2]: per-wave (sum, sumsq) of the output, splits == 1 only */,
+                 hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr /* stamped with the conv kernel's own begin / end */);
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]);
 int f16x3_tile_waves(const F16x3Plan &p);
 
