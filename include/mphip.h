@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 7
+#define MPHIP_ABI_VERSION 8
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -154,6 +154,17 @@ int mphip_conv3d_gn_table_fwd(const float *x, const float *x_range, const void *
                               const float *gamma, const float *beta, const float *w2, const float *b2, float *table, float *table_range,
                               int N, int Ci, int Co, int D, int H, int W, int k, int precision, int gn_groups, float gn_eps,
                               void *workspace, size_t workspace_bytes, void *stream);
+/* FlowField's first three residual blocks (reference model.py:369-408 at the fixed levels of model.py:439-471) in two launches per block:
+ *   y = upsample_nearest(relu?(AGN(conv3x3x3(x) + b) [+ conv1x1x1(res_x) + res_b]))      AGN: GroupNorm(groups) * gamma + beta, then * w2 + b2
+ * One workgroup owns a whole (frame, GroupNorm group): full input-channel loop, statistics, both affines, residual conv, ReLU and the
+ * nearest upsample in ONE launch, from the ORIGINAL weights (w [Co,Ci,3,3,3], res_w [Co,Cr,1,1,1]; no packed copy).  Shapes: the levels
+ * of FlowField only — (Co, D, H, W) in {(256,4,1,1), (128,8,2,2), (64,16,4,4)}, 32 groups, Ci (and Cr) a multiple of the level's
+ * slice count (128, 128, 16); _supported returns the level (1-3) or 0.  x [N,Ci,D,H,W], res_x [N,Cr,D,H,W] or NULL (Cr = 0),
+ * y [N,Co,D*uD,H*uH,W*uW]. */
+int mphip_flowfield_conv_gn_supported(int Ci, int Co, int D, int H, int W, int Cr, int groups);
+int mphip_flowfield_conv_gn(const float *x, const float *w, const float *b, const float *gamma, const float *beta, const float *w2,
+                            const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci, int Co,
+                            int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu, void *stream);
 /* measurement: the next conv launch on this thread carries these two HIP events (hipEvent_t).  The f16x3 3x3x3 kernels are launched
  * with them attached (hipExtLaunchKernelGGL: they take the kernel's own begin / end — time spent waiting for CUs that another stream's
  * kernel holds is not counted); every other conv kernel has them recorded on the launch stream right before / after it. */

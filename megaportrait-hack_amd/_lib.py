@@ -80,6 +80,8 @@ SIGNATURES = {
     "mphip_upsample_trilinear2_bwd_workspace_bytes": (_sz, [_i] * 4),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_field_coords": (_i, [_p] * 7 + [_i] * 6 + [_p]),
+    "mphip_flowfield_conv_gn_supported": (_i, [_i] * 7),
+    "mphip_flowfield_conv_gn": (_i, [_p] * 11 + [_i] * 11 + [ctypes.c_float, _i, _p]),
     "mphip_warp_volume_coords": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_warp_sample_box": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_conv3d_roi_granule": (_i, [_i] * 8 + [_p]),

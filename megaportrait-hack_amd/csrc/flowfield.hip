@@ -1,0 +1,321 @@
+// K1b — the first three residual blocks of FlowField (reference model.py:369-408 at the fixed levels of model.py:439-471: 512->256 @4x1x1,
+// 256->128 @8x2x2, 128->64 @16x4x4) as TWO launches per block instead of five:
+//   A:  a   = relu(AGN1(conv1(x)))
+//   B:  out = upsample_nearest(relu(AGN2(conv2(a)) + residual_conv(x)))
+// These tensors are tiny (<= 256 voxels per frame) and the chain of ~25 dependent 5-30 us launches per generator was what the head of
+// every step cost (DESIGN.md "Small-volume path").  The split-K gather convs needed a second launch per conv to fold their slabs before
+// the GroupNorm could see a whole group; here ONE workgroup owns a whole (frame, GroupNorm group): it runs the full input-channel
+// loop for the group's channels — sliced over its own 512-1024 threads and folded through LDS in slice order — so the statistics, both affines,
+// the residual 1x1x1 conv, ReLU and the nearest upsample happen in the same launch.  32 groups x 8 frames = 256 workgroups = the chip.
+// Arithmetic: fp32 FMA chains from the ORIGINAL [Co][Ci][27] weights (no packed copy to refresh after an optimizer step).
+//
+// Two thread mappings (all shapes are compile-time: the levels of FlowField do not depend on the image size):
+//   PLANE (4x1x1, 8x2x2):  thread = (channel of the group, slice of the input channels); the whole input plane of one input channel
+//                           lives in registers and every in-bounds (output voxel, tap) pair is one unrolled FMA.
+//   ROW   (16x4x4):         thread = (one w-row of outputs, slice of the input channels); per input channel the 9 neighbouring rows are
+//                           loaded once (16-byte loads) and feed 3 taps x W outputs x the group's channels; the weights of a slice
+//                           are wave-uniform (scalar loads).
+#include <stdlib.h>
+
+#include "mphip_common.h"
+
+namespace mphip {
+
+struct FfParams {
+    const float *x, *w, *b;                    // [N,Ci,S], [Co,Ci,27], [Co]
+    const float *gamma, *beta, *w2, *b2;       // group_norm.{weight,bias}, AdaptiveGroupNorm.{weight,bias} (model.py:304-316)
+    const float *rx, *rw, *rb;                 // residual 1x1x1 conv: input [N,Cr,S], weight [Co,Cr], bias [Co] (or all null)
+    float *y;                                  // [N,Co,D*uD,H*uH,W*uW]
+    int Ci, Co, Cr, uD, uH, uW, relu;
+    float eps;
+};
+
+__device__ __forceinline__ double ff_wave_sum(double v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+    return v;
+}
+
+// GroupNorm over the group's CPG*S values in LDS (bias already added), both affines, residual, ReLU, nearest upsample -> y.
+// Every thread of the 256 calls it (barriers inside).
+template <int D, int H, int W, int CPG, int NT>
+__device__ __forceinline__ void ff_finish(const FfParams &p, const float *__restrict__ vals, const float *__restrict__ res, int n, int c0,
+                                          double *red /* [2 * NT / 64] */, float *mr /* [2] */) {
+    constexpr int S = D * H * W, CNT = CPG * S;
+    const int tid = threadIdx.x;
+    float s = 0.0f, ss = 0.0f;
+    for (int e = tid; e < CNT; e += NT) {
+        const float v = vals[e];
+        s += v;
+        ss += v * v;
+    }
+    const double ds = ff_wave_sum((double)s), dss = ff_wave_sum((double)ss);
+    if ((tid & 63) == 0) {
+        red[(tid >> 6) * 2] = ds;
+        red[(tid >> 6) * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double a = 0.0, b = 0.0;
+        for (int wv = 0; wv < NT / 64; ++wv) {   // wave order: deterministic
+            a += red[wv * 2];
+            b += red[wv * 2 + 1];
+        }
+        const double mean = a / (double)CNT;
+        double var = b / (double)CNT - mean * mean;
+        if (var < 0.0) var = 0.0;
+        mr[0] = (float)mean;
+        mr[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    __syncthreads();
+    const float mean = mr[0], rstd = mr[1];
+    const int oH = H * p.uH, oW = W * p.uW, oD = D * p.uD;
+    const size_t oS = (size_t)oD * oH * oW;
+    for (int e = tid; e < CNT; e += NT) {
+        const int c = e / S, i = e - c * S, ch = c0 + c;
+        float v = (vals[e] - mean) * rstd * p.gamma[ch] + p.beta[ch];
+        if (p.w2) v = v * p.w2[ch] + p.b2[ch];
+        if (res) v += res[e] + (p.rb ? p.rb[ch] : 0.0f);
+        if (p.relu) v = fmaxf(v, 0.0f);
+        const int d = i / (H * W), h = (i / W) % H, w = i % W;
+        float *dst = p.y + ((size_t)n * p.Co + ch) * oS;
+        for (int a = 0; a < p.uD; ++a)
+            for (int b = 0; b < p.uH; ++b)
+                for (int cc = 0; cc < p.uW; ++cc) dst[((size_t)(d * p.uD + a) * oH + h * p.uH + b) * oW + w * p.uW + cc] = v;
+    }
+}
+
+// Fold the KS per-slice partial results red_[(k*CPG + c)*S + o] into dst[c*S + o] (+ bias[c0 + c]): NT / (CPG*S) threads share an output
+// (contiguous slice ranges, then the ranges in order — a fixed tree: deterministic).  Every thread calls it (barriers inside).
+template <int CPG, int S, int KS, int NT>
+__device__ __forceinline__ void ff_fold(const float *__restrict__ red_, float *__restrict__ part_, float *__restrict__ dst,
+                                        const float *__restrict__ bias, int c0) {
+    constexpr int OUT = CPG * S, PARTS = (NT / OUT) < 1 ? 1 : ((NT / OUT) > KS ? KS : (NT / OUT)), PER = KS / PARTS;
+    static_assert(KS % PARTS == 0, "slices split evenly over the folding threads");
+    const int tid = threadIdx.x;
+    for (int t = tid; t < OUT * PARTS; t += NT) {
+        const int e = t % OUT, q = t / OUT, cc = e / S, o = e - cc * S;
+        float v = red_[((q * PER) * CPG + cc) * S + o];
+        for (int kk = q * PER + 1; kk < (q + 1) * PER; ++kk) v += red_[(kk * CPG + cc) * S + o];
+        part_[t] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < OUT; e += NT) {
+        float v = part_[e];
+        for (int q = 1; q < PARTS; ++q) v += part_[q * OUT + e];
+        dst[e] = v + (bias ? bias[c0 + e / S] : 0.0f);
+    }
+}
+
+// ---- PLANE: thread = (channel c of the group, input-channel slice k); KS = NT / CPG slices (a slice is 1-4 input channels: the
+// loop is a chain of dependent global-load round trips, so the workgroup is made as wide as the channel count allows) --------------------------------------
+template <int D, int H, int W, int CPG, int NT>
+__global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
+    constexpr int S = D * H * W, KS = NT / CPG;
+    static_assert(S % 4 == 0 && S <= 32, "plane mapping: the input plane lives in registers");
+    const int tid = threadIdx.x, c = tid % CPG, k = tid / CPG;
+    const int groups = p.Co / CPG, n = blockIdx.x / groups, g = blockIdx.x % groups, c0 = g * CPG;
+    __shared__ float red_[KS * CPG * S];
+    __shared__ float vals[CPG * S], resv[CPG * S], part_[NT > CPG * S ? NT : CPG * S];
+    __shared__ double dred[2 * NT / 64];
+    __shared__ float mr[2];
+
+    float acc[S];
+#pragma unroll
+    for (int o = 0; o < S; ++o) acc[o] = 0.0f;
+    const int per = p.Ci / KS;   // 1..4 input channels: unrolled, so that every load of the slice is in flight at once
+#pragma unroll 4
+    for (int ci = k * per; ci < (k + 1) * per; ++ci) {
+        float xp[S], wv[27];
+        const float4 *xs = reinterpret_cast<const float4 *>(p.x + ((size_t)n * p.Ci + ci) * S);
+#pragma unroll
+        for (int q = 0; q < S / 4; ++q) {
+            const float4 v = xs[q];
+            xp[q * 4] = v.x; xp[q * 4 + 1] = v.y; xp[q * 4 + 2] = v.z; xp[q * 4 + 3] = v.w;
+        }
+        const float *wp = p.w + ((size_t)(c0 + c) * p.Ci + ci) * 27;
+#pragma unroll
+        for (int t = 0; t < 27; ++t) wv[t] = wp[t];   // (taps that no output of this shape can use are never loaded: dead after unrolling)
+#pragma unroll
+        for (int od = 0; od < D; ++od)
+#pragma unroll
+            for (int oh = 0; oh < H; ++oh)
+#pragma unroll
+                for (int ow = 0; ow < W; ++ow)
+#pragma unroll
+                    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+                        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                            for (int kw = 0; kw < 3; ++kw) {
+                                const int id = od + kd - 1, ih = oh + kh - 1, iw = ow + kw - 1;
+                                if (id >= 0 && id < D && ih >= 0 && ih < H && iw >= 0 && iw < W)
+                                    acc[(od * H + oh) * W + ow] =
+                                        __builtin_fmaf(wv[kd * 9 + kh * 3 + kw], xp[(id * H + ih) * W + iw], acc[(od * H + oh) * W + ow]);
+                            }
+    }
+#pragma unroll
+    for (int o = 0; o < S; ++o) red_[(k * CPG + c) * S + o] = acc[o];
+    __syncthreads();
+    ff_fold<CPG, S, KS, NT>(red_, part_, vals, p.b, c0);
+    if (p.rx) {   // (uniform) residual 1x1x1 conv of the block input, same slicing
+        __syncthreads();
+#pragma unroll
+        for (int o = 0; o < S; ++o) acc[o] = 0.0f;
+        const int perr = p.Cr / KS;
+#pragma unroll 4
+        for (int cr = k * perr; cr < (k + 1) * perr; ++cr) {
+            const float wr = p.rw[(size_t)(c0 + c) * p.Cr + cr];
+            const float4 *xs = reinterpret_cast<const float4 *>(p.rx + ((size_t)n * p.Cr + cr) * S);
+#pragma unroll
+            for (int q = 0; q < S / 4; ++q) {
+                const float4 v = xs[q];
+                acc[q * 4] = __builtin_fmaf(wr, v.x, acc[q * 4]);
+                acc[q * 4 + 1] = __builtin_fmaf(wr, v.y, acc[q * 4 + 1]);
+                acc[q * 4 + 2] = __builtin_fmaf(wr, v.z, acc[q * 4 + 2]);
+                acc[q * 4 + 3] = __builtin_fmaf(wr, v.w, acc[q * 4 + 3]);
+            }
+        }
+#pragma unroll
+        for (int o = 0; o < S; ++o) red_[(k * CPG + c) * S + o] = acc[o];
+        __syncthreads();
+        ff_fold<CPG, S, KS, NT>(red_, part_, resv, nullptr, c0);
+    }
+    __syncthreads();
+    ff_finish<D, H, W, CPG, NT>(p, vals, p.rx ? resv : nullptr, n, c0, dred, mr);
+}
+
+// ---- ROW: thread = (output row (d,h), input-channel slice k); rows * KS = 1024 threads (four waves per SIMD cover the load latency) ----------------------------------------------
+template <int D, int H, int W, int CPG, int KS>
+__global__ void __launch_bounds__(D * H * KS) ff_block_row_kernel(FfParams p) {
+    constexpr int S = D * H * W, R = D * H, NT = R * KS;
+    static_assert(NT <= 1024 && R % 64 == 0 && W % 4 == 0, "row mapping: a wave holds rows of ONE slice");
+    const int tid = threadIdx.x, r = tid % R, d = r / H, h = r % H;
+    const int k = __builtin_amdgcn_readfirstlane(tid / R);   // wave-uniform: the slice's weights are scalar loads
+    const int groups = p.Co / CPG, n = blockIdx.x / groups, g = blockIdx.x % groups, c0 = g * CPG;
+    __shared__ float red_[KS * CPG * S];
+    __shared__ float vals[CPG * S], resv[CPG * S], part_[NT > CPG * S ? NT : CPG * S];
+    __shared__ double dred[2 * NT / 64];
+    __shared__ float mr[2];
+
+    float acc[CPG][W];
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+        for (int ow = 0; ow < W; ++ow) acc[c][ow] = 0.0f;
+    const int per = p.Ci / KS;
+    for (int ci = k * per; ci < (k + 1) * per; ++ci) {
+        const float *xc = p.x + ((size_t)n * p.Ci + ci) * S;
+        float row[9][W];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int id = d + kd - 1, ih = h + kh - 1;
+                const bool ok = id >= 0 && id < D && ih >= 0 && ih < H;
+                const float4 *src = reinterpret_cast<const float4 *>(xc + ((size_t)(ok ? id : 0) * H + (ok ? ih : 0)) * W);
+#pragma unroll
+                for (int q = 0; q < W / 4; ++q) {
+                    const float4 v = ok ? src[q] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    row[kd * 3 + kh][q * 4] = v.x; row[kd * 3 + kh][q * 4 + 1] = v.y;
+                    row[kd * 3 + kh][q * 4 + 2] = v.z; row[kd * 3 + kh][q * 4 + 3] = v.w;
+                }
+            }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c) {
+            const float *wp = p.w + ((size_t)(c0 + c) * p.Ci + ci) * 27;   // wave-uniform address
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float wt = wp[t9 * 3 + kw];
+#pragma unroll
+                    for (int ow = 0; ow < W; ++ow) {
+                        const int iw = ow + kw - 1;
+                        if (iw >= 0 && iw < W) acc[c][ow] = __builtin_fmaf(wt, row[t9][iw], acc[c][ow]);
+                    }
+                }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CPG; ++c)
+#pragma unroll
+        for (int ow = 0; ow < W; ++ow) red_[(k * CPG + c) * S + r * W + ow] = acc[c][ow];
+    __syncthreads();
+    ff_fold<CPG, S, KS, NT>(red_, part_, vals, p.b, c0);
+    if (p.rx) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < CPG; ++c)
+#pragma unroll
+            for (int ow = 0; ow < W; ++ow) acc[c][ow] = 0.0f;
+        const int perr = p.Cr / KS;
+        for (int cr = k * perr; cr < (k + 1) * perr; ++cr) {
+            const float4 *src = reinterpret_cast<const float4 *>(p.rx + ((size_t)n * p.Cr + cr) * S + (size_t)r * W);
+            float xr[W];
+#pragma unroll
+            for (int q = 0; q < W / 4; ++q) {
+                const float4 v = src[q];
+                xr[q * 4] = v.x; xr[q * 4 + 1] = v.y; xr[q * 4 + 2] = v.z; xr[q * 4 + 3] = v.w;
+            }
+#pragma unroll
+            for (int c = 0; c < CPG; ++c) {
+                const float wr = p.rw[(size_t)(c0 + c) * p.Cr + cr];
+#pragma unroll
+                for (int ow = 0; ow < W; ++ow) acc[c][ow] = __builtin_fmaf(wr, xr[ow], acc[c][ow]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPG; ++c)
+#pragma unroll
+            for (int ow = 0; ow < W; ++ow) red_[(k * CPG + c) * S + r * W + ow] = acc[c][ow];
+        __syncthreads();
+        ff_fold<CPG, S, KS, NT>(red_, part_, resv, nullptr, c0);
+    }
+    __syncthreads();
+    ff_finish<D, H, W, CPG, NT>(p, vals, p.rx ? resv : nullptr, n, c0, dred, mr);
+}
+
+// level of FlowField a (Co, D, H, W) belongs to: 1..3, 0 = none.  (Level 4, 64->32 @16x8x8, stays on the split-K gather conv + one-launch
+// GroupNorm: measured as a row-mapped kernel it took 29-35 us per half — every one of the 32 group workgroups of a frame re-reads the
+// frame's whole 256 KB input through L2 and the fp32 FMA work alone is 11 us of a CU — vs 107 us for its five launches, but its 1024-thread
+// workgroups on every CU delayed the other generator's chain and the other batch: B=8 3.91 vs 3.86 ms per step with / without it.)
+static int ff_level(int Co, int D, int H, int W) {
+    if (Co == 256 && D == 4 && H == 1 && W == 1) return 1;
+    if (Co == 128 && D == 8 && H == 2 && W == 2) return 2;
+    if (Co == 64 && D == 16 && H == 4 && W == 4) return 3;
+    return 0;
+}
+static int ff_slices(int level) { return level == 3 ? 16 : 128; }
+
+}  // namespace mphip
+
+using namespace mphip;
+
+extern "C" int mphip_flowfield_conv_gn_supported(int Ci, int Co, int D, int H, int W, int Cr, int groups) {
+    const int lv = ff_level(Co, D, H, W);
+    if (!lv || groups != 32 || Ci <= 0 || Ci % ff_slices(lv) || Cr < 0 || (Cr && Cr % ff_slices(lv))) return 0;
+    return lv;
+}
+
+extern "C" int mphip_flowfield_conv_gn(const float *x, const float *w, const float *b, const float *gamma, const float *beta, const float *w2,
+                                       const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci,
+                                       int Co, int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu,
+                                       void *stream) {
+    MPHIP_REQUIRE(x && w && gamma && beta && y, "flowfield_conv_gn: null pointer");
+    MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "flowfield_conv_gn: w2/b2 must both be set or both NULL");
+    MPHIP_REQUIRE((res_x == nullptr) == (res_w == nullptr) && (res_x != nullptr) == (Cr > 0), "flowfield_conv_gn: residual input, weight and Cr go together");
+    MPHIP_REQUIRE(N > 0 && uD >= 1 && uH >= 1 && uW >= 1, "flowfield_conv_gn: bad dims");
+    const int lv = mphip_flowfield_conv_gn_supported(Ci, Co, D, H, W, Cr, groups);
+    MPHIP_REQUIRE(lv, "flowfield_conv_gn: shape %d->%d @%dx%dx%d (Cr=%d, %d groups) is not a FlowField level (query mphip_flowfield_conv_gn_supported)",
+                  Ci, Co, D, H, W, Cr, groups);
+    FfParams p{x, w, b, gamma, beta, w2, b2, res_x, res_w, res_b, y, Ci, Co, Cr, uD, uH, uW, relu, eps};
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)(N * groups));
+    switch (lv) {
+        case 1: hipLaunchKernelGGL((ff_block_plane_kernel<4, 1, 1, 8, 1024>), grid, dim3(1024), 0, s, p); break;
+        case 2: hipLaunchKernelGGL((ff_block_plane_kernel<8, 2, 2, 4, 512>), grid, dim3(512), 0, s, p); break;
+        default: hipLaunchKernelGGL((ff_block_row_kernel<16, 4, 4, 2, 16>), grid, dim3(1024), 0, s, p); break;
+    }
+    return check_launch("flowfield_conv_gn");
+}

@@ -415,6 +415,32 @@ void resblock_ada(GenLane (&ln)[L], int blk, T5 (&x)[L], int ud, int uh, int uw)
     T5 a[L], out[L];
     ResBlockAda *b[L];
     for (int l = 0; l < L; ++l) b[l] = &ln[l].g->ff.rb[blk];
+    static const bool ff_fused = !(getenv("MPHIP_FF_FUSED") && getenv("MPHIP_FF_FUSED")[0] == '0');   // dev: same-box A/B (ops._FF_FUSED)
+    if (ff_fused && !b[0]->identity &&
+        mphip_flowfield_conv_gn_supported(b[0]->conv1.ci, b[0]->conv1.co, x[0].d, x[0].h, x[0].w, 0, 32) &&
+        mphip_flowfield_conv_gn_supported(b[0]->conv2.ci, b[0]->conv2.co, x[0].d, x[0].h, x[0].w, b[0]->res.ci, 32)) {
+        // FlowField's levels: each half of the block is ONE launch (csrc/flowfield.hip; model.ResBlock3D_Adaptive._forward does the same)
+        for (int l = 0; l < L; ++l) {
+            Ctx &c = *ln[l].c;
+            a[l] = new_t5(c, x[l].n, b[l]->conv1.co, x[l].d, x[l].h, x[l].w, false);
+            RUN(c, mphip_flowfield_conv_gn(x[l].data.p, b[l]->conv1.w, b[l]->conv1.b, b[l]->n1.gw, b[l]->n1.gb, b[l]->n1.w2, b[l]->n1.b2, nullptr,
+                                           nullptr, nullptr, a[l].data.p, x[l].n, b[l]->conv1.ci, b[l]->conv1.co, x[l].d, x[l].h, x[l].w, 0, 1, 1, 1,
+                                           32, GN_EPS, 1, c.s));
+        }
+        for (int l = 0; l < L; ++l) {
+            Ctx &c = *ln[l].c;
+            out[l] = new_t5(c, x[l].n, b[l]->conv2.co, x[l].d * ud, x[l].h * uh, x[l].w * uw, false);
+            RUN(c, mphip_flowfield_conv_gn(a[l].data.p, b[l]->conv2.w, b[l]->conv2.b, b[l]->n2.gw, b[l]->n2.gb, b[l]->n2.w2, b[l]->n2.b2,
+                                           x[l].data.p, b[l]->res.w, b[l]->res.b, out[l].data.p, x[l].n, b[l]->conv2.ci, b[l]->conv2.co, x[l].d,
+                                           x[l].h, x[l].w, b[l]->res.ci, ud, uh, uw, 32, GN_EPS, 1, c.s));
+        }
+        for (int l = 0; l < L; ++l) {
+            give(*ln[l].c, a[l]);
+            give(*ln[l].c, x[l]);
+            x[l] = out[l];
+        }
+        return;
+    }
     for (int l = 0; l < L; ++l) y[l] = conv3d_split(*ln[l].c, x[l], b[l]->conv1, 32, &b[l]->n1, &b[l]->conv2);
     const bool tiny = groupnorm_fused_ok(y[0], 32);   // (shape decisions are the same on every lane: same batch, same layer)
     if (tiny) {

@@ -138,6 +138,12 @@ class ResBlock3D_Adaptive(nn.Module):
             y = ag.adaptive_groupnorm(y, self.norm2, residual=res, relu=True)
             return y if tuple(_up) == (1, 1, 1) else ag.UpsampleNearestFn.apply(y, tuple(_up))
         n1, n2 = self.norm1, self.norm2
+        res_conv = None if isinstance(self.residual_conv, nn.Identity) else self.residual_conv
+        if res_conv is not None and ops.flowfield_conv_gn_ok(tuple(x.shape), self.conv1) and \
+                ops.flowfield_conv_gn_ok(tuple(x.shape[:1]) + (self.conv2.weight.shape[1],) + tuple(x.shape[2:]), self.conv2, res_conv):
+            # FlowField's four levels: each half of the block is ONE launch (csrc/flowfield.hip)
+            a = ops.flowfield_conv_gn(x, self.conv1, n1, relu=True)
+            return ops.flowfield_conv_gn(a, self.conv2, n2, res_x=x, res_conv=res_conv, relu=True, up=_up)
         # split-K slabs are summed by the GN kernels below; a direct launch carries the norm's statistics along
         y = ops.conv3d_split(x, _packs.get(self.conv1), gn_groups=n1.num_groups, gn_eps=n1.group_norm.eps)
         tiny = ops.groupnorm_fused_ok(y, n1.num_groups)  # FlowField: statistics + apply in one launch

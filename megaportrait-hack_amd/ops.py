@@ -650,6 +650,42 @@ def groupnorm_small(x, gamma, beta, groups: int, eps: float = 1e-5, w2=None, b2=
     return y
 
 
+_FF_FUSED = _os.environ.get("MPHIP_FF_FUSED", "1") != "0"  # dev switch for same-box A/B runs (the plan reads the same variable)
+
+
+def flowfield_conv_gn_ok(x_shape, conv, res_conv=None, groups: int = 32) -> bool:
+    """True when `relu(AGN(conv(x)) [+ res_conv(xr)])` is one of FlowField's block halves (mphip_flowfield_conv_gn)."""
+    if not _FF_FUSED or len(x_shape) != 5:
+        return False
+    n, ci, d, h, w = x_shape
+    cr = res_conv.weight.shape[1] if res_conv is not None else 0
+    return bool(_lib.load().mphip_flowfield_conv_gn_supported(ci, conv.weight.shape[0], d, h, w, cr, groups))
+
+
+def flowfield_conv_gn(x, conv, norm, res_x=None, res_conv=None, relu=True, up=(1, 1, 1)) -> torch.Tensor:
+    """One launch: upsample_nearest(relu(AGN(conv3x3x3(x)) [+ conv1x1x1(res_x)])) for FlowField's four levels (model.py:369-408 at
+    439-471), from the modules' own weight tensors.  `norm`: AdaptiveGroupNorm (group_norm.{weight,bias}, weight, bias)."""
+    x = _req(x, "x")
+    n, ci, d, h, w = x.shape
+    co = conv.weight.shape[0]
+    wt, bs = _req(conv.weight.detach(), "conv.weight"), (_req(conv.bias.detach(), "conv.bias") if conv.bias is not None else None)
+    g, b = _req(norm.group_norm.weight.detach(), "gamma"), _req(norm.group_norm.bias.detach(), "beta")
+    w2, b2 = _req(norm.weight.detach(), "w2").reshape(-1), _req(norm.bias.detach(), "b2").reshape(-1)
+    rx = rw = rb = None
+    cr = 0
+    if res_conv is not None:
+        rx = _req(res_x, "res_x")
+        rw = _req(res_conv.weight.detach(), "res_conv.weight")
+        rb = _req(res_conv.bias.detach(), "res_conv.bias") if res_conv.bias is not None else None
+        cr = rw.shape[1]
+    up = tuple(int(u) for u in up)
+    y = torch.empty((n, co, d * up[0], h * up[1], w * up[2]), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().mphip_flowfield_conv_gn(_ptr(x), _ptr(wt), _ptr(bs), _ptr(g), _ptr(b), _ptr(w2), _ptr(b2), _ptr(rx), _ptr(rw),
+                                                   _ptr(rb), _ptr(y), n, ci, co, d, h, w, cr, up[0], up[1], up[2], norm.num_groups,
+                                                   norm.group_norm.eps, int(relu), _stream()), "mphip_flowfield_conv_gn")
+    return y
+
+
 # ------------------------------------------------------------------ K7
 def avgpool2(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")

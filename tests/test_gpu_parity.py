@@ -339,6 +339,51 @@ def test_conv_with_groupnorm_statistics(ops, dev, shape):
         assert maxabs(st2[:, 0], want2[:, 0].cpu()) < 1e-6 and (st2[:, 1] / want2[:, 1] - 1).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("level", [(512, 256, 4, 1, 1, (2, 2, 2)), (256, 128, 8, 2, 2, (2, 2, 2)), (128, 64, 16, 4, 4, (1, 2, 2))],
+                         ids=["512-256@4x1x1", "256-128@8x2x2", "128-64@16x4x4"])
+def test_flowfield_block_in_two_launches(ops, M, dev, level):
+    """FlowField's first three ResBlock3D_Adaptive levels (model.py:369-408 at 439-471) through mphip_flowfield_conv_gn — one workgroup per
+    (frame, GroupNorm group) runs conv + statistics + both affines (+ residual 1x1x1 conv) + ReLU + nearest upsample — vs the same block
+    evaluated with ATen on the CPU in float64, next to the five-launch path's error; and the module takes that path by itself."""
+    ci, co, d, h, w, up = level
+    torch.manual_seed(77)
+    blk = M.ResBlock3D_Adaptive(ci, co)
+    with torch.no_grad():   # non-trivial affines
+        for nrm in (blk.norm1, blk.norm2):
+            nrm.group_norm.weight.uniform_(0.5, 1.5); nrm.group_norm.bias.uniform_(-0.5, 0.5)
+            nrm.weight.uniform_(0.5, 1.5); nrm.bias.uniform_(-0.5, 0.5)
+    x = R.seeded_tensor((3, ci, d, h, w), 861, scale=1.7)
+
+    def ref(dt):
+        c = lambda t: t.detach().to(dt)
+        agn = lambda y, nrm: F.group_norm(y, 32, c(nrm.group_norm.weight), c(nrm.group_norm.bias), 1e-5) * c(nrm.weight) + c(nrm.bias)
+        y = F.relu(agn(F.conv3d(x.to(dt), c(blk.conv1.weight), c(blk.conv1.bias), padding=1), blk.norm1))
+        y = agn(F.conv3d(y, c(blk.conv2.weight), c(blk.conv2.bias), padding=1), blk.norm2)
+        y = F.relu(y + F.conv3d(x.to(dt), c(blk.residual_conv.weight), c(blk.residual_conv.bias)))
+        return F.interpolate(y, scale_factor=up, mode="nearest")
+
+    truth, cpu32 = ref(torch.float64), ref(torch.float32).double()
+    blk = blk.to(dev).eval()
+    assert ops.flowfield_conv_gn_ok(tuple(x.shape), blk.conv1) and ops.flowfield_conv_gn_ok((3, co, d, h, w), blk.conv2, blk.residual_conv)
+    with torch.no_grad():
+        a = ops.flowfield_conv_gn(x.to(dev), blk.conv1, blk.norm1, relu=True)
+        got = ops.flowfield_conv_gn(a, blk.conv2, blk.norm2, res_x=x.to(dev), res_conv=blk.residual_conv, relu=True, up=up).cpu().double()
+        assert torch.equal(blk(x.to(dev), _up=up).cpu().double(), got)   # the module's own inference path
+        old = ops._FF_FUSED
+        ops._FF_FUSED = False
+        try:
+            five = blk(x.to(dev), _up=up).cpu().double()
+        finally:
+            ops._FF_FUSED = old
+    scale = truth.abs().max().item()
+    e_new, e_old, e_cpu = (got - truth).abs().max().item(), (five - truth).abs().max().item(), (cpu32 - truth).abs().max().item()
+    print(f"{ci}->{co}: two launches {e_new:.2e}, five launches {e_old:.2e}, ATen fp32 {e_cpu:.2e} (|y|max {scale:.2f})")
+    assert got.shape == truth.shape and e_new < max(3.0 * e_cpu, 1e-5 * scale)
+    with pytest.raises(RuntimeError):   # not a FlowField level: refused, never computed some other way
+        wrong = M.ResBlock3D_Adaptive(64, 32).to(dev)
+        ops.flowfield_conv_gn(torch.zeros(1, 64, 16, 8, 8, device=dev), wrong.conv1, wrong.norm1)
+
+
 def test_cross_reenactment_equals_pairwise(M, dev, hot):
     """BASELINE config 5 (1 source x N drivers, dp.cross_reenact): the source-side half is computed once,
     results must equal running the hot slice on every (source, driver) pair."""
