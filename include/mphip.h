@@ -165,6 +165,11 @@ int mphip_flowfield_conv_gn_supported(int Ci, int Co, int D, int H, int W, int C
 int mphip_flowfield_conv_gn(const float *x, const float *w, const float *b, const float *gamma, const float *beta, const float *w2,
                             const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci, int Co,
                             int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu, void *stream);
+/* FlowField's output head (model.py:458-465): em = tanh(relu(GroupNorm(1, 3)(Conv3d(32, 3, 3)(x)))), x [N,32,16,16,16] -> em [N,3,16,16,16]:
+ * a direct 3-channel conv (one workgroup per depth slice, partial sums in double) + one normalising pass; w [3,32,3,3,3] as stored. */
+size_t mphip_flowfield_out_workspace_bytes(int N);
+int mphip_flowfield_out(const float *x, const float *w, const float *b, const float *gamma, const float *beta, float *em, int N, float eps,
+                        void *workspace, size_t workspace_bytes, void *stream);
 /* measurement: the next conv launch on this thread carries these two HIP events (hipEvent_t).  The f16x3 3x3x3 kernels are launched
  * with them attached (hipExtLaunchKernelGGL: they take the kernel's own begin / end — time spent waiting for CUs that another stream's
  * kernel holds is not counted); every other conv kernel has them recorded on the launch stream right before / after it. */

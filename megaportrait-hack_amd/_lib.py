@@ -81,6 +81,8 @@ SIGNATURES = {
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_field_coords": (_i, [_p] * 7 + [_i] * 6 + [_p]),
     "mphip_flowfield_conv_gn_supported": (_i, [_i] * 7),
+    "mphip_flowfield_out_workspace_bytes": (_sz, [_i]),
+    "mphip_flowfield_out": (_i, [_p] * 6 + [_i, ctypes.c_float, _p, _sz, _p]),
     "mphip_flowfield_conv_gn": (_i, [_p] * 11 + [_i] * 11 + [ctypes.c_float, _i, _p]),
     "mphip_warp_volume_coords": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_warp_sample_box": (_i, [_p, _p, _i, _i, _i, _i, _p]),

@@ -276,6 +276,80 @@ __global__ void __launch_bounds__(D * H * KS) ff_block_row_kernel(FfParams p) {
     ff_finish<D, H, W, CPG, NT>(p, vals, p.rx ? resv : nullptr, n, c0, dred, mr);
 }
 
+// ---- the output head of FlowField (model.py:458-465): Conv3d(32, 3, 3) @16x16x16 -> GroupNorm(1, 3) -> ReLU -> tanh ----------------------
+// The 3-channel conv is 90 % padding on a 32-row MFMA tile (29-50 us as a split-K gather conv) and its GroupNorm has ONE group per frame
+// (a one-workgroup-per-group kernel uses 8 CUs: 27-51 us).  Here: (1) a direct conv, thread = voxel, the three channels in registers,
+// weights wave-uniform, one workgroup per depth slice -> y and per-slice (sum, sum of squares) in double; (2) every workgroup folds its
+// frame's 16 slice partials in slice order (deterministic) and applies the norm, ReLU and tanh to its slice.
+constexpr int FO_C = 32, FO_G = 16, FO_S = FO_G * FO_G * FO_G;
+
+__global__ void __launch_bounds__(256) ff_out_conv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
+                                                          float *__restrict__ y, double *__restrict__ part) {
+    const int n = blockIdx.x / FO_G, d = blockIdx.x % FO_G, tid = threadIdx.x, h = tid / FO_G, ww = tid % FO_G;
+    float acc[3] = {0.0f, 0.0f, 0.0f};
+    const float *xn = x + (size_t)n * FO_C * FO_S;
+    for (int ci = 0; ci < FO_C; ++ci) {
+        const float *xc = xn + (size_t)ci * FO_S;
+        float v[27];
+#pragma unroll
+        for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int id = d + kd - 1, ih = h + kh - 1, iw = ww + kw - 1;
+                    const bool ok = id >= 0 && id < FO_G && ih >= 0 && ih < FO_G && iw >= 0 && iw < FO_G;
+                    v[kd * 9 + kh * 3 + kw] = ok ? xc[(id * FO_G + ih) * FO_G + iw] : 0.0f;
+                }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float *wp = w + ((size_t)c * FO_C + ci) * 27;   // wave-uniform
+#pragma unroll
+            for (int t = 0; t < 27; ++t) acc[c] = __builtin_fmaf(wp[t], v[t], acc[c]);
+        }
+    }
+    float s = 0.0f, ss = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float val = acc[c] + (b ? b[c] : 0.0f);
+        y[((size_t)n * 3 + c) * FO_S + d * FO_G * FO_G + tid] = val;
+        s += val;
+        ss += val * val;
+    }
+    const double ds = ff_wave_sum((double)s), dss = ff_wave_sum((double)ss);
+    __shared__ double red[8];
+    if ((tid & 63) == 0) {
+        red[(tid >> 6) * 2] = ds;
+        red[(tid >> 6) * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        part[(size_t)blockIdx.x * 2] = (red[0] + red[2]) + (red[4] + red[6]);
+        part[(size_t)blockIdx.x * 2 + 1] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
+}
+
+__global__ void __launch_bounds__(256) ff_out_norm_kernel(const float *__restrict__ y, const double *__restrict__ part, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, float eps, float *__restrict__ em) {
+    const int n = blockIdx.x / FO_G, d = blockIdx.x % FO_G, tid = threadIdx.x;
+    double a = 0.0, q = 0.0;
+    for (int t = 0; t < FO_G; ++t) {   // (every thread folds the same 16 pairs in the same order: uniform, no barrier)
+        a += part[((size_t)n * FO_G + t) * 2];
+        q += part[((size_t)n * FO_G + t) * 2 + 1];
+    }
+    const double cnt = 3.0 * FO_S, mean_d = a / cnt;
+    double var = q / cnt - mean_d * mean_d;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var + (double)eps));
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const size_t i = ((size_t)n * 3 + c) * FO_S + d * FO_G * FO_G + tid;
+        float v = (y[i] - mean) * rstd * gamma[c] + beta[c];
+        v = fmaxf(v, 0.0f);
+        em[i] = tanhf(v);
+    }
+}
+
 // level of FlowField a (Co, D, H, W) belongs to: 1..3, 0 = none.  (Level 4, 64->32 @16x8x8, stays on the split-K gather conv + one-launch
 // GroupNorm: measured as a row-mapped kernel it took 29-35 us per half — every one of the 32 group workgroups of a frame re-reads the
 // frame's whole 256 KB input through L2 and the fp32 FMA work alone is 11 us of a CU — vs 107 us for its five launches, but its 1024-thread
@@ -318,4 +392,23 @@ extern "C" int mphip_flowfield_conv_gn(const float *x, const float *w, const flo
         default: hipLaunchKernelGGL((ff_block_row_kernel<16, 4, 4, 2, 16>), grid, dim3(1024), 0, s, p); break;
     }
     return check_launch("flowfield_conv_gn");
+}
+
+extern "C" size_t mphip_flowfield_out_workspace_bytes(int N) { return N > 0 ? (size_t)N * FO_G * 2 * sizeof(double) + (size_t)N * 3 * FO_S * sizeof(float) : 0; }
+
+extern "C" int mphip_flowfield_out(const float *x, const float *w, const float *b, const float *gamma, const float *beta, float *em, int N,
+                                   float eps, void *workspace, size_t workspace_bytes, void *stream) {
+    MPHIP_REQUIRE(x && w && gamma && beta && em, "flowfield_out: null pointer");
+    MPHIP_REQUIRE(N > 0, "flowfield_out: bad batch");
+    const size_t need = mphip_flowfield_out_workspace_bytes(N);
+    if (!workspace || workspace_bytes < need) {
+        set_error("flowfield_out: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    double *part = (double *)workspace;
+    float *y = (float *)((char *)workspace + (size_t)N * FO_G * 2 * sizeof(double));
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(ff_out_conv_kernel, dim3(N * FO_G), dim3(256), 0, s, x, w, b, y, part);
+    hipLaunchKernelGGL(ff_out_norm_kernel, dim3(N * FO_G), dim3(256), 0, s, (const float *)y, (const double *)part, gamma, beta, eps, em);
+    return check_launch("flowfield_out");
 }

@@ -496,6 +496,21 @@ void generator_coords(GenLane (&ln)[L], int B, Buf (&coords)[L]) {
         RUN(c, mphip_add_matmul(ln[l].z, ln[l].e, ff.w_head, ff.b1x1, x[l].data.p, B, 512, 2048, 0, c.s));
     }
     for (int i = 0; i < 4; ++i) resblock_ada<L>(ln, i, x, UPS[i][0], UPS[i][1], UPS[i][2]);
+    static const bool ff_fused = !(getenv("MPHIP_FF_FUSED") && getenv("MPHIP_FF_FUSED")[0] == '0');
+    const ConvW &co0 = ln[0].g->ff.conv_out;
+    const bool out_fused = ff_fused && co0.ci == 32 && co0.co == 3 && co0.k == 3 && x[0].d == 16 && x[0].h == 16 && x[0].w == 16;
+    if (out_fused) {   // the output head as a direct 3-channel conv + one normalising pass (csrc/flowfield.hip; ops.flowfield_out)
+        for (int l = 0; l < L; ++l) {
+            Ctx &c = *ln[l].c;
+            FlowFieldW &ff = ln[l].g->ff;
+            em[l] = new_t5(c, B, 3, 16, 16, 16, false);
+            const size_t wsb = mphip_flowfield_out_workspace_bytes(B);
+            Buf ws = take(c, wsb);
+            RUN(c, mphip_flowfield_out(x[l].data.p, ff.conv_out.w, ff.conv_out.b, ff.gn.gw, ff.gn.gb, em[l].data.p, B, GN_EPS, ws.p, wsb, c.s));
+            give(c, ws);
+            give(c, x[l]);
+        }
+    } else {
     for (int l = 0; l < L; ++l) { y[l] = conv3d_split(*ln[l].c, x[l], ln[l].g->ff.conv_out, 0); give(*ln[l].c, x[l]); }
     if (groupnorm_fused_ok(y[0], 1)) {
         for (int l = 0; l < L; ++l) em[l] = groupnorm_small(*ln[l].c, y[l], ln[l].g->ff.gn, 1, nullptr, true, true, 1, 1, 1);
@@ -504,6 +519,7 @@ void generator_coords(GenLane (&ln)[L], int B, Buf (&coords)[L]) {
         for (int l = 0; l < L; ++l) em[l] = groupnorm_apply(*ln[l].c, y[l], ln[l].g->ff.gn, 1, nullptr, true, true, false, 1, 1, 1);
     }
     for (int l = 0; l < L; ++l) give(*ln[l].c, y[l]);
+    }
     for (int l = 0; l < L; ++l) {
         Ctx &c = *ln[l].c;
         theta[l] = take(c, (size_t)B * 12 * sizeof(float));

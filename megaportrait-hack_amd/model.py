@@ -240,6 +240,8 @@ class FlowField(nn.Module):
             x = ag.groupnorm(x, self.gn, relu=True, tanh=True)
             assert x.shape[1] == 3, f"Expected 3 channels after conv3x3x3, got {x.shape[1]}"
             return x
+        if ops.flowfield_out_ok(tuple(x.shape), self.conv3x3x3) and self.gn.num_groups == 1:
+            return ops.flowfield_out(x, self.conv3x3x3, self.gn)   # direct 3-channel conv + one normalising pass (csrc/flowfield.hip)
         x = ops.conv3d_split(x, _packs.get(self.conv3x3x3))
         if ops.groupnorm_fused_ok(x, 1):
             x = ops.groupnorm_small(x, self.gn.weight, self.gn.bias, 1, self.gn.eps, relu=True, tanh=True)

@@ -686,6 +686,25 @@ def flowfield_conv_gn(x, conv, norm, res_x=None, res_conv=None, relu=True, up=(1
     return y
 
 
+def flowfield_out_ok(x_shape, conv) -> bool:
+    return _FF_FUSED and tuple(x_shape[1:]) == (32, 16, 16, 16) and tuple(conv.weight.shape) == (3, 32, 3, 3, 3)
+
+
+def flowfield_out(x, conv, gn) -> torch.Tensor:
+    """tanh(relu(GroupNorm(1, 3)(conv3x3x3(x)))) for FlowField's output head (model.py:458-465): two launches."""
+    x = _req(x, "x")
+    n = x.shape[0]
+    lib = _lib.load()
+    wt, bs = _req(conv.weight.detach(), "conv.weight"), (_req(conv.bias.detach(), "conv.bias") if conv.bias is not None else None)
+    g, b = _req(gn.weight.detach(), "gamma"), _req(gn.bias.detach(), "beta")
+    ws_bytes = lib.mphip_flowfield_out_workspace_bytes(n)
+    ws = torch.empty((ws_bytes + 7) // 8, dtype=torch.float64, device=x.device)
+    em = torch.empty((n, 3, 16, 16, 16), dtype=torch.float32, device=x.device)
+    _lib.check(lib.mphip_flowfield_out(_ptr(x), _ptr(wt), _ptr(bs), _ptr(g), _ptr(b), _ptr(em), n, gn.eps, _ptr(ws), ws_bytes, _stream()),
+               "mphip_flowfield_out")
+    return em
+
+
 # ------------------------------------------------------------------ K7
 def avgpool2(x: torch.Tensor) -> torch.Tensor:
     x = _req(x, "x")

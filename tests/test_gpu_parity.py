@@ -384,6 +384,29 @@ def test_flowfield_block_in_two_launches(ops, M, dev, level):
         ops.flowfield_conv_gn(torch.zeros(1, 64, 16, 8, 8, device=dev), wrong.conv1, wrong.norm1)
 
 
+def test_flowfield_output_head(ops, M, dev):
+    """FlowField's output head (model.py:458-465: Conv3d(32, 3, 3) -> GroupNorm(1, 3) -> ReLU -> tanh) through mphip_flowfield_out (a direct
+    3-channel conv + one normalising pass) vs ATen on the CPU in float64, next to the split-K conv + one-launch GroupNorm it replaces."""
+    torch.manual_seed(78)
+    ff = M.FlowField()
+    with torch.no_grad():
+        ff.gn.weight.uniform_(0.5, 1.5); ff.gn.bias.uniform_(-0.5, 0.5)
+    x = R.seeded_tensor((3, 32, 16, 16, 16), 871, scale=1.7)
+    ref = lambda dt: torch.tanh(F.relu(F.group_norm(F.conv3d(x.to(dt), ff.conv3x3x3.weight.detach().to(dt), ff.conv3x3x3.bias.detach().to(dt),
+                                                             padding=1), 1, ff.gn.weight.detach().to(dt), ff.gn.bias.detach().to(dt), 1e-5)))
+    truth, cpu32 = ref(torch.float64), ref(torch.float32).double()
+    ff = ff.to(dev).eval()
+    assert ops.flowfield_out_ok(tuple(x.shape), ff.conv3x3x3)
+    with torch.no_grad():
+        got = ops.flowfield_out(x.to(dev), ff.conv3x3x3, ff.gn).cpu().double()
+        y = ops.conv3d_split(x.to(dev), M._packs.get(ff.conv3x3x3))
+        old = ops.groupnorm_small(y, ff.gn.weight, ff.gn.bias, 1, ff.gn.eps, relu=True, tanh=True).cpu().double()
+    e_new, e_old, e_cpu = (got - truth).abs().max().item(), (old - truth).abs().max().item(), (cpu32 - truth).abs().max().item()
+    print(f"output head: two launches {e_new:.2e}, split-K conv + GroupNorm {e_old:.2e}, ATen fp32 {e_cpu:.2e}")
+    assert got.shape == truth.shape and e_new < max(3.0 * e_cpu, 1e-6)
+    assert (got >= 0).all() and (got < 1).all()   # [0, 1): what makes the reference's warps sample the low corner (SURVEY.md quirk 1)
+
+
 def test_cross_reenactment_equals_pairwise(M, dev, hot):
     """BASELINE config 5 (1 source x N drivers, dp.cross_reenact): the source-side half is computed once,
     results must equal running the hot slice on every (source, driver) pair."""
