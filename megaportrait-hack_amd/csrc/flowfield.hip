@@ -279,33 +279,78 @@ __global__ void __launch_bounds__(D * H * KS) ff_block_row_kernel(FfParams p) {
 // ---- the output head of FlowField (model.py:458-465): Conv3d(32, 3, 3) @16x16x16 -> GroupNorm(1, 3) -> ReLU -> tanh ----------------------
 // The 3-channel conv is 90 % padding on a 32-row MFMA tile (29-50 us as a split-K gather conv) and its GroupNorm has ONE group per frame
 // (a one-workgroup-per-group kernel uses 8 CUs: 27-51 us).  Here: (1) a direct conv, thread = voxel, the three channels in registers,
-// weights wave-uniform, one workgroup per depth slice -> y and per-slice (sum, sum of squares) in double; (2) every workgroup folds its
+// weights wave-uniform, one workgroup per depth slice with the slice's input staged in LDS -> y and per-slice (sum, sum of squares) in double; (2) every workgroup folds its
 // frame's 16 slice partials in slice order (deterministic) and applies the norm, ReLU and tanh to its slice.
 constexpr int FO_C = 32, FO_G = 16, FO_S = FO_G * FO_G * FO_G;
 
 __global__ void __launch_bounds__(256) ff_out_conv_kernel(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ b,
                                                           float *__restrict__ y, double *__restrict__ part) {
+    // the slice's three input planes of all 32 channels, zero-padded by one voxel in h and w (and whole planes of zeros outside the
+    // volume in d): 32 x 3 x 18 x 18 floats = 124 KB of LDS, staged once; the 27 x 32 taps of a voxel are then plain LDS reads
+    constexpr int P = FO_G + 2, PLANE = P * P, XS = FO_C * 3 * PLANE;
+    __shared__ float xs[XS];
+    __shared__ __attribute__((aligned(16))) float wsd[FO_C * 3 * 28];   // weights [ci][c][27 (+1 pad)]: 16-byte LDS reads, no scalar-load round
+                                                                       // trip per input channel (one wave per SIMD: nothing would hide it)
     const int n = blockIdx.x / FO_G, d = blockIdx.x % FO_G, tid = threadIdx.x, h = tid / FO_G, ww = tid % FO_G;
-    float acc[3] = {0.0f, 0.0f, 0.0f};
     const float *xn = x + (size_t)n * FO_C * FO_S;
+    // every global load of the workgroup is issued before the first use: 24 16-byte loads of the slab + 3 of the weights per thread
+    // (a loop of dependent load -> LDS-write trips cost one memory round trip each: 57-70 us for this kernel)
+    float4 xv[24];
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+        const int f = q * 256 + tid;                     // float4 index in [ci][kd][h][w/4]
+        const int w4 = f % 4, hh = (f / 4) % FO_G, kd = (f / 64) % 3, ci = f / 192, id = d + kd - 1;
+        xv[q] = (id >= 0 && id < FO_G) ? *reinterpret_cast<const float4 *>(xn + (size_t)ci * FO_S + (id * FO_G + hh) * FO_G + w4 * 4)
+                                        : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    float wl[11];
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+        const int i = q * 256 + tid;                     // [ci][c][28]
+        const int t = i % 28, c = (i / 28) % 3, ci = i / 84;
+        wl[q] = (i < FO_C * 3 * 28 && t < 27) ? w[((size_t)c * FO_C + ci) * 27 + t] : 0.0f;
+    }
+    for (int i = tid; i < FO_C * 3 * P; i += 256) {      // the padding: columns 0 and 17 of every row, rows 0 and 17 of every plane
+        const int r = i % P, pl = i / P;
+        xs[pl * PLANE + r * P] = 0.0f;
+        xs[pl * PLANE + r * P + P - 1] = 0.0f;
+        xs[pl * PLANE + r] = 0.0f;
+        xs[pl * PLANE + (P - 1) * P + r] = 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < 24; ++q) {
+        const int f = q * 256 + tid;
+        const int w4 = f % 4, hh = (f / 4) % FO_G, pl = f / 64;   // pl = ci*3 + kd
+        float *dst = xs + pl * PLANE + (hh + 1) * P + 1 + w4 * 4;
+        dst[0] = xv[q].x; dst[1] = xv[q].y; dst[2] = xv[q].z; dst[3] = xv[q].w;
+    }
+#pragma unroll
+    for (int q = 0; q < 11; ++q) {
+        const int i = q * 256 + tid;
+        if (i < FO_C * 3 * 28) wsd[i] = wl[q];
+    }
+    __syncthreads();
+    float acc[3] = {0.0f, 0.0f, 0.0f};
     for (int ci = 0; ci < FO_C; ++ci) {
-        const float *xc = xn + (size_t)ci * FO_S;
+        const float *xc = xs + ci * 3 * PLANE + h * P + ww;   // tap (kd, kh, kw) at + kd*PLANE + kh*P + kw
         float v[27];
 #pragma unroll
         for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int id = d + kd - 1, ih = h + kh - 1, iw = ww + kw - 1;
-                    const bool ok = id >= 0 && id < FO_G && ih >= 0 && ih < FO_G && iw >= 0 && iw < FO_G;
-                    v[kd * 9 + kh * 3 + kw] = ok ? xc[(id * FO_G + ih) * FO_G + iw] : 0.0f;
-                }
+                for (int kw = 0; kw < 3; ++kw) v[kd * 9 + kh * 3 + kw] = xc[kd * PLANE + kh * P + kw];
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float *wp = w + ((size_t)c * FO_C + ci) * 27;   // wave-uniform
+            const float4 *wp = reinterpret_cast<const float4 *>(wsd + (ci * 3 + c) * 28);
 #pragma unroll
-            for (int t = 0; t < 27; ++t) acc[c] = __builtin_fmaf(wp[t], v[t], acc[c]);
+            for (int q = 0; q < 7; ++q) {
+                const float4 wq = wp[q];
+                acc[c] = __builtin_fmaf(wq.x, v[q * 4], acc[c]);
+                if (q * 4 + 1 < 27) acc[c] = __builtin_fmaf(wq.y, v[q * 4 + 1], acc[c]);
+                if (q * 4 + 2 < 27) acc[c] = __builtin_fmaf(wq.z, v[q * 4 + 2], acc[c]);
+                if (q * 4 + 3 < 27) acc[c] = __builtin_fmaf(wq.w, v[q * 4 + 3], acc[c]);
+            }
         }
     }
     float s = 0.0f, ss = 0.0f;
