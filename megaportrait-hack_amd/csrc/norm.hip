@@ -28,6 +28,7 @@ gn_partial_kernel(const float *__restrict__ x, double *__restrict__ partial, siz
     const size_t end = begin + GN_CHUNK < cnt ? begin + GN_CHUNK : cnt;
     float s = 0.0f, ss = 0.0f;
     if ((cnt & 3) == 0 && (((size_t)p) & 15) == 0) {
+#pragma unroll 8   // (independent loads: in flight together instead of one round trip per trip; the adds keep their order)
         for (size_t i = begin + (size_t)threadIdx.x * 4; i < end; i += 1024) {
             float4 v = *reinterpret_cast<const float4 *>(p + i);
             s += (v.x + v.y) + (v.z + v.w);
@@ -89,6 +90,7 @@ gn_stats_direct_kernel(const float *__restrict__ x, float *__restrict__ stats, s
         const size_t end = begin + GN_CHUNK < cnt ? begin + GN_CHUNK : cnt;
         float s = 0.0f, ss = 0.0f;
         if (vec) {
+#pragma unroll 8
             for (size_t i = begin + (size_t)threadIdx.x * 4; i < end; i += 1024) {
                 float4 v = *reinterpret_cast<const float4 *>(p + i);
                 s += (v.x + v.y) + (v.z + v.w);
@@ -143,6 +145,7 @@ gn_stats_split_kernel(const float *__restrict__ x, int splits, size_t slab, cons
     double ds = 0.0, dss = 0.0;
     {   // flat over the (channel, voxel) span so tiny S (FlowField's 4x1x1 level) still uses every lane
         float s = 0.0f, ss = 0.0f;
+#pragma unroll 4
         for (size_t e = threadIdx.x; e < cnt; e += blockDim.x) {
             const size_t o = base + e;
             float v = sum_slabs(x, splits, slab, o);
@@ -373,6 +376,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
     const int c0 = (int)((base / S) % (size_t)p.C);
     const int shift = (S & (S - 1)) == 0 ? __ffs(S) - 1 : -1;  // S is a power of two on every hot-path layer
     float s = 0.0f, ss = 0.0f;
+#pragma unroll 4
     for (int e = threadIdx.x; e < cnt; e += nthr) {
         const int c = shift >= 0 ? (e >> shift) : e / S;
         float v = sum_slabs(p.x, q.x_splits, q.slab, base + e);
@@ -412,6 +416,7 @@ __global__ void __launch_bounds__(1024) gn_small_fused_kernel(GnSplitParams q, f
     const size_t oS = (size_t)oD * oH * oW;
     const int n_c0 = (int)(base / S);  // global (n*C + c) index of the group's first channel plane
     unsigned mbits = 0;
+#pragma unroll 4
     for (int e = threadIdx.x; e < cnt; e += nthr) {
         const int c = shift >= 0 ? (e >> shift) : e / S;
         const int i = e - c * S;
@@ -834,6 +839,7 @@ gn_tile_finalize_kernel(const float *__restrict__ part, const float *__restrict_
         const float2 *p = reinterpret_cast<const float2 *>(part) + (size_t)(g * cpg + c) * all_rows + (size_t)n * rows;
         const double b = bias ? (double)bias[g * cpg + c] : 0.0;
         double s1 = 0.0, s2 = 0.0;
+#pragma unroll 4
         for (int r = threadIdx.x; r < rows; r += 256) {   // sums of the raw accumulators ((value - bias[c]) / u) over a row's voxels
             const float2 v = p[r];
             s1 += (double)v.x;
