@@ -738,6 +738,23 @@ def main():
 
             if lanes is not None and use_plan:
                 leg("one_in_flight", one_in_flight_leg, hot, inp, B, peak=peak)
+                dc = (line.get("one_in_flight") or {}).get("dominant_conv")
+                if dc and f16x3:
+                    # The kernel's roofline is quoted where nothing else holds CUs while it runs: between the two events of a launch
+                    # in the two-batch loop sit the other batch's small kernels too (they delay some of the conv's persistent
+                    # workgroups, and the launch ends with its last one).  Same kernel, same process, same events — and the number
+                    # that the kernel trace of this command shows (under rocprofv3 the host is too slow to keep two batches going).
+                    r = line["roofline"]
+                    r["in_two_batch_loop"] = {k: r[k] for k in ("launch_ms", "launches_timed", "achieved", "frac")}
+                    r.update(launch_ms=dc["launch_ms"], launches_timed=dc["launches_timed"], achieved=dc["achieved"], frac=dc["frac"])
+                    r["measured"] = ("HIP events stamped with the kernel's begin / end (hipExtLaunchKernelGGL), K steps on ONE stream "
+                                     "(the `one_in_flight` leg of this run); `in_two_batch_loop`: the same events during the timed "
+                                     "region of the headline, where the other batch's kernels hold CUs while the conv starts and drains")
+                    r["note"] = (f"algorithmic (fp32-equivalent) FLOPs; the kernel issues 3x that on the f16 pipe: {round(3 * dc['achieved'], 1)} "
+                                 f"TFLOP/s = {round(3 * dc['achieved'] / peak, 4)} of the f16 peak; vs the fp32-MFMA peak "
+                                 f"({PEAK_F32_MFMA_TFLOPS}) the algorithmic rate is {round(dc['achieved'] / PEAK_F32_MFMA_TFLOPS, 2)}x.  The "
+                                 "kernel is power-bound: the package sits at its 1400 W limit with the clock throttled to ~1.7-2.0 GHz "
+                                 "while it runs (profiles/r02_power_probe.txt); the 2500 TFLOP/s peak assumes 2.4 GHz")
             if demand:
                 leg("full_final_conv", full_final_conv_leg, hot, inp, B)
             leg("roofline_hbm", roofline_hbm, hot, inp, B)
