@@ -291,7 +291,16 @@ __device__ __forceinline__ void stage_box(const float *__restrict__ vb /* v + b*
         int y = r2 / bx.ex, x = r2 - y * bx.ex;
         const float *src = vb + (size_t)c0 * vol + ((size_t)(bx.oz + z) * H + bx.oy + y) * W + bx.ox + x;
         float *dst = lds + r * cs_pad;
-        for (int c = wave; c < cs; c += 4) dst[c] = src[(size_t)c * vol];
+        // eight channel planes per trip, loads first: a load -> LDS-store trip at a time costs one L2 round trip per trip (24 of them
+        // for 96 channels; r03: that was half of K2's 57 us on the reference's fields)
+        for (int c = wave; c < cs; c += 32) {
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = c + 4 * k < cs ? src[(size_t)(c + 4 * k) * vol] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c + 4 * k < cs) dst[c + 4 * k] = t[k];
+        }
     }
 }
 
@@ -306,7 +315,14 @@ __device__ __forceinline__ void stage_box_planar(const float *__restrict__ vb, f
         int y = r2 / bx.ex, x = r2 - y * bx.ex;
         const float *src = vb + (size_t)c0 * vol + ((size_t)(bx.oz + z) * H + bx.oy + y) * W + bx.ox + x;
         float *dst = lds + r;
-        for (int c = wave; c < cs; c += 4) dst[c * bvol] = src[(size_t)c * vol];
+        for (int c = wave; c < cs; c += 32) {   // (eight planes per trip, loads first: see stage_box)
+            float t[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) t[k] = c + 4 * k < cs ? src[(size_t)(c + 4 * k) * vol] : 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (c + 4 * k < cs) dst[(c + 4 * k) * bvol] = t[k];
+        }
     }
 }
 
