@@ -186,14 +186,17 @@ f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const
 // ---- the conv kernel ---------------------------------------------------------------------------
 // GS = packed slabs (of 3 taps) streamed per barrier interval: 3 -> 4 barriers per chunk and 110 KB of
 // weight buffers (one workgroup per CU), 1 -> 10 barriers per chunk and 37 KB.
-template <int TD, int TH, int TW, int NWAVES, int GS>
+// MTS = 32-channel row tiles of the 96-channel slab one workgroup computes: 3 (all; blockIdx.y = the 96-channel tile) or 1
+// (blockIdx.y = 3 * tile + third: demand-driven launches, where a tile is ONE CU's matrix work and three CUs per tile cut its latency)
+template <int TD, int TH, int TW, int NWAVES, int GS, int MTS = 3>
 __device__ __forceinline__ void
 conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                      const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                      int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
                      const float *__restrict__ x_scale_p /* range descriptor of x */, int tiles_total, int xcd_aware,
                      const int *__restrict__ roi, int roi_frames, float *__restrict__ gn_part) {
-    constexpr int MT = 3, KC = F16X3_KC;
+    constexpr int MT = MTS, KC = F16X3_KC;
+    static_assert(MTS == 3 || MTS == 1, "row tiles per workgroup");
     // operand scale of the input tensor: from its range descriptor (activations: max|x| noted by the producing kernel or
     // mphip_absmax_range; gradients: mphip_grad_prep) — per tensor, a power of two
     // Demand-driven evaluation (tile_list != nullptr): only the listed output tiles are computed — G3d's final_conv feeds
@@ -250,7 +253,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     // XCD-aware start: workgroup ids go round-robin over the 8 XCDs, so consecutive ids get consecutive RANGES of tiles —
     // neighbouring tiles (which share halo rows) then run on the same XCD and meet in its L2
     decode_tile(tile_at(j_first));
-    const int cot = blockIdx.y;
+    const int cot = MTS == 3 ? blockIdx.y : blockIdx.y / 3, mb = MTS == 3 ? 0 : blockIdx.y % 3;
     const int nchunks = Ci / KC;
     const int c_begin = blockIdx.z * chunks_per_split;
     const int c_end = min(nchunks, c_begin + chunks_per_split);
@@ -369,7 +372,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     const int jpos = j < 4 ? j : j < 12 ? j - 4 : j < 20 ? j - 8 : j < 28 ? j - 12 : j - 16;
     const int jv = jg * 16 + jpos;  // column (voxel slot) of lane j inside its 32-voxel tile
     // fragment bases (halfs)
-    const int a_base = (kg * F16X3_COT + j) * 8;           // + ((part*TG + tap)*2*96 + m*32)*8
+    const int a_base = (kg * F16X3_COT + j + mb * 32) * 8;   // + ((part*TG + tap)*2*96 + m*32)*8
     int b_base[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -579,7 +582,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     const bool direct = gridDim.z == 1;
     float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
     const float unscale = whdr[0] * x_unscale;
-    const int co0 = cot * F16X3_COT;
+    const int co0 = cot * F16X3_COT + mb * 32;
     if (gn_part) {
         // GroupNorm statistics of THIS conv's output without a pass over it: per-channel (sum, sum of squares) of the values about to
         // be stored, as raw accumulators (the finalize kernel applies unscale and the bias in double), over the wave's 32*NT voxels -> gn_part[co][tile][wave][2]; gn_tile_finalize_kernel (norm.hip) folds a frame's
@@ -701,6 +704,19 @@ conv3d_k3_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__
                        float *__restrict__ gn_part) {
     conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
                                                  in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames, gn_part);
+}
+
+// demand-driven launches: one 32-channel third of a tile per workgroup (three CUs per tile; same bits: a row tile's accumulation
+// does not depend on its neighbours)
+template <int TD, int TH, int TW, int NWAVES, int GS>
+__global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv3d_k3_f16x3_third_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
+                             const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
+                             int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
+                             const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames,
+                             float *__restrict__ gn_part) {
+    conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS, 1>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
+                                                    in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames, gn_part);
 }
 
 // One wave per SIMD with up to 512 registers: a wave owns 96 output channels x 128 voxels (12 accumulator tiles), so every
@@ -1034,11 +1050,13 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     // the (2,8,8) one), each walking its share of the tiles
     const int tiles_total = (int)p.grid.x;
     const int per_cu = p.variant == 2 ? 2 : (p.variant == 1 || p.variant == 3 || p.td == 4) ? 1 : 2;
-    const long others = (long)p.grid.y * p.grid.z;
+    static const bool thirds_off = getenv("MPHIP_ROI_THIRDS") && getenv("MPHIP_ROI_THIRDS")[0] == '0';   // dev: same-box A/B
+    const bool thirds = roi && p.variant == 0 && p.td == 4 && !gn_part && !thirds_off;
+    const long others = (long)p.grid.y * (thirds ? 3 : 1) * p.grid.z;
     long gx = (256L * per_cu + others - 1) / others;
     if (gx < 1) gx = 1;
     if (gx > tiles_total || getenv("MPHIP_F16X3_NO_PERSIST")) gx = tiles_total;
-    dim3 grid((unsigned)gx, p.grid.y, p.grid.z);
+    dim3 grid((unsigned)gx, p.grid.y * (thirds ? 3 : 1), p.grid.z);
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');  // dev switch for same-box A/B
     // (two-slab groups for the 512-voxel tile — 5 instead of 9 barriers per chunk, 147 KB of LDS — were tried: the
     //  compiler spills 188 registers in that instantiation and it runs 35 % slower)
@@ -1056,6 +1074,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     if (p.variant == 3) F16X3_LAUNCH((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), 256)
     else if (p.variant == 2) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), 256)
     else if (p.variant == 1) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), 512)
+    else if (p.td == 4 && thirds) F16X3_LAUNCH((conv3d_k3_f16x3_third_kernel<4, 8, 8, 8, 3>), 512)
     else if (p.td == 4) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), 512)
     else F16X3_LAUNCH((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), 256)
 #undef F16X3_LAUNCH
