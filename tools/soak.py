@@ -40,3 +40,24 @@ for blk in range(3):
           f"loss {float(losses[-n_tr // 3]):.6f} -> {float(losses[-1]):.6f}", flush=True)
 assert all(torch.isfinite(l) for l in losses) and float(losses[-1]) < float(losses[0])
 print("soak ok")
+# two batches in flight on two streams (bench.py's default loop): every output equals the single-stream result bit for bit
+hot.eval()
+lanes = [torch.cuda.Stream(device=dev) for _ in range(2)]
+with torch.no_grad():
+    ref = hot(**inp).clone()
+    for ln in lanes:
+        ln.wait_stream(torch.cuda.current_stream())
+    ok, t0 = True, time.perf_counter()
+    outs = []
+    for i in range(n_inf // 3):
+        with torch.cuda.stream(lanes[i % 2]):
+            outs.append(hot(**inp))
+        if len(outs) == 64:
+            torch.cuda.synchronize()
+            ok = ok and all(torch.equal(o, ref) for o in outs)
+            outs = []
+    torch.cuda.synchronize()
+    ok = ok and all(torch.equal(o, ref) for o in outs)
+    dt = time.perf_counter() - t0
+    print(f"two streams, {n_inf // 3} steps: {8 * (n_inf // 3) / dt:7.1f} frames/s (incl. the checks), bitwise equal to the single-stream step: {ok}; "
+          f"reserved {torch.cuda.memory_reserved() / 2**20:.0f} MiB", flush=True)
