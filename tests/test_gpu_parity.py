@@ -969,3 +969,36 @@ def test_bench_two_ranks_over_rccl():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 16 and line["value"] > 0
+
+
+def test_bench_line_contract_on_one_gpu():
+    """`python bench.py --gpus 1 --steps K --warmup W` (the driver's call, with a small K): ONE JSON line with the contract's keys, the
+    default loop (two batches in flight, one plan per stream), the dominant kernel's roofline quoted from the one-stream leg of the same
+    run with the two-batch reading beside it, and the legs a one-second extras budget still admits."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
+                        "--extras-budget", "1"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline"):
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 4 and line["warmup"] == 2 and line["unit"] == "frames/s" and line["value"] > 0
+    assert abs(line["value"] - 8 * 4 / (line["ms_per_step"] * 4e-3)) / line["value"] < 1e-2      # value = frames of the K steps / their time
+    assert line["higher_is_better"] is True and line["scaling"] == "weak" and line["vs_baseline"] is None and line["data"] == "synthetic"
+    assert "workload" in line["config"] and line["config"]["batches_in_flight"] == 2 and line["config"]["frames_per_gpu_per_step"] == 8
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["unit"] == "TFLOP/s" and roof["peak"] == 2500.0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and 0.05 < roof["frac"] < 0.5
+    assert abs(roof["achieved"] - roof["flops_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e12) / roof["achieved"] < 1e-2
+    one = line["one_in_flight"]
+    # (the events of the timed region come from ONE of the two plans: its 2 of the 4 steps, two full-size launches each)
+    assert one["dominant_conv"]["launch_ms"] == roof["launch_ms"] and roof["in_two_batch_loop"]["launches_timed"] == 4
+    assert one["value"] > 0 and one["step_ms"]["min"] <= one["step_ms"]["median"] <= one["step_ms"]["max"]
+    assert roof["demand_driven_launch"]["launches_timed"] == 2
