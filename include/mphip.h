@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 8
+#define MPHIP_ABI_VERSION 9
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -436,6 +436,12 @@ void mphip_hot_slice_plan_destroy(mphip_hot_slice_plan *plan);
  * the f16 range since the last reset — Inf/NaN inputs, or finite values beyond a wrong caller-supplied range descriptor.
  * They are NOT clamped (the output carries Inf/NaN like the reference's fp32 conv would); 0 in normal operation.     */
 int mphip_f16x3_saturation_count(unsigned long long *count, int reset);
+
+/* Measurement only (tools/mfma_sol.py, bench.py `roofline.sustained_peak`): the f16x3 convs' MFMA stream and nothing else — three
+ * v_mfma_f32_32x32x16_f16 per product on random hi/lo fragments, 3 x 2 accumulator tiles per wave, 8 waves per workgroup; mode 1 reads
+ * its ten fragments per tap from LDS like the conv, mode 0 keeps them in registers.  No global traffic.  One launch issues
+ * workgroups * 8 * iters * 162 MFMAs (32768 FLOP each); sink: >= workgroups * 512 floats (keeps the result alive).        */
+int mphip_debug_mfma_sol(float *sink, int workgroups, int iters, int mode, void *stream);
 
 #ifdef __cplusplus
 }

@@ -104,6 +104,7 @@ SIGNATURES = {
     "mphip_g3d_workspace_bytes": (_sz, [_p, _i]),
     "mphip_g3d_forward": (_i, [_p, _p, _p, _p, _i, _p, _sz, _p]),
     "mphip_hot_slice_plan_destroy": (None, [_p]),
+    "mphip_debug_mfma_sol": (_i, [_p, _i, _i, _i, _p]),
 }
 
 _lib = None

@@ -10,7 +10,7 @@ objs=()
 pids=()
 bdir="${MPHIP_BUILD_DIR:-$here/build}"
 mkdir -p "$bdir"
-for f in api warp norm conv3d conv3d_f16x3 backward conv3d_bwd_f16x3 flowfield plan; do
+for f in api warp norm conv3d conv3d_f16x3 conv3d_f16x3_wino mfma_sol backward conv3d_bwd_f16x3 flowfield plan; do
   "$HIPCC" $FLAGS -c "$here/$f.hip" -o "$bdir/$f.o" &
   pids+=($!)
   objs+=("$bdir/$f.o")

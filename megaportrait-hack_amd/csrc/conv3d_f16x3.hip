@@ -26,16 +26,11 @@
 
 #include "mphip_common.h"
 #include "mphip_conv.h"
+#include "mphip_f16x3.h"
 
 namespace mphip {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half2v __attribute__((ext_vector_type(2)));
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
 constexpr float X_SCALE = 16.0f;          // legacy fixed activation scale: only when a caller passes no range descriptor
-constexpr float F16_CLAMP = 65000.0f;
 constexpr int F16X3_KC = 16;              // input channels per chunk = K of one MFMA
 constexpr int F16X3_TG = 3;               // taps per packed weight slab
 constexpr int F16X3_NG = 27 / F16X3_TG;   // slabs per 16-channel chunk
@@ -48,12 +43,6 @@ constexpr int SLAB_HALFS = 2 * F16X3_TG * 2 * F16X3_COT * 8;  // [part][tap][kg]
 // lo = 0, and the MFMA propagates Inf/NaN into the output exactly like the reference's fp32 conv would.  Such elements are
 // counted (one atomic per wavefront that saw any, i.e. none in normal operation): mphip_f16x3_saturation_count().
 __device__ unsigned long long g_f16x3_saturated;
-
-__device__ __forceinline__ void split_f16(float v, _Float16 &hi, _Float16 &lo) {
-    hi = (_Float16)v;                      // |v| > 65504 -> +-Inf, NaN -> NaN
-    const float r = v - (float)hi;
-    lo = (fabsf(v) <= F16_CLAMP) ? (_Float16)r : (_Float16)0.0f;   // (Inf - Inf would be NaN: keep Inf an Inf)
-}
 
 #ifdef MPHIP_PROFILE_PHASES
 // dev instrumentation: cycles (s_memtime) per phase, summed over all waves: [0] prologue [1] X-load issue [2] DMA issue
@@ -103,14 +92,6 @@ __global__ void __launch_bounds__(256) f16x3_absmax_kernel(const float *__restri
         const unsigned mine = __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));  // non-negative floats order like uints
         if (mine > __hip_atomic_load(hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(hdr + 2, mine);
     }
-}
-
-__device__ __forceinline__ float weight_scale(unsigned maxbits) {
-    float m = __uint_as_float(maxbits);
-    if (!(m > 0.0f) || !(m < 1e30f)) return 1.0f;
-    int e;
-    frexpf(m, &e);              // m = f * 2^e, f in [0.5,1)  ->  m < 2^e
-    return ldexpf(1.0f, 15 - e);  // m*scale < 2^15 = 32768
 }
 
 // OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*NG + g][part][tap][kg][co][8] f16 (after the header).
@@ -358,12 +339,21 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
         const int npieces_ = (((grp) + 1) * GS <= F16X3_NG ? GS : F16X3_NG - (grp) * GS) * (SLAB_HALFS * 2 / 1024); \
         _Pragma("unroll") for (int q = 0; q < (W_PIECES + NWAVES - 1) / NWAVES; ++q) {            \
             const int piece_ = q * NWAVES + wave;                                                 \
-            if (piece_ < npieces_)                                                                \
-                __builtin_amdgcn_global_load_lds(                                                 \
-                    (const __attribute__((address_space(1))) void *)(src_ + piece_ * 512),        \
-                    (__attribute__((address_space(3))) void *)(Ws + (wbuf) * W_BUF + piece_ * 512), 16, 0, 0); \
+            if (piece_ < npieces_) F16X3_DMA16(src_ + piece_ * 512, Ws + (wbuf) * W_BUF + piece_ * 512) \
         }                                                                                         \
     }
+    // (the DMA is issued by hand, mphip_f16x3.h: with the builtin hipcc puts `s_waitcnt vmcnt(0)` in front of the first fragment read
+    //  that follows a transfer — it cannot prove the read does not alias the destination — so every barrier interval opened with a
+    //  full L2 round trip; now a transfer has the whole interval to land and is waited for right before the interval's barrier)
+#ifdef MPHIP_BUILTIN_DMA   /* dev: same-box A/B against the compiler-issued DMA */
+#define F16X3_DMA16(src_p_, dst_p_)                                                               \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src_p_),    \
+                                     (__attribute__((address_space(3))) void *)(dst_p_), 16, 0, 0);
+#define F16X3_DMA_LANDED()
+#else
+#define F16X3_DMA16(src_p_, dst_p_) lds_dma16((src_p_), (unsigned)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)(dst_p_));
+#define F16X3_DMA_LANDED() lds_dma_wait<0>();
+#endif
 
     // ds_read_b128 is serviced in 16-lane groups {0-3,12-15,20-27} / {4-11,16-19,28-31} (per half-wave):
     // give every group two whole 8-voxel rows (2 x 128 contiguous bytes) instead of row fragments of
@@ -400,6 +390,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     F16X3_DMA_W(c_begin, 0, 0);
     F16X3_LOAD_X(c_begin);
     F16X3_WRITE_X(c_begin);
+    F16X3_DMA_LANDED()
     __syncthreads();
     PROF_ADD(0)
     int wb = 0;
@@ -552,7 +543,8 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 #endif
 #undef F16X3_MFMA
             PROF_ADD(3)
-            __syncthreads();  // slab (g+1) landed (DMA drained by the barrier's vmcnt(0)); slab g free
+            F16X3_DMA_LANDED()
+            __syncthreads();  // slab (g+1) landed (this wave's pieces: the wait above; the others': the barrier); slab g free
             PROF_ADD(4)
             wb ^= 1;
         }
@@ -657,6 +649,8 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 #undef F16X3_WRITE_X
 #undef F16X3_PUT
 #undef F16X3_DMA_W
+#undef F16X3_DMA16
+#undef F16X3_DMA_LANDED
     if (__builtin_amdgcn_ballot_w64(sat_ != 0) != 0) {  // never taken in normal operation
         unsigned tot = sat_;
 #pragma unroll
@@ -923,8 +917,12 @@ size_t f16x3_packed_bytes_k1(int Co, int Ci) {
     return 16 + (size_t)(Co / F16X3_COT) * (Ci / F16X3_KC) * K1_SLAB_HALFS * sizeof(_Float16);
 }
 
-size_t f16x3_packed_bytes(int Co, int Ci) {
+static size_t f16x3_direct_bytes(int Co, int Ci) {   // header + the direct kernel's slabs
     return 16 + (size_t)(Co / F16X3_COT) * (Ci / F16X3_KC) * F16X3_NG * SLAB_HALFS * sizeof(_Float16);
+}
+
+size_t f16x3_packed_bytes(int Co, int Ci) {   // ... + the transformed-domain slabs of the layers that can take that kernel
+    return f16x3_direct_bytes(Co, Ci) + f16x3_wino_packed_bytes(Co, Ci);
 }
 
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
@@ -952,6 +950,8 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     // (a ~5^3 box is 2 tiles either way: 4x8x8 halves the work per tile)
     // (2x8x8 tiles on 4 waves for these launches: measured the same 0.092 ms as 4x8x8, r03)
     if (roi && p.td == 4 && !force) p.variant = 0;
+    // variant 4: the 1-D Winograd F(2,3) kernel (conv3d_f16x3_wino.hip; (4,8,8) tile, 2/3 of the MFMAs) on launches that fill the chip
+    if (!roi && !force && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
     const long tiles = (p.variant == 1 || p.variant == 3) ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup (each split adds a slab write + a reduce pass): the largest
@@ -973,18 +973,20 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     }
     const char *force_sp = getenv("MPHIP_F16X3_SPLITS");   // dev: planner sweep (tools/sweep_conv_plans.py)
     if (force_sp && atoi(force_sp) > 0 && nchunks % atoi(force_sp) == 0) sp = atoi(force_sp);   // (whole chunks per split only)
+    if (p.variant == 4) sp = 1;   // (the transformed-domain kernel has no split-K form; it only takes launches that fill the chip)
     p.splits = sp;
     p.chunks_per_split = (nchunks + sp - 1) / sp;
     p.grid = dim3((unsigned)tiles, Co / F16X3_COT, sp);
     return p;
 }
 
-int f16x3_tile_waves(const F16x3Plan &p) {   // waves per workgroup of the kernel variant f16x3_launch picks
-    return (p.variant == 2 || p.variant == 3) ? 4 : (p.variant == 1 || p.td == 4) ? 8 : 4;
+int f16x3_tile_waves(const F16x3Plan &p) {   // GroupNorm-partial rows per tile of the kernel variant f16x3_launch picks (= its waves;
+                                              // the Winograd kernel leaves one row per plane pair)
+    return p.variant == 4 ? 2 : (p.variant == 2 || p.variant == 3) ? 4 : (p.variant == 1 || p.td == 4) ? 8 : 4;
 }
 
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]) {   // output tile (d,h,w) of the kernel variant f16x3_launch picks
-    dims[0] = (p.variant == 1 || p.variant == 2 || p.variant == 3) ? 4 : p.td;
+    dims[0] = (p.variant >= 1 && p.variant <= 4) ? 4 : p.td;
     dims[1] = 8;
     dims[2] = (p.variant == 1 || p.variant == 3) ? 16 : 8;
 }
@@ -1002,9 +1004,11 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed,
     if (k == 1)
         hipLaunchKernelGGL(f16x3_pack_k1_kernel, dim3(256), dim3(256), 0, s, w, (_Float16 *)((char *)out + 16), hdr, (float *)out, Co,
                            Ci, transposed);
-    else
+    else {
         hipLaunchKernelGGL(f16x3_pack_kernel, dim3((unsigned)((Co / PK_CO) * (Ci / F16X3_KC))), dim3(256), 0, s, w,
                            (_Float16 *)((char *)out + 16), hdr, (float *)out, Co, Ci, transposed);
+        if (f16x3_wino_packed_bytes(Co, Ci)) f16x3_wino_pack(w, (char *)out + f16x3_direct_bytes(Co, Ci), hdr, Co, Ci, transposed, s);
+    }
     return check_launch("pack_conv_weight(f16x3)");
 }
 
@@ -1037,6 +1041,14 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const float *hdr = (const float *)wpacked;
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
+    if (p.variant == 4) {
+        if (in_affine && Ci > 256) {
+            set_error("conv3d_fwd(f16x3, F(2,3)): fused input GroupNorm supports Ci <= 256 (got %d)", Ci);
+            return MPHIP_EINVAL;
+        }
+        return f16x3_wino_launch(x, (const char *)wpacked + f16x3_direct_bytes(Co, Ci), hdr, bias, dst, N, Ci, Co, D, H, W, in_affine,
+                                 in_relu, x_scale, s, gn_part, t0, t1);
+    }
     if (roi) {   // demand-driven: boxes -> the list of tiles they touch (1 + tiles ints of caller workspace); the kernel gets the LIST
         int dims[3];
         f16x3_tile_dims(p, dims);
@@ -1108,5 +1120,11 @@ extern "C" int mphip_f16x3_saturation_count(unsigned long long *count, int reset
             return MPHIP_ELAUNCH;
         }
     }
+    unsigned long long wn = 0;   // the transformed-domain kernel keeps its own counter (separate translation unit)
+    if (mphip::f16x3_wino_saturation(&wn, reset) != 0) {
+        mphip::set_error("f16x3_saturation_count: hipMemcpyFromSymbol failed");
+        return MPHIP_ELAUNCH;
+    }
+    *count += wn;
     return MPHIP_OK;
 }

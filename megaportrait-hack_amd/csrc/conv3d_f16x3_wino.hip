@@ -1,0 +1,492 @@
+// K4 fast mode, transformed domain — Conv3d 3x3x3 on the f16 matrix cores ("f16x3" split arithmetic) with a 1-D Winograd
+// F(2,3) transform along W: two thirds of the matrix work of conv3d_f16x3.hip for the same fp32-class result.
+//
+// Why: the direct f16x3 kernel is bound by the energy of its MFMAs (the package sits at its power limit while it runs:
+// DESIGN.md 3, profiles/r02_power_probe.txt; 63 % of a launch's energy is the 23.9 M v_mfma_f32_32x32x16_f16 it issues).  Only
+// fewer MFMAs per output voxel make it faster.  F(2,3) along w computes an output PAIR (w = 2q, 2q+1) of one (d,h) row from
+// four input values x[2q-1 .. 2q+2] per (input channel, kd, kh) with 4 multiplies instead of 6:
+//     t0 = x0 - x2   t1 = x1 + x2   t2 = x2 - x1   t3 = x1 - x3                      (input transform, fp32, before the split)
+//     u0 = g0        u1 = (g0+g1+g2)/2   u2 = (g0-g1+g2)/2   u3 = g2                 (filter transform, at pack time)
+//     M_p[co][q] = sum over (ci, kd, kh) of u_p * t_p                                  (four independent GEMMs, K = 9 Ci)
+//     y[2q] = M0 + M1 + M2     y[2q+1] = M1 - M2 - M3                                   (output transform, fp32)
+// Each u_p / t_p is split into two f16 halves like the direct kernel's operands (three MFMAs per product, fp32 accumulate):
+// |t| <= 2 max|x| and |u| <= 1.5 max|w| stay inside the f16 range at the same per-tensor power-of-two scales.
+//
+// Shape of the kernel (512 threads = 8 waves, two per SIMD, one workgroup per CU, persistent over tiles):
+//   * tile = 4 x 8 x 8 output voxels x 96 output channels = 4 positions x 128 pair-columns; wave (p, ch) owns position p of the
+//     two d-planes 2ch, 2ch+1: 3 x 2 MFMA tiles, 96 accumulator registers — the direct kernel's wave shape, so the LDS reads
+//     per MFMA are the same.  (Accumulators per output voxel double in the transformed domain; that is why the tile is 256
+//     voxels, not 512.)
+//   * X: the halo rows (6 x 10 rows of 10 voxels per channel) are loaded one (channel pair, row) per thread, transformed and split
+//     in registers, and written to LDS as [part][position][k-group][row][pair][8 channels] — the pair domain has no halo in w,
+//     so the 32 columns of an MFMA tile (8 rows x 4 pairs of one plane) are 512 contiguous bytes per k-group: conflict-free
+//     ds_read_b128 without any lane permutation.
+//   * W: one slab = one (kd,kh) x 16 input channels x 4 positions x 96 output channels = 24 KB, streamed by LDS-DMA into a
+//     RING of four slabs, three slabs ahead of the MFMAs.  The DMA is issued by hand (mphip_f16x3.h: lds_dma16) so that no
+//     compiler-inserted vmcnt(0) sits between a transfer and the fragment reads of OTHER slabs, and a wave waits only for the
+//     pieces it issued two intervals ago.  A-fragments of the next slab are prefetched BEFORE the interval's barrier (the slab
+//     was published one barrier earlier), so the barrier only guards the ring slot that is overwritten next.
+//   * output transform: the four positions of a pair live in four waves.  After the last chunk every wave parks three quarters
+//     of its accumulators in the (now dead) X region, one 32-channel row tile per round, and finishes the quarter it keeps:
+//     y0/y1, bias, the GroupNorm statistics partials of its channels, 8-byte stores.
+#include <stdlib.h>
+
+#include <hip/hip_ext.h>
+
+#include "mphip_conv.h"
+#include "mphip_f16x3.h"
+
+namespace mphip {
+
+constexpr int WN_KC = 16;                                  // input channels per chunk = K of one MFMA
+constexpr int WN_COT = 96;                                 // output channels per workgroup (3 MFMA row tiles)
+constexpr int WN_NG = 9;                                   // (kd,kh) slabs per chunk
+constexpr int WN_RING = 4;                                 // slabs resident in LDS
+constexpr int WN_SLAB_HALFS = 2 * 4 * 2 * WN_COT * 8;      // [part][position][kg][co][8] = 12288 halfs = 24576 B
+constexpr int WN_PART_HALFS = WN_SLAB_HALFS / 2;
+constexpr int WN_TD = 4, WN_TH = 8, WN_TW = 8;             // output tile
+constexpr int WN_HD = WN_TD + 2, WN_HH = WN_TH + 2;
+constexpr int WN_ROWS = WN_HD * WN_HH;                     // 60 halo rows
+constexpr int WN_XBLK = WN_ROWS * 4 * 8 + 16;              // halfs per (part, position, kg) block: 240 (row, pair) slots x 8 channels
+                                                           // + 32 B so that the two k-groups of a staging write sit 8 banks apart
+constexpr int WN_XPART = 4 * 2 * WN_XBLK;                  // halfs per part (hi or lo)
+constexpr int WN_X_HALFS = 2 * WN_XPART;                   // 30976 halfs = 61952 B
+constexpr int WN_AFF_CI = 256;                             // fused input GroupNorm table: Ci <= 256 (LDS: 98304 + 61952 + 2048 B)
+constexpr int WN_XLOADS = 8;                               // vector-memory instructions of one halo prefetch (per wave)
+
+// ---- weight packing: OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*9 + (kd*3+kh)][part][position][kg][co][8] f16 ----
+// (scale: the per-tensor power of two of the direct pack's header, max|w|*scale < 2^15, so |u|*scale < 1.5 * 2^15 < 65504)
+__global__ void __launch_bounds__(256)
+f16x3_wino_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *__restrict__ hdr, int Co, int Ci,
+                       int transposed) {
+    const float scale = weight_scale(hdr[2]);
+    const int nchunks = Ci / WN_KC;
+    const size_t total = (size_t)(Co / WN_COT) * nchunks * WN_NG * 4 * 2 * WN_COT;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t r = i;
+        const int co = (int)(r % WN_COT); r /= WN_COT;
+        const int kg = (int)(r % 2); r /= 2;
+        const int p = (int)(r % 4); r /= 4;
+        const int g = (int)(r % WN_NG); r /= WN_NG;
+        const int chunk = (int)(r % nchunks);
+        const int cot = (int)(r / nchunks);
+        const int kd = g / 3, kh = g % 3, cog = cot * WN_COT + co;
+        half8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ci = chunk * WN_KC + kg * 8 + e;
+            double g0, g1, g2;
+            if (!transposed) {
+                const float *q = w + ((size_t)cog * Ci + ci) * 27 + kd * 9 + kh * 3;
+                g0 = q[0]; g1 = q[1]; g2 = q[2];
+            } else {   // w is the original conv's [Ci][Co][27] weight, this pack its bwd-data conv (taps reversed)
+                const float *q = w + ((size_t)ci * Co + cog) * 27 + (2 - kd) * 9 + (2 - kh) * 3;
+                g0 = q[2]; g1 = q[1]; g2 = q[0];
+            }
+            const double u = p == 0 ? g0 : p == 1 ? 0.5 * (g0 + g1 + g2) : p == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+            const double us = u * (double)scale;
+            const _Float16 h = (_Float16)(float)us;                  // (the filter transform itself is exact in double)
+            const float rem = (float)(us - (double)(float)h);
+            hi[e] = h;
+            lo[e] = (fabs(us) <= (double)F16_CLAMP) ? (_Float16)rem : (_Float16)0.0f;
+        }
+        const size_t slab = ((size_t)cot * nchunks + chunk) * WN_NG + g;
+        const size_t inner = ((size_t)(p * 2 + kg) * WN_COT + co) * 8;
+        *reinterpret_cast<half8 *>(out + slab * WN_SLAB_HALFS + inner) = hi;
+        *reinterpret_cast<half8 *>(out + slab * WN_SLAB_HALFS + WN_PART_HALFS + inner) = lo;
+    }
+}
+
+__device__ unsigned long long g_f16x3_wino_saturated;
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
+                            const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
+                            unsigned x_bytes, const float *__restrict__ in_affine, int in_relu, const float *__restrict__ x_range,
+                            int tiles_total, int xcd_aware, float *__restrict__ gn_part) {
+    __shared__ __attribute__((aligned(16))) _Float16 smem[WN_RING * WN_SLAB_HALFS + WN_X_HALFS + WN_AFF_CI * 4];
+    _Float16 *const Ws = smem;                                   // ring of 4 slabs
+    _Float16 *const Xs = smem + WN_RING * WN_SLAB_HALFS;         // [part][position][kg][row*4 + pair][8]
+    float *const aff = reinterpret_cast<float *>(Xs + WN_X_HALFS);   // [Ci][2]: (scale, shift) of the fused input GroupNorm
+    float *const Ex = reinterpret_cast<float *>(Xs);             // output-transform exchange: [wave][slot 0..5][lane][4] (48 KB)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = wave & 3, ch = wave >> 2;                      // Winograd position, plane pair
+    const int j = lane & 31, kgl = lane >> 5;
+    const int HW = H * W, DHW = D * HW;
+    const int ntiles = tiles_total;
+    const int j_first = xcd_aware ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    if (j_first >= ntiles) return;   // (workgroup-uniform, before any barrier)
+    float x_scale = 16.0f, x_unscale = 1.0f / 16.0f;
+    if (x_range) range_scale_block(x_range, x_scale, x_unscale);
+
+    const int tiles_w = W / WN_TW, tiles_h = H / WN_TH, tiles_d = D / WN_TD;
+    int n, d0, h0, w0;   // the tile the STAGING side addresses (one chunk ahead of the MFMAs; the next tile during a tile's last chunk)
+    auto decode_tile = [&](int tile_id) {
+        int bid = tile_id;
+        const int tw = bid % tiles_w; bid /= tiles_w;
+        const int th = bid % tiles_h; bid /= tiles_h;
+        const int td = bid % tiles_d;
+        n = bid / tiles_d;
+        d0 = td * WN_TD; h0 = th * WN_TH; w0 = tw * WN_TW;
+    };
+    decode_tile(j_first);
+    const int cot = blockIdx.y;
+    const int nchunks = Ci / WN_KC;
+    const int nmine = (ntiles - j_first + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles this workgroup walks
+    const int s_total = nmine * nchunks * WN_NG;                                   // slabs it consumes
+
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
+    const unsigned chan_stride = (unsigned)DHW * 4u;
+
+    // ---- X staging: thread = (channel pair cp, halo row srow); 480 of the 512 threads ------------------------------------------
+    const int cp = tid & 7, srow = tid >> 3;
+    const bool stager = srow < WN_ROWS;
+    const int sdl = srow / WN_HH, shl = srow % WN_HH;
+    const bool fuse_in = in_affine != nullptr;   // workgroup-uniform
+    int aff_n = -1;
+    auto row_off = [&]() -> unsigned {   // byte offset of (n, channel 2cp of chunk 0, row, w0), or OOB (padding rows / idle threads)
+        const int gd = d0 - 1 + sdl, gh = h0 - 1 + shl;
+        if (stager && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H)
+            return (unsigned)((((long)n * Ci + 2 * cp) * DHW + (long)gd * HW + gh * W + w0) * 4);
+        return OOB;
+    };
+    f32x4 xa0, xb0, xa1, xb1;   // channels 2cp / 2cp+1: voxels w0..w0+3, w0+4..w0+7
+    float xl0, xr0, xl1, xr1;   // ... w0-1, w0+8
+#define WN_LOAD_X(chunk)                                                                                   \
+    {                                                                                                      \
+        const unsigned soff_ = (unsigned)((long)(chunk) * WN_KC * DHW * 4);                                \
+        const unsigned o_ = row_off();                                                                     \
+        const unsigned o1_ = o_ == OOB ? OOB : o_ + chan_stride;                                           \
+        const bool lft_ = o_ != OOB && w0 > 0, rgt_ = o_ != OOB && w0 + WN_TW < W;                         \
+        xa0 = buf_load_f4(rsrc, o_, soff_);                                                                \
+        xb0 = buf_load_f4(rsrc, o_ == OOB ? OOB : o_ + 16u, soff_);                                        \
+        xa1 = buf_load_f4(rsrc, o1_, soff_);                                                               \
+        xb1 = buf_load_f4(rsrc, o1_ == OOB ? OOB : o1_ + 16u, soff_);                                      \
+        xl0 = buf_load_f(rsrc, lft_ ? o_ - 4u : OOB, soff_);                                               \
+        xr0 = buf_load_f(rsrc, rgt_ ? o_ + 32u : OOB, soff_);                                              \
+        xl1 = buf_load_f(rsrc, lft_ ? o1_ - 4u : OOB, soff_);                                              \
+        xr1 = buf_load_f(rsrc, rgt_ ? o1_ + 32u : OOB, soff_);                                             \
+    }
+    unsigned sat_ = 0;
+    // registers -> (fused GroupNorm + ReLU) -> scale -> F(2,3) input transform -> split -> LDS
+#define WN_WRITE_X(chunk)                                                                                  \
+    if (stager) {                                                                                          \
+        float v0_[10] = {xl0, xa0[0], xa0[1], xa0[2], xa0[3], xb0[0], xb0[1], xb0[2], xb0[3], xr0};        \
+        float v1_[10] = {xl1, xa1[0], xa1[1], xa1[2], xa1[3], xb1[0], xb1[1], xb1[2], xb1[3], xr1};        \
+        if (fuse_in) {                                                                                     \
+            const bool row_ok_ = row_off() != OOB;                                                         \
+            const float4 sc_ = *reinterpret_cast<const float4 *>(aff + ((chunk) * WN_KC + 2 * cp) * 2);    \
+            _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                               \
+                const bool ok_ = row_ok_ && (i == 0 ? w0 > 0 : i == 9 ? w0 + WN_TW < W : true);            \
+                float a_ = v0_[i] * sc_.x + sc_.y, b_ = v1_[i] * sc_.z + sc_.w;                            \
+                if (in_relu) {                                                                             \
+                    a_ = fmaxf(a_, 0.0f);                                                                  \
+                    b_ = fmaxf(b_, 0.0f);                                                                  \
+                }                                                                                          \
+                v0_[i] = ok_ ? a_ : 0.0f;                                                                  \
+                v1_[i] = ok_ ? b_ : 0.0f;                                                                  \
+            }                                                                                              \
+        }                                                                                                  \
+        _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                   \
+            v0_[i] *= x_scale;                                                                             \
+            v1_[i] *= x_scale;                                                                             \
+            sat_ += !(fabsf(v0_[i]) <= 0.5f * F16_CLAMP) + !(fabsf(v1_[i]) <= 0.5f * F16_CLAMP);  /* NaN counts */ \
+        }                                                                                                  \
+        _Float16 *xd_ = Xs + (cp >> 2) * WN_XBLK + srow * 32 + (cp & 3) * 2;                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
+            const float t0_[4] = {v0_[2 * q] - v0_[2 * q + 2], v0_[2 * q + 1] + v0_[2 * q + 2],            \
+                                  v0_[2 * q + 2] - v0_[2 * q + 1], v0_[2 * q + 1] - v0_[2 * q + 3]};       \
+            const float t1_[4] = {v1_[2 * q] - v1_[2 * q + 2], v1_[2 * q + 1] + v1_[2 * q + 2],            \
+                                  v1_[2 * q + 2] - v1_[2 * q + 1], v1_[2 * q + 1] - v1_[2 * q + 3]};       \
+            _Pragma("unroll") for (int pp = 0; pp < 4; ++pp) {                                             \
+                _Float16 h0_, l0_, h1_, l1_;                                                               \
+                split_f16(t0_[pp], h0_, l0_);                                                              \
+                split_f16(t1_[pp], h1_, l1_);                                                              \
+                const half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                           \
+                *reinterpret_cast<half2v *>(xd_ + pp * 2 * WN_XBLK + q * 8) = hv_;                         \
+                *reinterpret_cast<half2v *>(xd_ + WN_XPART + pp * 2 * WN_XBLK + q * 8) = lv_;              \
+            }                                                                                              \
+        }                                                                                                  \
+    }
+
+    // ---- weight stream: slab s of this workgroup = (chunk (s / 9) % nchunks, group s % 9), ring slot s & 3 ---------------------
+    const unsigned ws_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)Ws;
+    const _Float16 *const wsrc = wslabs + (size_t)cot * nchunks * WN_NG * WN_SLAB_HALFS + (size_t)lane * 8;
+    int dma_s = 0, dma_cg = 0;   // slabs issued so far; its (chunk*9 + group) index into the packed tensor
+    const int cg_total = nchunks * WN_NG;
+    auto dma_issue = [&]() -> int {   // 3 pieces of 1 KiB per wave; returns the number of vector-memory instructions issued
+        if (dma_s >= s_total) return 0;
+        const _Float16 *src = wsrc + (size_t)dma_cg * WN_SLAB_HALFS + wave * 512;
+        const unsigned dst = ws_lds + (unsigned)(dma_s & (WN_RING - 1)) * (WN_SLAB_HALFS * 2) + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) lds_dma16(src + q * 8 * 512, dst + (unsigned)q * 8192u);
+        ++dma_s;
+        if (++dma_cg == cg_total) dma_cg = 0;
+        return 3;
+    };
+
+    // fragment bases (halfs)
+    const int a_base = ((p * 2 + kgl) * WN_COT + j) * 8;   // + part*WN_PART_HALFS + m*256, inside a ring slot
+    int b_base[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) b_base[t] = (p * 2 + kgl) * WN_XBLK + (((2 * ch + t) * WN_HH + (j >> 2)) * 4 + (j & 3)) * 8;
+
+    auto load_aff = [&]() {
+        for (int i = tid; i < Ci * 2; i += 512) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
+        aff_n = n;
+    };
+
+    // ---- prologue: slabs 0..2 in flight, X(chunk 0) staged ---------------------------------------------------------------------
+    if (fuse_in) {
+        load_aff();
+        lds_barrier();
+    }
+    dma_issue();
+    dma_issue();
+    dma_issue();
+    WN_LOAD_X(0);
+    WN_WRITE_X(0);
+    lds_dma_wait<0>();
+    lds_barrier();
+
+    half8 ah[3], al[3], bl[2], bh[2][2];
+    int s = 0;   // slab being consumed
+#pragma unroll
+    for (int m = 0; m < 3; ++m) al[m] = *reinterpret_cast<const half8 *>(Ws + a_base + WN_PART_HALFS + m * 256);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+
+    const float unscale = whdr[0] * x_unscale;
+    const int co0 = cot * WN_COT;
+
+    for (int tj = j_first; tj < ntiles; tj += (int)gridDim.x) {
+        const int en = n, ed0 = d0, eh0 = h0, ew0 = w0, etile = tj;   // this tile (the staging variables move on during its last chunk)
+        const bool has_next = tj + (int)gridDim.x < ntiles;
+        f32x16 acc[3][2];
+#pragma unroll
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            const bool do_load = more || has_next;   // a halo prefetch is issued in this chunk's interval 2 (uniform)
+            const int load_chunk = more ? c + 1 : 0;
+            if (!more && has_next) {
+                decode_tile(tj + (int)gridDim.x);   // staging now addresses the next tile
+                // (the affine table was last read by the WRITE_X that ended the previous chunk, a barrier ago)
+                if (fuse_in && n != aff_n) load_aff();
+            }
+            // One interval = one (kd,kh) slab: 18 MFMAs per wave (P1 = Wlo*Xhi, P2 = Whi*Xhi, P3 = Whi*Xlo).
+            //   top      : DMA of slab s+3 into the slot slab s-1 left (every wave is past barrier s-1); interval 2 first issues the
+            //              halo prefetch of the next chunk
+            //   fragments: Whi(s), Xlo now; Wlo(s+1) and Xhi(next tap) after P1 — slab s+1 was published by barrier s-1
+            //   bottom   : wait for THIS wave's pieces of slab s+2 (issued one interval ago; younger transfers stay in flight),
+            //              barrier s: slab s+2 published, slot of slab s free
+#define WN_TOFF(G) ((((G) / 3) * WN_HH + (G) % 3) * 32)
+#define WN_INTERVAL(G)                                                                                                     \
+    {                                                                                                                      \
+        constexpr int cur_ = (G) & 1;                                                                                      \
+        if ((G) == 2 && do_load) { WN_LOAD_X(load_chunk); }   /* (before the DMA: hipcc's own vmcnt(k) waits on the   */ \
+        const int issued_ = dma_issue();                       /*  registers it reloads then only cover landed pieces) */ \
+        const _Float16 *wsb_ = Ws + (s & (WN_RING - 1)) * WN_SLAB_HALFS + a_base;                                          \
+        const _Float16 *wsn_ = Ws + ((s + 1) & (WN_RING - 1)) * WN_SLAB_HALFS + a_base + WN_PART_HALFS;                    \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m) ah[m] = *reinterpret_cast<const half8 *>(wsb_ + m * 256);            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                      \
+            bl[t] = *reinterpret_cast<const half8 *>(Xs + WN_XPART + b_base[t] + WN_TOFF(G));                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[cur_][t], acc[m][t], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if (s + 1 < s_total) {                                                                                             \
+            _Pragma("unroll") for (int m = 0; m < 3; ++m) al[m] = *reinterpret_cast<const half8 *>(wsn_ + m * 256);        \
+        }                                                                                                                  \
+        if ((G) < 8) {                                                                                                     \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                bh[cur_ ^ 1][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t] + WN_TOFF(((G) < 8 ? (G) + 1 : 0)));     \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[cur_][t], acc[m][t], 0, 0, 0);                \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        /* younger than this wave's pieces of slab s+2: interval 2's halo prefetch (8) and this interval's pieces (3) */   \
+        if ((G) == 2 && do_load) {                                                                                         \
+            if (issued_) lds_dma_wait<WN_XLOADS + 3>(); else lds_dma_wait<WN_XLOADS>();                                    \
+        } else {                                                                                                           \
+            if (issued_) lds_dma_wait<3>(); else lds_dma_wait<0>();                                                        \
+        }                                                                                                                  \
+        lds_barrier();                                                                                                     \
+        ++s;                                                                                                               \
+    }
+            WN_INTERVAL(0)
+            WN_INTERVAL(1)
+            WN_INTERVAL(2)
+            WN_INTERVAL(3)
+            WN_INTERVAL(4)
+            WN_INTERVAL(5)
+            WN_INTERVAL(6)
+            WN_INTERVAL(7)
+            WN_INTERVAL(8)
+#undef WN_INTERVAL
+            if (more) {
+                WN_WRITE_X(c + 1);   // every wave is past its last read of the X tile (barrier above)
+                lds_barrier();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+            }
+        }
+
+        // ---- output transform + epilogue: three rounds (one 32-channel row tile each) through the dead X region ---------------------
+        const int gn_rows = tiles_total * 2;   // channel-major [Co][tile * 2 + ch][2] (the finalize kernel reads rows of it)
+        if (gn_part && etile == 0 && tid == 0) gn_part[(size_t)gn_rows * Co * 2] = unscale;   // (behind the partials)
+        float *const dsto = y + (size_t)en * Co * DHW + (size_t)(ed0 + 2 * ch) * HW + (size_t)(eh0 + (j >> 2)) * W + ew0 + 2 * (j & 3);
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of both column tiles; wave p keeps unit p
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u != p) {
+                        const int slot = t * 3 + (u - (u > p ? 1 : 0));
+                        const f32x4 v = {acc[m][t][4 * u], acc[m][t][4 * u + 1], acc[m][t][4 * u + 2], acc[m][t][4 * u + 3]};
+                        *reinterpret_cast<f32x4 *>(Ex + ((wave * 6 + slot) * 64 + lane) * 4) = v;
+                    }
+            lds_barrier();
+            float ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            float bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[co0 + m * 32 + 8 * p + 4 * kgl + i] : 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                f32x4 M[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q != p) {
+                        const int slot = t * 3 + (p - (p > q ? 1 : 0));
+                        M[q] = *reinterpret_cast<const f32x4 *>(Ex + (((ch * 4 + q) * 6 + slot) * 64 + lane) * 4);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) M[q][i] = acc[m][t][4 * q + i];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float y0 = (M[0][i] + M[1][i]) + M[2][i];
+                    const float y1 = (M[1][i] - M[2][i]) - M[3][i];
+                    ssum[i] += y0 + y1;
+                    qsum[i] = __builtin_fmaf(y0, y0, qsum[i]);
+                    qsum[i] = __builtin_fmaf(y1, y1, qsum[i]);
+                    const int co = co0 + m * 32 + 8 * p + 4 * kgl + i;
+                    *reinterpret_cast<float2 *>(dsto + (size_t)co * DHW + (size_t)t * HW) = make_float2(y0 * unscale + bv[i], y1 * unscale + bv[i]);
+                }
+            }
+            if (gn_part) {
+                // per-channel (sum, sum of squares) of the RAW transformed accumulators over this wave's 2 x 64 voxels of the channel:
+                // the 32 lanes of a half-wave hold one channel's columns (the finalize kernel applies unscale and the bias in double)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+#define WN_ROW_ADD(v_, ctrl_) v_ += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), ctrl_, 0xf, 0xf, false));
+                    WN_ROW_ADD(ssum[i], 0x128) WN_ROW_ADD(qsum[i], 0x128)   // row_ror:8, :4, :2, :1 -> every lane of a 16-lane row: the row's sum
+                    WN_ROW_ADD(ssum[i], 0x124) WN_ROW_ADD(qsum[i], 0x124)
+                    WN_ROW_ADD(ssum[i], 0x122) WN_ROW_ADD(qsum[i], 0x122)
+                    WN_ROW_ADD(ssum[i], 0x121) WN_ROW_ADD(qsum[i], 0x121)
+#undef WN_ROW_ADD
+                    ssum[i] += __shfl_xor(ssum[i], 16, 64);
+                    qsum[i] += __shfl_xor(qsum[i], 16, 64);
+                }
+                if (j == 0) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int co = co0 + m * 32 + 8 * p + 4 * kgl + i;
+                        *reinterpret_cast<float2 *>(gn_part + ((size_t)co * gn_rows + (size_t)etile * 2 + ch) * 2) = make_float2(ssum[i], qsum[i]);
+                    }
+                }
+            }
+            lds_barrier();   // the region is rewritten by the next round / the next tile's halo
+        }
+
+        if (has_next) {
+            WN_WRITE_X(0);   // the next tile's first halo chunk (prefetched during this tile's last chunk)
+            lds_barrier();
+#pragma unroll
+            for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+        }
+    }
+#undef WN_LOAD_X
+#undef WN_WRITE_X
+#undef WN_TOFF
+    if (__builtin_amdgcn_ballot_w64(sat_ != 0) != 0) {  // never taken in normal operation
+        unsigned tot = sat_;
+#pragma unroll
+        for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft, 64);
+        if (lane == 0) atomicAdd(&g_f16x3_wino_saturated, (unsigned long long)tot);
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------
+int f16x3_wino_saturation(unsigned long long *count, int reset) {   // (mphip_f16x3_saturation_count adds it to the direct kernels' counter)
+    if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_f16x3_wino_saturated), sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        const unsigned long long z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16x3_wino_saturated), &z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+
+static bool wino_enabled() {   // dev: same-box A/B against the direct kernel (read per call: tests flip it in-process; packs always carry the slabs)
+    const char *e = getenv("MPHIP_WINOGRAD");
+    return !(e && e[0] == '0');
+}
+
+// layers that can ever take the transformed-domain kernel get its slabs behind the direct pack (a weight tensor does not know the
+// volume it will meet): Ci <= 256 covers G3d's levels 0-1 and Eapp's 3-D tail, +133 % pack bytes on <= 4 MB tensors
+size_t f16x3_wino_packed_bytes(int Co, int Ci) {
+    if (Ci % WN_KC || Co % WN_COT || Ci > WN_AFF_CI) return 0;
+    return (size_t)(Co / WN_COT) * (Ci / WN_KC) * WN_NG * WN_SLAB_HALFS * sizeof(_Float16);
+}
+
+bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W) {
+    if (!wino_enabled() || f16x3_wino_packed_bytes(Co, Ci) == 0 || D % WN_TD || H % WN_TH || W % WN_TW) return false;
+    // one workgroup per CU: worth it only when the launch fills the chip (small launches are latency-, not energy-bound)
+    const long tiles = (long)N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW);
+    const char *min_s = getenv("MPHIP_WINOGRAD_MIN_TILES");   // dev: threshold sweep
+    const long min_tiles = min_s ? atol(min_s) : 256;
+    return tiles * (Co / WN_COT) >= min_tiles;
+}
+
+void f16x3_wino_pack(const float *w, void *slabs, const void *hdr, int Co, int Ci, int transposed, hipStream_t s) {
+    const size_t total = (size_t)(Co / WN_COT) * (Ci / WN_KC) * WN_NG * 4 * 2 * WN_COT;
+    hipLaunchKernelGGL(f16x3_wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (_Float16 *)slabs,
+                       (const unsigned *)hdr, Co, Ci, transposed);
+}
+
+int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
+                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, float *gn_part, hipEvent_t t0,
+                      hipEvent_t t1) {
+    const int tiles = N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW), cots = Co / WN_COT;
+    long gx = (256L + cots - 1) / cots;   // persistent: one workgroup per CU
+    if (gx > tiles) gx = tiles;
+    const dim3 grid((unsigned)gx, (unsigned)cots, 1);
+    const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
+    static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');
+    if (t0 && t1)
+        hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, t0, t1, 0, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci,
+                              Co, D, H, W, xb, in_affine, in_relu, x_range, tiles, xcd_on, gn_part);
+    else
+        hipLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W,
+                           xb, in_affine, in_relu, x_range, tiles, xcd_on, gn_part);
+    return check_launch("conv3d_fwd(f16x3, F(2,3))");
+}
+
+}  // namespace mphip

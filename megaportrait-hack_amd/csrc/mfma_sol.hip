@@ -1,0 +1,97 @@
+// Measurement only: what rate of the f16x3 convs' MFMA stream does the part SUSTAIN?  (VERDICT r3 #1a)
+//
+// The conv kernels are priced against the 2.5 PFLOP/s dense f16 peak, which assumes 2.4 GHz; under this instruction mix the package
+// sits at its power limit and clocks lower.  This kernel issues the conv's inner stream and nothing else:
+// v_mfma_f32_32x32x16_f16 in the three-products-per-tap order (Wlo*Xhi, Whi*Xhi, Whi*Xlo), 3 x 2 accumulator tiles per wave, eight
+// waves per workgroup (two per SIMD), one workgroup per CU, on REAL hi/lo fragments (random values split like the conv's operands:
+// multiplying zeros draws less power and clocks higher, MI355X_MICROARCH.md "DVFS give-back").  mode 1 also reads its ten 16-byte
+// fragments per tap from LDS the way the conv does (same reads per MFMA); mode 0 keeps them in registers.  No global traffic, no
+// barriers, no staging: tools/mfma_sol.py / bench.py run it back to back for >= 2 s and report rate, package power and clock —
+// the ceiling a conv kernel with perfect overlap could reach on this arithmetic at the power limit.
+#include "mphip_f16x3.h"
+
+namespace mphip {
+
+__device__ __forceinline__ unsigned sol_hash(unsigned v) {
+    v ^= v >> 16; v *= 0x7feb352du; v ^= v >> 15; v *= 0x846ca68bu; v ^= v >> 16;
+    return v;
+}
+
+template <int LDS_READS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+mfma_sol_kernel(float *__restrict__ sink, int iters) {
+    constexpr int FRAGS = 64;                                  // 64 hi + 64 lo fragment rows of 1 KiB = 128 KiB
+    __shared__ __attribute__((aligned(16))) _Float16 frag[2 * FRAGS * 512];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // operands: uniform in (-2^13, 2^13) scaled fp32 values, split hi/lo exactly like the conv's staging
+    for (int i = tid; i < FRAGS * 512; i += 512) {
+        const unsigned h = sol_hash((unsigned)i * 2654435761u + blockIdx.x * 977u + 12345u);
+        const float v = ((float)(h & 0xffffffu) * (1.0f / 8388608.0f) - 1.0f) * 8192.0f;
+        _Float16 hi, lo;
+        split_f16(v, hi, lo);
+        frag[i] = hi;
+        frag[FRAGS * 512 + i] = lo;
+    }
+    __syncthreads();
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+    const _Float16 *base = frag + lane * 8 + wave * 512;
+    half8 ah[3], al[3], bh[2], bl[2];
+#define SOL_LOAD(k_)                                                                                                   \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m) {                                                                \
+            ah[m] = *reinterpret_cast<const half8 *>(base + (((k_) * 5 + m) & 55) * 512);                              \
+            al[m] = *reinterpret_cast<const half8 *>(base + FRAGS * 512 + (((k_) * 5 + m) & 55) * 512);                \
+        }                                                                                                              \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                \
+            bh[t] = *reinterpret_cast<const half8 *>(base + (((k_) * 5 + 3 + t) & 55) * 512);                          \
+            bl[t] = *reinterpret_cast<const half8 *>(base + FRAGS * 512 + (((k_) * 5 + 3 + t) & 55) * 512);            \
+        }                                                                                                              \
+    }
+    SOL_LOAD(0)
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            if (LDS_READS) SOL_LOAD(k)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[t], acc[m][t], 0, 0, 0);
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
+            if (!LDS_READS) asm volatile("" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));   // (keeps the loop from being folded)
+        }
+    }
+#undef SOL_LOAD
+    float r = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) r += acc[m][t][q];
+    sink[(size_t)blockIdx.x * 512 + tid] = r;
+}
+
+}  // namespace mphip
+
+// sink: >= workgroups * 512 floats.  Issues workgroups * 8 waves * iters * 9 * 18 MFMAs of 32768 FLOP.
+extern "C" int mphip_debug_mfma_sol(float *sink, int workgroups, int iters, int mode, void *stream) {
+    MPHIP_REQUIRE(sink && workgroups > 0 && iters > 0, "mfma_sol: bad arguments");
+    if (mode)
+        hipLaunchKernelGGL(mphip::mfma_sol_kernel<1>, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, sink, iters);
+    else
+        hipLaunchKernelGGL(mphip::mfma_sol_kernel<0>, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, sink, iters);
+    return mphip::check_launch("mfma_sol");
+}

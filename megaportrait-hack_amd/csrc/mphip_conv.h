@@ -38,6 +38,17 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]);
 int f16x3_tile_waves(const F16x3Plan &p);
 
+// conv3d_f16x3_wino.hip: the same split-f16 arithmetic in the 1-D Winograd F(2,3) domain (2/3 of the MFMAs).  Its slabs live
+// behind the direct slabs of a precision-1 k=3 pack (0 bytes when the layer can never take the kernel); F16x3Plan.variant 4.
+size_t f16x3_wino_packed_bytes(int Co, int Ci);
+bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W);
+void f16x3_wino_pack(const float *w_oidhw, void *slabs, const void *hdr /* the direct pack's 16-byte header (max|w|) */, int Co, int Ci,
+                     int transposed, hipStream_t s);
+int f16x3_wino_saturation(unsigned long long *count, int reset);
+int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
+                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, float *gn_part, hipEvent_t t0,
+                      hipEvent_t t1);
+
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)
 bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
