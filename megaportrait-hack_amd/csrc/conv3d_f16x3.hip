@@ -951,7 +951,8 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     // (2x8x8 tiles on 4 waves for these launches: measured the same 0.092 ms as 4x8x8, r03)
     if (roi && p.td == 4 && !force) p.variant = 0;
     // variant 4: the 1-D Winograd F(2,3) kernel (conv3d_f16x3_wino.hip; (4,8,8) tile, 2/3 of the MFMAs) on launches that fill the chip
-    if (!roi && !force && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
+    // (demand-driven launches follow the full launch's choice, so that the tiles they compute carry the same bits)
+    if (!force && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
     const long tiles = (p.variant == 1 || p.variant == 3) ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup (each split adds a slab write + a reduce pass): the largest
@@ -1041,14 +1042,6 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     const float *hdr = (const float *)wpacked;
     const _Float16 *slabs = (const _Float16 *)((const char *)wpacked + 16);
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
-    if (p.variant == 4) {
-        if (in_affine && Ci > 256) {
-            set_error("conv3d_fwd(f16x3, F(2,3)): fused input GroupNorm supports Ci <= 256 (got %d)", Ci);
-            return MPHIP_EINVAL;
-        }
-        return f16x3_wino_launch(x, (const char *)wpacked + f16x3_direct_bytes(Co, Ci), hdr, bias, dst, N, Ci, Co, D, H, W, in_affine,
-                                 in_relu, x_scale, s, gn_part, t0, t1);
-    }
     if (roi) {   // demand-driven: boxes -> the list of tiles they touch (1 + tiles ints of caller workspace); the kernel gets the LIST
         int dims[3];
         f16x3_tile_dims(p, dims);
@@ -1057,6 +1050,14 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
         hipLaunchKernelGGL(roi_tile_list_kernel, dim3(1), dim3(1024), 0, s, roi, roi_frames, (int)p.grid.x, D, H, W, dims[0], dims[1], dims[2],
                            roi_dilate, tile_list);
         roi = tile_list;
+    }
+    if (p.variant == 4) {   // the 1-D Winograd F(2,3) kernel (full launches and demand-driven ones alike: a listed tile carries the full launch's bits)
+        if (in_affine && Ci > 256) {
+            set_error("conv3d_fwd(f16x3, F(2,3)): fused input GroupNorm supports Ci <= 256 (got %d)", Ci);
+            return MPHIP_EINVAL;
+        }
+        return f16x3_wino_launch(x, (const char *)wpacked + f16x3_direct_bytes(Co, Ci), hdr, bias, dst, N, Ci, Co, D, H, W, in_affine,
+                                 in_relu, x_scale, s, roi, gn_part, t0, t1);
     }
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles

@@ -99,11 +99,25 @@ f16x3_wino_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, 
 
 __device__ unsigned long long g_f16x3_wino_saturated;
 
+#ifdef MPHIP_PROFILE_PHASES
+// dev instrumentation (itself intrusive, ~+10 % wave cycles): shader cycles per phase, summed over all waves:
+// [0] prologue  [1] interval: DMA issue + fragment reads + MFMA issue  [2] interval: wait for this wave's DMA pieces  [3] interval: barrier
+// [4] halo write (transform + split + LDS stores)  [5] its barrier + first fragment reload  [6] output transform + epilogue  [7] waves
+__device__ unsigned long long g_f16x3_wino_prof[8];
+#define WPROF_DECL unsigned long long pt_ = __builtin_readcyclecounter(), pa_[7] = {0, 0, 0, 0, 0, 0, 0}
+#define WPROF_ADD(slot) { const unsigned long long n_ = __builtin_readcyclecounter(); pa_[slot] += n_ - pt_; pt_ = n_; }
+#define WPROF_FLUSH if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_f16x3_wino_prof[q_], pa_[q_]); atomicAdd(&g_f16x3_wino_prof[7], 1ull); }
+#else
+#define WPROF_DECL
+#define WPROF_ADD(slot)
+#define WPROF_FLUSH
+#endif
+
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                             const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
                             unsigned x_bytes, const float *__restrict__ in_affine, int in_relu, const float *__restrict__ x_range,
-                            int tiles_total, int xcd_aware, float *__restrict__ gn_part) {
+                            int tiles_total, int xcd_aware, const int *__restrict__ tile_list, float *__restrict__ gn_part) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[WN_RING * WN_SLAB_HALFS + WN_X_HALFS + WN_AFF_CI * 4];
     _Float16 *const Ws = smem;                                   // ring of 4 slabs
     _Float16 *const Xs = smem + WN_RING * WN_SLAB_HALFS;         // [part][position][kg][row*4 + pair][8]
@@ -116,8 +130,11 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     const int p = wave & 3, ch = wave >> 2;                      // Winograd position, plane pair
     const int j = lane & 31, kgl = lane >> 5;
     const int HW = H * W, DHW = D * HW;
-    const int ntiles = tiles_total;
-    const int j_first = xcd_aware ? (int)xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    // Demand-driven evaluation (tile_list = {count, id, id, ...}, roi_tile_list_kernel): only the listed output tiles are computed, dealt
+    // round-robin over the persistent workgroups — same arithmetic per tile, so a listed tile carries the full launch's bits.
+    const int ntiles = tile_list ? tile_list[0] : tiles_total;
+    auto tile_at = [&](int jj) -> int { return tile_list ? tile_list[1 + jj] : jj; };
+    const int j_first = (tile_list || !xcd_aware) ? (int)blockIdx.x : (int)xcd_remap(blockIdx.x, gridDim.x);
     if (j_first >= ntiles) return;   // (workgroup-uniform, before any barrier)
     float x_scale = 16.0f, x_unscale = 1.0f / 16.0f;
     if (x_range) range_scale_block(x_range, x_scale, x_unscale);
@@ -132,7 +149,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         n = bid / tiles_d;
         d0 = td * WN_TD; h0 = th * WN_TH; w0 = tw * WN_TW;
     };
-    decode_tile(j_first);
+    decode_tile(tile_at(j_first));
     const int cot = blockIdx.y;
     const int nchunks = Ci / WN_KC;
     const int nmine = (ntiles - j_first + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles this workgroup walks
@@ -239,6 +256,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         aff_n = n;
     };
 
+    WPROF_DECL;
     // ---- prologue: slabs 0..2 in flight, X(chunk 0) staged ---------------------------------------------------------------------
     if (fuse_in) {
         load_aff();
@@ -261,9 +279,10 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 
     const float unscale = whdr[0] * x_unscale;
     const int co0 = cot * WN_COT;
+    WPROF_ADD(0)
 
     for (int tj = j_first; tj < ntiles; tj += (int)gridDim.x) {
-        const int en = n, ed0 = d0, eh0 = h0, ew0 = w0, etile = tj;   // this tile (the staging variables move on during its last chunk)
+        const int en = n, ed0 = d0, eh0 = h0, ew0 = w0, etile = tile_at(tj);   // this tile (the staging variables move on during its last chunk)
         const bool has_next = tj + (int)gridDim.x < ntiles;
         f32x16 acc[3][2];
 #pragma unroll
@@ -278,7 +297,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             const bool do_load = more || has_next;   // a halo prefetch is issued in this chunk's interval 2 (uniform)
             const int load_chunk = more ? c + 1 : 0;
             if (!more && has_next) {
-                decode_tile(tj + (int)gridDim.x);   // staging now addresses the next tile
+                decode_tile(tile_at(tj + (int)gridDim.x));   // staging now addresses the next tile
                 // (the affine table was last read by the WRITE_X that ended the previous chunk, a barrier ago)
                 if (fuse_in && n != aff_n) load_aff();
             }
@@ -319,13 +338,16 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
                 acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);                      \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        WPROF_ADD(1)                                                                                                       \
         /* younger than this wave's pieces of slab s+2: interval 2's halo prefetch (8) and this interval's pieces (3) */   \
         if ((G) == 2 && do_load) {                                                                                         \
             if (issued_) lds_dma_wait<WN_XLOADS + 3>(); else lds_dma_wait<WN_XLOADS>();                                    \
         } else {                                                                                                           \
             if (issued_) lds_dma_wait<3>(); else lds_dma_wait<0>();                                                        \
         }                                                                                                                  \
+        WPROF_ADD(2)                                                                                                       \
         lds_barrier();                                                                                                     \
+        WPROF_ADD(3)                                                                                                       \
         ++s;                                                                                                               \
     }
             WN_INTERVAL(0)
@@ -340,9 +362,11 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #undef WN_INTERVAL
             if (more) {
                 WN_WRITE_X(c + 1);   // every wave is past its last read of the X tile (barrier above)
+                WPROF_ADD(4)
                 lds_barrier();
 #pragma unroll
                 for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+                WPROF_ADD(5)
             }
         }
 
@@ -416,11 +440,14 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             lds_barrier();   // the region is rewritten by the next round / the next tile's halo
         }
 
+        WPROF_ADD(6)
         if (has_next) {
             WN_WRITE_X(0);   // the next tile's first halo chunk (prefetched during this tile's last chunk)
+            WPROF_ADD(4)
             lds_barrier();
 #pragma unroll
             for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+            WPROF_ADD(5)
         }
     }
 #undef WN_LOAD_X
@@ -432,6 +459,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft, 64);
         if (lane == 0) atomicAdd(&g_f16x3_wino_saturated, (unsigned long long)tot);
     }
+    WPROF_FLUSH
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -452,6 +480,8 @@ static bool wino_enabled() {   // dev: same-box A/B against the direct kernel (r
 // layers that can ever take the transformed-domain kernel get its slabs behind the direct pack (a weight tensor does not know the
 // volume it will meet): Ci <= 256 covers G3d's levels 0-1 and Eapp's 3-D tail, +133 % pack bytes on <= 4 MB tensors
 size_t f16x3_wino_packed_bytes(int Co, int Ci) {
+    static const bool nopack = getenv("MPHIP_WINOGRAD_PACK") && getenv("MPHIP_WINOGRAD_PACK")[0] == '0';   // dev: bisecting (process-wide: set before the first pack)
+    if (nopack) return 0;
     if (Ci % WN_KC || Co % WN_COT || Ci > WN_AFF_CI) return 0;
     return (size_t)(Co / WN_COT) * (Ci / WN_KC) * WN_NG * WN_SLAB_HALFS * sizeof(_Float16);
 }
@@ -472,8 +502,8 @@ void f16x3_wino_pack(const float *w, void *slabs, const void *hdr, int Co, int C
 }
 
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
-                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, float *gn_part, hipEvent_t t0,
-                      hipEvent_t t1) {
+                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, const int *tile_list,
+                      float *gn_part, hipEvent_t t0, hipEvent_t t1) {
     const int tiles = N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW), cots = Co / WN_COT;
     long gx = (256L + cots - 1) / cots;   // persistent: one workgroup per CU
     if (gx > tiles) gx = tiles;
@@ -482,11 +512,22 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');
     if (t0 && t1)
         hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, t0, t1, 0, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci,
-                              Co, D, H, W, xb, in_affine, in_relu, x_range, tiles, xcd_on, gn_part);
+                              Co, D, H, W, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
     else
         hipLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W,
-                           xb, in_affine, in_relu, x_range, tiles, xcd_on, gn_part);
+                           xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
     return check_launch("conv3d_fwd(f16x3, F(2,3))");
 }
 
 }  // namespace mphip
+
+#ifdef MPHIP_PROFILE_PHASES
+extern "C" int mphip_debug_f16x3_wino_profile(unsigned long long *out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(mphip::g_f16x3_wino_prof), 64) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(mphip::g_f16x3_wino_prof), z, 64) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif

@@ -57,7 +57,10 @@ mfma_sol_kernel(float *__restrict__ sink, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int k = 0; k < 9; ++k) {
-            if (LDS_READS) SOL_LOAD(k)
+            if (LDS_READS) {
+                SOL_LOAD(k)
+                __builtin_amdgcn_sched_barrier(0);   // (one tap's fragments at a time: hoisting all nine taps' loads spills)
+            }
 #pragma unroll
             for (int m = 0; m < 3; ++m)
 #pragma unroll
@@ -71,6 +74,7 @@ mfma_sol_kernel(float *__restrict__ sink, int iters) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
             if (!LDS_READS) asm volatile("" : "+v"(ah[0]), "+v"(al[0]), "+v"(bh[0]), "+v"(bl[0]));   // (keeps the loop from being folded)
+            else __builtin_amdgcn_sched_barrier(0);
         }
     }
 #undef SOL_LOAD

@@ -46,8 +46,8 @@ void f16x3_wino_pack(const float *w_oidhw, void *slabs, const void *hdr /* the d
                      int transposed, hipStream_t s);
 int f16x3_wino_saturation(unsigned long long *count, int reset);
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
-                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, float *gn_part, hipEvent_t t0,
-                      hipEvent_t t1);
+                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s,
+                      const int *tile_list /* demand-driven: {count, tile ids} or NULL */, float *gn_part, hipEvent_t t0, hipEvent_t t1);
 
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)

@@ -292,7 +292,7 @@ def test_rt_theta_backward(dev, invert):
 
 
 def _check_param_grads(named_params, ref_grad, tol):
-    """Every parameter's gradient within `tol` of its own max-abs.  A conv bias feeding a GroupNorm whose groups hold
+    """Every parameter's gradient within `tol` (a number, or name -> number) of its own max-abs.  A conv bias feeding a GroupNorm whose groups hold
     one channel each (FlowField's 32-channel block, model.py:374-383) has an exactly zero true gradient — the norm
     removes a per-channel shift — so both sides are rounding noise of sum(dy); a bias is therefore measured on the
     scale of max(own gradient, 1 % of its layer's weight gradient), which that noise is proportional to."""
@@ -307,7 +307,7 @@ def _check_param_grads(named_params, ref_grad, tol):
         if sib is not None:
             scale = max(scale, 1e-2 * sib.abs().max().item())
         err = (p.grad.detach().cpu().double() - g.double()).abs().max().item() / scale
-        if err >= tol:
+        if err >= (tol(n) if callable(tol) else tol):
             bad.append((err, n, g.abs().max().item()))
     assert not bad, sorted(bad, reverse=True)[:6]
 
@@ -418,29 +418,47 @@ def test_config3_train_step_full_size(dev, M):
     """BASELINE config 3's per-GPU shard at its own size: B=4 frames of the 512^2 volume (96x16x64x64) through the
     whole hot slice under autograd — the full-resolution bwd-weight split/slab-reduce plan, warp_volume_bwd at
     16x64x64 and the batch-4 paths.  Loss gradient wrt EVERY input (vs, es, Rs, ts, zs, Rd, td, zd) and EVERY
-    parameter vs CPU autograd of oracle/hotpath_ref.py (the reference's module graph) evaluated in FLOAT64, bar 2e-3
-    of each gradient's max-abs (the end-to-end bar of the smaller cases).  Float64 because at this size the fp32 CPU
-    oracle is itself off by up to 5.9e-3 (G3d.downsampling.4.conv1.weight: oneDNN's fp32 weight-gradient
-    accumulation over 4x4096 voxels; tools/grad_truth.py on the GPU box: HIP 1.6e-6 vs fp32-CPU 5.9e-3 against the
-    fp64 truth for that tensor, HIP worst case 5.4e-4 overall) — an fp32 CPU comparison would grade the checker."""
+    parameter vs CPU autograd of oracle/hotpath_ref.py (the reference's module graph) evaluated in FLOAT64.
+    Bar: 2e-3 of each gradient's max-abs (the end-to-end bar of the smaller cases) + twice the TRUTH'S OWN movement
+    under an fp32-rounding-sized perturbation of the input.  The gradient of a ReLU network is discontinuous where
+    a pre-activation crosses zero; at this size a handful of activations of G3d's 4x16x16 level sit within 1e-6 of
+    zero, and the fp64 oracle's gradient of G3d.downsampling.4.conv1.weight moves by 5.9e-3 (gn1.bias 3.6e-3,
+    conv1.bias 3.2e-3) when `vs` is perturbed by 1e-6 relative noise — the SAME three numbers the fp32 CPU oracle
+    and the F(2,3) conv kernels show against the unperturbed fp64 truth (tools/dbg_wino_bwd.py, profiles/
+    r04_gradient_sensitivity.txt; r02 read the fp32 CPU oracle's 5.9e-3 as oneDNN accumulation error and r02-r03's
+    direct kernels happened to round that activation the truth's way).  Every other tensor's movement is < 1e-3
+    and its bar stays near 2e-3; a wrong kernel shows up at >= 1e-1."""
     sd = R.seeded_gbase_hot_state_dict(7)
     hot = M.GbaseHotSlice()
     M.load_hot_state_dict(hot, sd)
     hot = hot.to(dev).train()
     inp = R.seeded_hot_inputs(4, 47)
-    cpu_in = {k: v.double().requires_grad_(True) for k, v in inp.items()}
-    cpu_sd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
-    out_ref = R.hot_slice(sd=cpu_sd, **cpu_in)
+
+    def truth(vs_noise):
+        gen = torch.Generator().manual_seed(3)
+        t_in = {k: v.double() for k, v in inp.items()}
+        if vs_noise:
+            t_in["vs"] = t_in["vs"] * (1 + vs_noise * torch.randn(t_in["vs"].shape, generator=gen, dtype=torch.float64))
+        t_in = {k: v.requires_grad_(True) for k, v in t_in.items()}
+        t_sd = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        o = R.hot_slice(sd=t_sd, **t_in)
+        o.backward(R.seeded_tensor(tuple(o.shape), 93).double())
+        return o.detach(), t_in, t_sd
+
+    out_ref, cpu_in, cpu_sd = truth(0.0)
+    _, mov_in, mov_sd = truth(2e-6)   # (the HIP forward is 1-2e-6 relative from the fp64 forward)
     dout = R.seeded_tensor(tuple(out_ref.shape), 93)
-    out_ref.backward(dout.double())
     gpu_in = {k: v.clone().to(dev).requires_grad_(True) for k, v in inp.items()}
     out = hot(**gpu_in)                                   # the reference's 512^2-only entry (model.py:1157 assert holds)
     assert out.shape == (4, 96, 64, 64)
-    assert (out.detach().cpu().double() - out_ref.detach()).abs().max().item() < 1e-3
+    assert (out.detach().cpu().double() - out_ref).abs().max().item() < 1e-3
     out.backward(dout.to(dev))
+    moved = lambda a, b: 0.0 if a is None or b is None else (a - b).abs().max().item() / max(b.abs().max().item(), 1e-300)
     for k in inp:
-        assert rel_err(gpu_in[k].grad, cpu_in[k].grad) < 2e-3, k
-    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3)
+        assert rel_err(gpu_in[k].grad, cpu_in[k].grad) < 2e-3 + 2 * moved(mov_in[k].grad, cpu_in[k].grad), k
+    movement = {n: moved(mov_sd[n].grad, cpu_sd[n].grad) for n in cpu_sd}
+    assert sorted(movement.values())[len(movement) // 2] < 1e-4, "the truth's typical movement must stay far below the bar"
+    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, lambda n: 2e-3 + 2 * movement.get(n, 0.0))
 
 
 @pytest.mark.parametrize("precision", [1, 0])
