@@ -11,7 +11,9 @@ run N independent shards (weak scaling, no data-path collective); rank 0 prints 
 Extra objects on the line:
   roofline     — the dominant kernel (conv3d 3x3x3 96->96 @16x64x64, 60 % of hot-slice FLOPs):
                  algorithmic FLOPs per launch / its average launch duration, measured live with
-                 HIP events on the launch stream during the timed steps, vs the dense fp32-MFMA peak.
+                 HIP events on the launch stream during the timed steps, vs the dense f16-MFMA peak,
+                 and `sustained_peak`: the same MFMA stream alone, >= 2 s back to back, with package
+                 power and clock (what the part sustains on this arithmetic at its power limit).
   cpu_baseline — the CPU oracle (oracle/hotpath_ref.py, ATen CPU ops = what the reference runs on a
                  CPU host) timed on this host on a bounded sample, rank 0, N=1 only.
 """
@@ -82,6 +84,7 @@ def parse():
     ap.add_argument("--per-op", action="store_true", help="drive the step through the per-op Python schedule instead of the C-side plan")
     ap.add_argument("--full-final-conv", action="store_true",
                     help="evaluate G3d's last upsample + conv on every voxel (default: demand-driven, only what the final warp reads)")
+    ap.add_argument("--repeats", type=int, default=5, help="extra K-step blocks timed after the graded one (their ms/step: `repeats` on the line)")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the side measurements on the line (fp32_exact, roofline_hbm, end_to_end)")
     return ap.parse_args()
@@ -172,17 +175,51 @@ class DominantKernelTimer:
         return sum(a.elapsed_time(b) for a, b in self.events) / max(1, len(self.events))
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/), or None."""
+def _sha256(path):
+    import hashlib
+
+    with open(path, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def pmc_record(name, sources):
+    """A committed rocprofv3 --pmc summary (profiles/<name>) — used ONLY when it is stamped with the sha256 of the kernel sources it
+    measured and those are the sources of this build (tools/collect_profiles.sh stamps them); otherwise (None, True): the line then
+    says `"traffic": null, "stale": true` instead of quoting counters of a kernel that has changed since."""
+    path = os.path.join(ROOT, "profiles", name)
     try:
-        name = "r03_pmc_conv.json" if os.path.isfile(os.path.join(ROOT, "profiles", "r03_pmc_conv.json")) else "r02_pmc_conv.json"
-        with open(os.path.join(ROOT, "profiles", name)) as f:
+        with open(path) as f:
             rec = json.load(f)
-        if rec["kernel"].startswith(kernel_prefix):
-            return rec["derived"]["traffic_bytes_per_launch"]
     except Exception:
-        pass
-    return None
+        return None, True
+    stamped = rec.get("_sources") or {}
+    for src in sources:
+        if stamped.get(src) != _sha256(os.path.join(ROOT, "megaportrait-hack_amd", "csrc", src)):
+            return None, True
+    return rec, False
+
+
+def pmc_traffic(wino):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes, or (None, stale)."""
+    rec, stale = pmc_record("r04_pmc_conv.json", ["conv3d_f16x3_wino.hip" if wino else "conv3d_f16x3.hip", "mphip_f16x3.h"])
+    if rec is None:
+        return None, stale
+    try:
+        return rec["derived"]["traffic_bytes_per_launch"], False
+    except Exception:
+        return None, True
+
+
+def sustained_peak(seconds=2.2):
+    """The f16x3 convs' MFMA stream alone (mphip_debug_mfma_sol, fragments read from LDS like the conv), back to back for `seconds`:
+    issued TFLOP/s, package power, clock — the ceiling a perfectly overlapped conv kernel could reach on this arithmetic."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mfma_sol
+
+    r = mfma_sol.measure(seconds, mode=1)
+    return {"tflops_issued": round(r["tflops_issued"], 1), "power_w": r["power_w"], "sclk_mhz": r["sclk_mhz"], "seconds": round(r["seconds"], 2),
+            "what": "v_mfma_f32_32x32x16_f16 in the convs' three-products-per-tap order on random hi/lo fragments read from LDS (10 ds_read_b128 per "
+                    "18 MFMAs), 3 x 2 accumulator tiles per wave, 2 waves per SIMD, every CU, no global traffic, no barriers (csrc/mfma_sol.hip)"}
 
 
 def torch_rocm_baseline(dev, B, steps=5):
@@ -220,26 +257,36 @@ def torch_rocm_baseline(dev, B, steps=5):
 
 
 def cpu_baseline(frames):
-    """Times the CPU oracle on this host: B=1 frames through oracle.hotpath_ref.hot_slice."""
+    """Times the CPU oracle on this host: B=1 frames through oracle.hotpath_ref.hot_slice, at the ATen thread count that is fastest
+    on this host among {8, 16, 32, 64, all} (every core of a many-core host oversubscribes a B=1 problem)."""
     from oracle import hotpath_ref as R
 
     torch.manual_seed(20240501)
     sd = R.seeded_gbase_hot_state_dict(7)
     inp = R.seeded_hot_inputs(1, 3)
-    threads = torch.get_num_threads()
+    all_threads = torch.get_num_threads()
+    tried = {}
     with torch.no_grad():
-        t0 = time.perf_counter()
-        R.hot_slice(sd=sd, **inp)                      # warm-up (also sizes the sample)
-        warm = time.perf_counter() - t0
+        R.hot_slice(sd=sd, **inp)                      # warm-up (allocator, oneDNN primitives)
+        for n in sorted({n for n in (8, 16, 32, 64, all_threads) if n <= all_threads}):
+            torch.set_num_threads(n)
+            R.hot_slice(sd=sd, **inp)
+            t0 = time.perf_counter()
+            R.hot_slice(sd=sd, **inp)
+            tried[n] = 1.0 / (time.perf_counter() - t0)
+        threads = max(tried, key=tried.get)
+        torch.set_num_threads(threads)
         if frames <= 0:
-            frames = max(2, min(40, int(15.0 / max(warm, 1e-3))))
+            frames = max(2, min(40, int(12.0 * tried[threads])))
         t0 = time.perf_counter()
         for _ in range(frames):
             R.hot_slice(sd=sd, **inp)
         dt = time.perf_counter() - t0
+        torch.set_num_threads(all_threads)
     return {"value": frames / dt, "unit": "frames/s", "cores": threads, "kind": "port",
+            "threads_tried_frames_per_s": {str(k): round(v, 2) for k, v in tried.items()},
             "sample": f"{frames} frames (B=1, 96x16x64x64) through oracle/hotpath_ref.py hot_slice "
-                      f"(ATen CPU fp32, {threads} threads), {dt:.1f} s"}
+                      f"(ATen CPU fp32, {threads} threads = the fastest of {sorted(tried)} on this host), {dt:.1f} s"}
 
 
 def end_to_end(dev, B, steps=8, warmup=3, fp16=False, channels_last=False):
@@ -574,6 +621,15 @@ def main():
         Rs=(torch.rand(B, 3, generator=g) * 60 - 30), Rd=(torch.rand(B, 3, generator=g) * 60 - 30),
         ts=torch.randn(B, 3, generator=g) * 0.1, td=torch.randn(B, 3, generator=g) * 0.1)
     inp = {k: v.to(dev) for k, v in inp.items()}
+    # the timed steps rotate over distinct input sets (different volumes, codes and head poses: the demand-driven tail's tile list, the
+    # range descriptors and the warps' source boxes are recomputed from the data every step)
+    g2 = torch.Generator(device="cpu").manual_seed(20240601 + rank)
+    inp_b = dict(
+        vs=torch.randn(B, 96, 16, 64, 64, generator=g2) * 1.3, es=torch.randn(B, 512, generator=g2),
+        zs=torch.randn(B, 512, generator=g2), zd=torch.randn(B, 512, generator=g2),
+        Rs=(torch.rand(B, 3, generator=g2) * 60 - 30), Rd=(torch.rand(B, 3, generator=g2) * 60 - 30),
+        ts=torch.randn(B, 3, generator=g2) * 0.1, td=torch.randn(B, 3, generator=g2) * 0.1)
+    inp_sets = [inp, {k: v.to(dev) for k, v in inp_b.items()}]
 
     dom = DominantKernelTimer((96, 96, 16, 64, 64))
     step = hot
@@ -603,6 +659,7 @@ def main():
             dom.active = False
         ops.set_conv_hook(None)
         step = M.GraphedHotSlice(hot, inp)
+        inp_sets = [inp]   # (a replayed graph reads its static input buffers)
     else:
         ops.set_conv_hook(dom)
 
@@ -630,37 +687,57 @@ def main():
         if use_plan:
             plan.profile(True)
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)] if lanes is None else None
-        t0 = time.perf_counter()
-        if lanes is None:
-            marks[0].record()
-            for i in range(args.steps):
-                out = step(**inp)
-                marks[i + 1].record()      # device-side step boundaries (an event record, no sync): the spread of the K steps
-        else:
-            for lane in lanes:
-                lane.wait_stream(torch.cuda.current_stream())
-            for i in range(args.steps):
-                with torch.cuda.stream(lanes[i % len(lanes)]):
-                    out = step(**inp)
-            for lane in lanes:
-                torch.cuda.current_stream().wait_stream(lane)
-        sync_all()
-        dt = time.perf_counter() - t0
+
+        def timed_block(record_marks):
+            """EXACTLY K steps between barrier + synchronize on both sides; returns the wall time."""
+            sync_all()
+            t0_ = time.perf_counter()
+            out_ = None
+            if lanes is None:
+                if record_marks:
+                    marks[0].record()
+                for i in range(args.steps):
+                    out_ = step(**inp_sets[i % len(inp_sets)])
+                    if record_marks:
+                        marks[i + 1].record()      # device-side step boundaries (an event record, no sync): the spread of the K steps
+            else:
+                for lane in lanes:
+                    lane.wait_stream(torch.cuda.current_stream())
+                for i in range(args.steps):
+                    with torch.cuda.stream(lanes[i % len(lanes)]):
+                        out_ = step(**inp_sets[(i // len(lanes)) % len(inp_sets)])
+                for lane in lanes:
+                    torch.cuda.current_stream().wait_stream(lane)
+            sync_all()
+            return time.perf_counter() - t0_, out_
+
+        dt, out = timed_block(True)
         dom.active = False
+        prof = None
+        if use_plan:   # (the roofline events come from the K graded steps only: read them before the repeat blocks)
+            prof = (plan.profile_read(0), plan.profile_read(1))
+            plan.profile(False)
+        # the same K-step block a few more times (VERDICT r3 #8): `value` stays the first block, the spread is reported beside it
+        rep_ms = []
+        for _ in range(max(0, args.repeats)):
+            rdt, _o = timed_block(False)
+            rep_ms.append(rdt / args.steps * 1e3)
     assert torch.isfinite(out).all()
 
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if rep_ms:
+            t = torch.tensor(rep_ms, dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            rep_ms = [float(v) for v in t.tolist()]
 
     step_ms = sorted(a.elapsed_time(b) for a, b in zip(marks[:-1], marks[1:])) if marks else []
     dom_ms, dom_launches, demand = dom.mean_ms(), len(dom.events), None
     if use_plan:
-        tot, dom_launches = plan.profile_read(0)
+        (tot, dom_launches), (dtot, dcnt) = prof
         dom_ms = tot / max(1, dom_launches)
-        dtot, dcnt = plan.profile_read(1)
-        plan.profile(False)
         if dcnt:
             demand = {"launch_ms": round(dtot / dcnt, 4), "launches_timed": dcnt,
                       "what": "G3d's last conv (same kernel family, 4x8x8 tiles) evaluated only on the output tiles the final warp reads: "
@@ -671,13 +748,24 @@ def main():
     if rank == 0:
         fps = world * B * args.steps / dt
         achieved = dom_flops / (dom_ms * 1e-3) / 1e12
+        wino = bool(f16x3 and _lib.load().mphip_conv3d_kernel_variant(B, 96, 96, 16, 64, 64, 3, 1) == 5)
+        issued_per_alg = 2.0 if wino else 3.0   # f16 MFMA FLOPs issued per algorithmic FLOP: 3 products, x 2/3 in the F(2,3) domain
         if f16x3:
-            dom_name = ("conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, "
+            dom_name = (("conv3d_k3_f16x3_wino_kernel (Conv3d 3x3x3 96->96 @16x64x64 in the 1-D Winograd F(2,3) domain: 2/3 of the direct "
+                         "kernel's MFMAs, " if wino else "conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, ")
                         + ("2 full launches/step + 1 demand-driven" if demand else "3 launches/step") + ")")
-            peak, dtype = PEAK_F16_MFMA_TFLOPS, "f16x3 (fp32 in/out, operands split into 2 f16 halves, 3 f16 MFMAs per product, fp32 accumulate)"
+            peak, dtype = PEAK_F16_MFMA_TFLOPS, ("f16x3 (fp32 in/out, operands split into 2 f16 halves, 3 f16 MFMAs per product, fp32 accumulate"
+                                                 + ("; 3x3x3 convs that fill the chip run in the F(2,3) Winograd domain along W" if wino else "") + ")")
         else:
             dom_name = "conv3d_k3_tiled_kernel<4,8,8,3,2> (Conv3d 3x3x3 96->96 @16x64x64, 3 launches/step)"
             peak, dtype = PEAK_F32_MFMA_TFLOPS, "f32"
+        traffic, stale = pmc_traffic(wino) if (f16x3 and B == 8) else (None, False)
+        f16_note = lambda ach: (
+            f"algorithmic (fp32-equivalent) FLOPs of the reference's conv; the kernel issues {issued_per_alg:g}x that on the f16 pipe "
+            f"(3 split products{', x 2/3 in the F(2,3) domain' if wino else ''}): {round(issued_per_alg * ach, 1)} TFLOP/s = "
+            f"{round(issued_per_alg * ach / peak, 4)} of the f16 peak; vs the fp32-MFMA peak ({PEAK_F32_MFMA_TFLOPS}) the algorithmic rate is "
+            f"{round(ach / PEAK_F32_MFMA_TFLOPS, 2)}x.  The 2500 TFLOP/s peak assumes 2.4 GHz; on dense f16 MFMAs the part clocks "
+            "~1.65-1.75 GHz at its power limit: `sustained_peak` is the same MFMA stream alone, measured in this run")
         line = {
             "metric": "Gbase fwd hot-slice frames/sec @512^2 (96ch 16x64x64 volume)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -700,26 +788,27 @@ def main():
             "rank0_host_pinning": pinned or None,
             "step_ms": ({"min": round(step_ms[0], 3), "median": round(step_ms[len(step_ms) // 2], 3), "max": round(step_ms[-1], 3)}
                         if step_ms else None),
-            "hot_slice_tflops": round(fps * FRAME_FLOPS / 1e12, 2),   # algorithmic: the reference graph's FLOPs per frame x frames/s
+            # the reference graph's FLOPs per frame x frames/s (NOT a machine rate: the demand-driven tail skips most of final_conv and
+            # the F(2,3) kernels execute 2/3 of a conv's multiplies) ...
+            "hot_slice_tflops_reference_graph": round(fps * FRAME_FLOPS / 1e12, 2),
+            # ... and with the skipped part of final_conv subtracted (still the reference's multiply count for what is evaluated)
             "hot_slice_tflops_executed": round(fps * (FRAME_FLOPS - (FINAL_CONV_FLOPS if demand else 0.0)) / 1e12, 2),
             "hot_slice_vs_f32_mfma_peak": round(fps * FRAME_FLOPS / 1e12 / (PEAK_F32_MFMA_TFLOPS * world), 4),
             "hot_slice_layerwise_GBps": round(fps * FRAME_BYTES / 1e9, 1),
             "roofline": {"kernel": dom_name, "bound": "mfma", "achieved": round(achieved, 2), "peak": peak,
                          "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                         "traffic": pmc_traffic("conv3d_k3_f16x3_kernel") if (f16x3 and B == 8) else None,
+                         "traffic": traffic, "stale": stale,
                          "launch_ms": round(dom_ms, 4), "launches_timed": dom_launches,
                          "demand_driven_launch": demand,
-                         "flops_per_launch": dom_flops,
-                         "note": ("algorithmic (fp32-equivalent) FLOPs; the kernel issues 3x that on the f16 pipe: "
-                                  f"{round(3 * achieved, 1)} TFLOP/s = {round(3 * achieved / peak, 4)} of the f16 peak; "
-                                  f"vs the fp32-MFMA peak ({PEAK_F32_MFMA_TFLOPS}) the algorithmic rate is "
-                                  f"{round(achieved / PEAK_F32_MFMA_TFLOPS, 2)}x.  The kernel is power-bound: the package sits at its "
-                                  "1400 W limit with the clock throttled to ~1.7-2.0 GHz while it runs (profiles/r02_power_probe.txt); the "
-                                  "2500 TFLOP/s peak assumes 2.4 GHz"
+                         "flops_per_launch": dom_flops, "f16_flops_issued_per_algorithmic_flop": issued_per_alg if f16x3 else None,
+                         "note": (f16_note(achieved)
                                   + ("; with several batches in flight the two events around a launch also see the time the launch "
                                      "waits for CUs another batch's kernel still holds: `one_in_flight.dominant_conv` is the same "
                                      "measurement with the steps on one stream" if lanes else "")) if f16x3 else
                                  "exact fp32 MFMA (v_mfma_f32_32x32x2_f32)"},
+            "repeats": ({"ms_per_step": [round(v, 3) for v in rep_ms], "min": round(min(rep_ms), 3), "median": round(sorted(rep_ms)[len(rep_ms) // 2], 3),
+                         "max": round(max(rep_ms), 3), "what": f"{len(rep_ms)} more blocks of the same {args.steps} steps (barrier + synchronize on "
+                         "both sides each), after the graded block; the steps of every block rotate over 2 distinct input sets"} if rep_ms else None),
         }
         if world == 1 and not args.no_extras:
             # side measurements (N=1 only, never inside the timed region): each leg is timed, and legs that would push the
@@ -750,11 +839,16 @@ def main():
                     r["measured"] = ("HIP events stamped with the kernel's begin / end (hipExtLaunchKernelGGL), K steps on ONE stream "
                                      "(the `one_in_flight` leg of this run); `in_two_batch_loop`: the same events during the timed "
                                      "region of the headline, where the other batch's kernels hold CUs while the conv starts and drains")
-                    r["note"] = (f"algorithmic (fp32-equivalent) FLOPs; the kernel issues 3x that on the f16 pipe: {round(3 * dc['achieved'], 1)} "
-                                 f"TFLOP/s = {round(3 * dc['achieved'] / peak, 4)} of the f16 peak; vs the fp32-MFMA peak "
-                                 f"({PEAK_F32_MFMA_TFLOPS}) the algorithmic rate is {round(dc['achieved'] / PEAK_F32_MFMA_TFLOPS, 2)}x.  The "
-                                 "kernel is power-bound: the package sits at its 1400 W limit with the clock throttled to ~1.7-2.0 GHz "
-                                 "while it runs (profiles/r02_power_probe.txt); the 2500 TFLOP/s peak assumes 2.4 GHz")
+                    r["note"] = f16_note(dc["achieved"])
+            if f16x3:
+                leg("_sustained", sustained_peak)
+                sp = line.pop("_sustained", None)
+                if sp and "tflops_issued" in sp:
+                    r = line["roofline"]
+                    r["sustained_peak"] = sp
+                    r["frac_of_sustained"] = round(issued_per_alg * r["achieved"] / sp["tflops_issued"], 4)
+                    r["frac_of_sustained_what"] = ("f16 FLOP/s this kernel ISSUES (achieved x f16_flops_issued_per_algorithmic_flop) / the rate the same "
+                                                   "MFMA stream sustains alone on this package in this run")
             if demand:
                 leg("full_final_conv", full_final_conv_leg, hot, inp, B)
             leg("roofline_hbm", roofline_hbm, hot, inp, B)

@@ -437,6 +437,11 @@ void mphip_hot_slice_plan_destroy(mphip_hot_slice_plan *plan);
  * They are NOT clamped (the output carries Inf/NaN like the reference's fp32 conv would); 0 in normal operation.     */
 int mphip_f16x3_saturation_count(unsigned long long *count, int reset);
 
+/* Which kernel a full launch of mphip_conv3d_fwd takes for this shape: 0 = exact fp32 kernels / the k = 1 GEMM, 1 / 2 = the direct
+ * f16x3 kernel on (td,8,8) / (4,8,16) tiles, 5 = the f16x3 kernel in the 1-D Winograd F(2,3) domain (2/3 of the MFMAs;
+ * conv3d_f16x3_wino.hip).  For measurements and tests: results do not depend on it beyond fp32 rounding.                     */
+int mphip_conv3d_kernel_variant(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
+
 /* Measurement only (tools/mfma_sol.py, bench.py `roofline.sustained_peak`): the f16x3 convs' MFMA stream and nothing else — three
  * v_mfma_f32_32x32x16_f16 per product on random hi/lo fragments, 3 x 2 accumulator tiles per wave, 8 waves per workgroup; mode 1 reads
  * its ten fragments per tap from LDS like the conv, mode 0 keeps them in registers.  No global traffic.  One launch issues

@@ -105,6 +105,7 @@ SIGNATURES = {
     "mphip_g3d_forward": (_i, [_p, _p, _p, _p, _i, _p, _sz, _p]),
     "mphip_hot_slice_plan_destroy": (None, [_p]),
     "mphip_debug_mfma_sol": (_i, [_p, _i, _i, _i, _p]),
+    "mphip_conv3d_kernel_variant": (_i, [_i] * 8),
 }
 
 _lib = None

@@ -587,6 +587,10 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
                       float *gn_stats, int gn_groups, float gn_eps, bool keep_split, int N, int Ci, int Co, int D, int H, int W, int k, int precision, void *workspace,
                       size_t workspace_bytes, void *stream, const int *roi = nullptr, int roi_frames = 0, int roi_dilate = 0,
                       const GnTable *gn_table = nullptr) {
+    // the measurement hook's events belong to THIS call whatever happens below (an early error return must not leave them armed
+    // for an unrelated later launch on this thread)
+    hipEvent_t te0 = g_time_e0, te1 = g_time_e1;
+    g_time_e0 = g_time_e1 = nullptr;
     MPHIP_REQUIRE(x && w_packed && y, "conv3d_fwd: null pointer");
     MPHIP_REQUIRE(N > 0 && Ci > 0 && Co > 0 && D > 0 && H > 0 && W > 0, "conv3d_fwd: bad dims");
     MPHIP_REQUIRE(k == 1 || k == 3, "conv3d_fwd: kernel size %d not supported (1 or 3)", k);
@@ -645,8 +649,6 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
     }
     void *gn_ws = (char *)workspace + slab_bytes;
     int rc;
-    hipEvent_t te0 = g_time_e0, te1 = g_time_e1;
-    g_time_e0 = g_time_e1 = nullptr;
     const bool stamp = te0 && te1 && precision == 1 && k == 3;   // the f16x3 3x3x3 kernels carry the events themselves (kernel begin / end)
     if (te0 && !stamp) (void)hipEventRecord(te0, s);
     if (precision == 1 && k == 1) {
@@ -725,6 +727,13 @@ extern "C" int mphip_conv3d_fwd_roi(const float *x, const float *x_range, const 
     // (shapes / precisions without a tiled kernel compute every voxel: the result is a superset of what was asked for)
     return conv3d_run(x, nullptr, 0, x_range, w_packed, bias, y, nullptr, 0, 0.0f, false, N, Ci, Co, D, H, W, k, precision, workspace,
                       workspace_bytes, stream, tiled ? roi : nullptr, tiled ? roi_frames : 0);
+}
+
+// which kernel a (full) conv launch of this shape takes: 0 = exact fp32 kernels / k = 1 GEMM, 1 / 2 = the direct f16x3 kernel on
+// (td,8,8) / (4,8,16) tiles, 5 = the 1-D Winograd F(2,3) f16x3 kernel.  Measurement / tests only.
+extern "C" int mphip_conv3d_kernel_variant(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {
+    if (precision != 1 || k != 3 || !mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
+    return f16x3_plan(N, Ci, Co, D, H, W).variant + 1;
 }
 
 extern "C" int mphip_conv3d_splits(int N, int Ci, int Co, int D, int H, int W, int k, int precision) {

@@ -112,6 +112,9 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
             if (!(w0 < b[0] + b[3] && w0 + 8 > b[0] && h0 < b[1] + b[4] && h0 + 8 > b[1] && d0 < b[2] + b[5] && d0 + 2 > b[2])) continue;
         }
         __syncthreads();  // the previous tile is fully consumed
+        int tz = 0;
+        asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps the staging code's per-thread index math from being hoisted out of the
+                                      // tile loop into registers the 192 accumulators do not leave (hipcc spilled 12 of them to scratch)
 #ifdef BF_ABL_NOSTAGE
         if (tile == t_begin)
 #endif
@@ -120,7 +123,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
             float4 ya[3][2];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int q = tid + i * 512, co = q >> 4, rr = q & 15;
+                const int q = tid + i * 512 + tz, co = q >> 4, rr = q & 15;
                 const int gd = d0 + (rr >> 3), gh = h0 + (rr & 7);
                 const bool ok = co0 + co < Co && gd < D && gh < H;
                 const float *p = dy + (ok ? ((size_t)n * Co + co0 + co) * DHW + (size_t)gd * HW + gh * W + w0 : 0);
@@ -130,7 +133,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int q = tid + i * 512, co = q >> 4, rr = q & 15;
+                const int q = tid + i * 512 + tz, co = q >> 4, rr = q & 15;
                 const float v[8] = {ya[i][0].x, ya[i][0].y, ya[i][0].z, ya[i][0].w, ya[i][1].x, ya[i][1].y, ya[i][1].z, ya[i][1].w};
                 half8 hi, lo;
 #pragma unroll
@@ -149,7 +152,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
             float xl[3], xr[3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int q = tid + i * 512;
+                const int q = tid + i * 512 + tz;
                 const int ci = q / 40, pr = q % 40;
                 const int gd = d0 - 1 + pr / 10, gh = h0 - 1 + pr % 10;
                 const bool ok = q < 1280 && ci0 + ci < Ci && (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
@@ -165,7 +168,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
             }
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int q = tid + i * 512;
+                const int q = tid + i * 512 + tz;
                 if (q < 1280) {
                     const int ci = q / 40, pr = q % 40;
                     const float v[10] = {xl[i], xa[i][0].x, xa[i][0].y, xa[i][0].z, xa[i][0].w,

@@ -623,23 +623,23 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
             }
         }
     }
-    float bv[MT][16];
+    // (one 32-channel row tile at a time: its 16 bias values are loaded right before its stores — all 48 up front cost the 512-voxel
+    //  instantiation 16 of its spilled registers)
 #pragma unroll
-    for (int m = 0; m < MT; ++m)
+    for (int m = 0; m < MT; ++m) {
+        float bv[16];
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg)
-            bv[m][reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg + tz] : 0.0f;
+            bv[reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg + tz] : 0.0f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int v = (wave * NT + t) * 32 + jv;
-        const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
-        float *dv = dst + (size_t)en * Co * DHW + (size_t)(ed0 + vd) * HW + (eh0 + vh) * W + ew0 + vw;
-#pragma unroll
-        for (int m = 0; m < MT; ++m) {
+        for (int t = 0; t < NT; ++t) {
+            const int v = (wave * NT + t) * 32 + jv;
+            const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
+            float *dv = dst + (size_t)en * Co * DHW + (size_t)(ed0 + vd) * HW + (eh0 + vh) * W + ew0 + vw;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int co = co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg + tz;
-                dv[(size_t)co * DHW] = acc[m][t][reg] * unscale + bv[m][reg];
+                dv[(size_t)co * DHW] = acc[m][t][reg] * unscale + bv[reg];
             }
         }
     }
@@ -713,19 +713,8 @@ conv3d_k3_f16x3_third_kernel(const float *__restrict__ x, const _Float16 *__rest
                                                     in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames, gn_part);
 }
 
-// One wave per SIMD with up to 512 registers: a wave owns 96 output channels x 128 voxels (12 accumulator tiles), so every
-// weight fragment read from LDS feeds four MFMAs instead of two (LDS reads per MFMA 0.56 -> 0.39) and half as many waves meet at
-// every barrier.  The kernel is power-bound: fewer joules per tile is what can make it faster.
-template <int TD, int TH, int TW, int NWAVES, int GS>
-__global__ void __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 1)))
-conv3d_k3_f16x3_wide_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
-                            const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
-                            int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
-                            const float *__restrict__ x_scale_p, int tiles_total, int xcd_aware, const int *__restrict__ roi, int roi_frames,
-                       float *__restrict__ gn_part) {
-    conv3d_k3_f16x3_body<TD, TH, TW, NWAVES, GS>(x, wslabs, whdr, bias, y, N, Ci, Co, D, H, W, chunks_per_split, x_bytes, in_affine,
-                                                 in_relu, x_scale_p, tiles_total, xcd_aware, roi, roi_frames, gn_part);
-}
+// (r02-r03 experiments removed in r04, measured and rejected — DESIGN.md 3: four "wide" waves, one per SIMD with 512 registers and 96 x 128
+//  accumulators, 4-10 % slower; two 4-wave workgroups per CU on (4,8,8) tiles, +-0.  Both instantiations spilled 80-110 registers.)
 
 // ---- k = 1: the 1x1x1 shortcut convs of G3d (model.py:510) on the same split-f16 arithmetic ---------------------------------
 // Y[co][vox] = sum_ci W[co][ci] * X[ci][vox] is a plain GEMM that streams X once: HBM-bound.  No LDS, no barriers: a wave owns
@@ -938,14 +927,6 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     p.variant = (tiles1 * cot >= 256) ? 1 : 0;
     if (force && force[0] == '0') p.variant = 0;
     if (force && force[0] == '1' && tiles1) p.variant = 1;
-    // variant 2: (4,8,8) tile, FOUR waves, two workgroups per CU (81 KB of LDS each).  The two workgroups of a CU run out of
-    // phase, so one's barrier / staging / store phases overlap the other's MFMA bursts.
-    static const char *v2min_s = getenv("MPHIP_F16X3_V2_MIN");   // dev: threshold sweep
-    const long v2min = v2min_s ? atol(v2min_s) : (1L << 60);      // off by default: measured neutral end to end (same-box A/B, r02)
-    const long tiles8 = (long)N * (D / 4) * (H / 8) * (W / 8);
-    if (!force && p.td == 4 && tiles8 * cot >= v2min) p.variant = 2;
-    if (force && force[0] == '2' && p.td == 4) p.variant = 2;
-    if (force && force[0] == '3' && tiles1) p.variant = 3;   // the 512-voxel tile on FOUR wide waves (dev: same-box A/B)
     // demand-driven launches compute a handful of tiles, one per CU: the time is ONE tile's latency, so the smallest tile wins
     // (a ~5^3 box is 2 tiles either way: 4x8x8 halves the work per tile)
     // (2x8x8 tiles on 4 waves for these launches: measured the same 0.092 ms as 4x8x8, r03)
@@ -953,7 +934,7 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     // variant 4: the 1-D Winograd F(2,3) kernel (conv3d_f16x3_wino.hip; (4,8,8) tile, 2/3 of the MFMAs) on launches that fill the chip
     // (demand-driven launches follow the full launch's choice, so that the tiles they compute carry the same bits)
     if (!force && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
-    const long tiles = (p.variant == 1 || p.variant == 3) ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
+    const long tiles = p.variant == 1 ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup (each split adds a slab write + a reduce pass): the largest
     // whole-chunk split that still fits the chip in ONE round of resident workgroups (one per CU; two for the 4-wave (2,8,8) kernel).
@@ -983,13 +964,13 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
 
 int f16x3_tile_waves(const F16x3Plan &p) {   // GroupNorm-partial rows per tile of the kernel variant f16x3_launch picks (= its waves;
                                               // the Winograd kernel leaves one row per plane pair)
-    return p.variant == 4 ? 2 : (p.variant == 2 || p.variant == 3) ? 4 : (p.variant == 1 || p.td == 4) ? 8 : 4;
+    return p.variant == 4 ? 2 : (p.variant == 1 || p.td == 4) ? 8 : 4;
 }
 
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]) {   // output tile (d,h,w) of the kernel variant f16x3_launch picks
-    dims[0] = (p.variant >= 1 && p.variant <= 4) ? 4 : p.td;
+    dims[0] = (p.variant == 1 || p.variant == 4) ? 4 : p.td;
     dims[1] = 8;
-    dims[2] = (p.variant == 1 || p.variant == 3) ? 16 : 8;
+    dims[2] = p.variant == 1 ? 16 : 8;
 }
 
 int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed, const void *header_from, hipStream_t s) {
@@ -1062,7 +1043,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles
     const int tiles_total = (int)p.grid.x;
-    const int per_cu = p.variant == 2 ? 2 : (p.variant == 1 || p.variant == 3 || p.td == 4) ? 1 : 2;
+    const int per_cu = (p.variant == 1 || p.td == 4) ? 1 : 2;
     static const bool thirds_off = getenv("MPHIP_ROI_THIRDS") && getenv("MPHIP_ROI_THIRDS")[0] == '0';   // dev: same-box A/B
     const bool thirds = roi && p.variant == 0 && p.td == 4 && !gn_part && !thirds_off;
     const long others = (long)p.grid.y * (thirds ? 3 : 1) * p.grid.z;
@@ -1084,9 +1065,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
             hipLaunchKernelGGL(kern_, grid, dim3(block_), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, p.chunks_per_split, xb, \
                                in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);                      \
     }
-    if (p.variant == 3) F16X3_LAUNCH((conv3d_k3_f16x3_wide_kernel<4, 8, 16, 4, 1>), 256)
-    else if (p.variant == 2) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 4, 1>), 256)
-    else if (p.variant == 1) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), 512)
+    if (p.variant == 1) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), 512)
     else if (p.td == 4 && thirds) F16X3_LAUNCH((conv3d_k3_f16x3_third_kernel<4, 8, 8, 8, 3>), 512)
     else if (p.td == 4) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), 512)
     else F16X3_LAUNCH((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), 256)

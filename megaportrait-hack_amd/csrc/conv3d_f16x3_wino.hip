@@ -159,10 +159,13 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     const unsigned chan_stride = (unsigned)DHW * 4u;
 
     // ---- X staging: thread = (channel pair cp, halo row srow); 480 of the 512 threads ------------------------------------------
-    const int cp = tid & 7, srow = tid >> 3;
-    const bool stager = srow < WN_ROWS;
+    // (threads 480..511 re-do row 59 — same loads, same values, same LDS addresses — so that the staging code is branch-free: it is
+    //  issued into the shadow of a chunk's last MFMAs, and the scheduler interleaves only inside one basic block)
+    const int cp = tid & 7, srow = min(tid >> 3, WN_ROWS - 1);
+    const bool stager = true;
     const int sdl = srow / WN_HH, shl = srow % WN_HH;
     const bool fuse_in = in_affine != nullptr;   // workgroup-uniform
+    const float relu_floor = in_relu ? 0.0f : -3.0e38f;   // (the fused ReLU as a max against a uniform: no branch in the staging code)
     int aff_n = -1;
     auto row_off = [&]() -> unsigned {   // byte offset of (n, channel 2cp of chunk 0, row, w0), or OOB (padding rows / idle threads)
         const int gd = d0 - 1 + sdl, gh = h0 - 1 + shl;
@@ -187,45 +190,50 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         xl1 = buf_load_f(rsrc, lft_ ? o1_ - 4u : OOB, soff_);                                              \
         xr1 = buf_load_f(rsrc, rgt_ ? o1_ + 32u : OOB, soff_);                                             \
     }
-    unsigned sat_ = 0;
+    float xmax_ = 0.0f;   // max |scaled halo value| this thread staged: beyond 2^15 the transformed values can leave the f16 range
     // registers -> (fused GroupNorm + ReLU) -> scale -> F(2,3) input transform -> split -> LDS
-#define WN_WRITE_X(chunk)                                                                                  \
-    if (stager) {                                                                                          \
-        float v0_[10] = {xl0, xa0[0], xa0[1], xa0[2], xa0[3], xb0[0], xb0[1], xb0[2], xb0[3], xr0};        \
-        float v1_[10] = {xl1, xa1[0], xa1[1], xa1[2], xa1[3], xb1[0], xb1[1], xb1[2], xb1[3], xr1};        \
-        if (fuse_in) {                                                                                     \
-            const bool row_ok_ = row_off() != OOB;                                                         \
+#ifdef MPHIP_WN_ABL_NOWRITE   /* dev (timing only, wrong results): no halo transform / split / LDS stores */
+#define WN_STAGER_ON (stager && tiles_total < 0)
+#else
+#define WN_STAGER_ON stager
+#endif
+    // All arithmetic on (channel 2cp, channel 2cp+1) PAIRS (f32x2): the pair is exactly the half2 a staging store writes, so scale,
+    // transform and split run on v_pk_mul_f32 / v_pk_add_f32 / v_cvt_pk_f16_f32 — ~130 VALU instructions per thread and chunk instead of
+    // ~560 with scalar conversions (the halo write was 21 % of a launch: profiles/r04_wino_ablations.txt).  Split: hi = rne(t), lo =
+    // rne(t - hi); a non-finite t gives hi = Inf / NaN and lo = NaN, i.e. a non-finite product, like the reference's fp32 conv.
+#define WN_WRITE_X(chunk, FUSE)                                                                            \
+    if (WN_STAGER_ON) {                                                                                    \
+        f32x2 v_[10] = {{xl0, xl1}, {xa0[0], xa1[0]}, {xa0[1], xa1[1]}, {xa0[2], xa1[2]}, {xa0[3], xa1[3]},  \
+                        {xb0[0], xb1[0]}, {xb0[1], xb1[1]}, {xb0[2], xb1[2]}, {xb0[3], xb1[3]}, {xr0, xr1}}; \
+        if (FUSE) {   /* compile-time.  Padding (rows / edge voxels outside the volume) must stay 0: its (scale, shift) pair is zeroed, */ \
+                      /* and max(0*x + 0, floor) = 0 for both floors — no select, no branch                                       */ \
+            const int gd_ = d0 - 1 + sdl, gh_ = h0 - 1 + shl;                                              \
+            const float mid_ = ((unsigned)gd_ < (unsigned)D && (unsigned)gh_ < (unsigned)H) ? 1.0f : 0.0f; \
+            const float lft_ = w0 > 0 ? mid_ : 0.0f, rgt_ = w0 + WN_TW < W ? mid_ : 0.0f;                  \
             const float4 sc_ = *reinterpret_cast<const float4 *>(aff + ((chunk) * WN_KC + 2 * cp) * 2);    \
+            const f32x2 mul_ = {sc_.x, sc_.z}, add_ = {sc_.y, sc_.w};                                      \
+            const f32x2 mm_ = mul_ * mid_, am_ = add_ * mid_, ml_ = mul_ * lft_, al_ = add_ * lft_, mr_ = mul_ * rgt_, ar_ = add_ * rgt_; \
             _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                               \
-                const bool ok_ = row_ok_ && (i == 0 ? w0 > 0 : i == 9 ? w0 + WN_TW < W : true);            \
-                float a_ = v0_[i] * sc_.x + sc_.y, b_ = v1_[i] * sc_.z + sc_.w;                            \
-                if (in_relu) {                                                                             \
-                    a_ = fmaxf(a_, 0.0f);                                                                  \
-                    b_ = fmaxf(b_, 0.0f);                                                                  \
-                }                                                                                          \
-                v0_[i] = ok_ ? a_ : 0.0f;                                                                  \
-                v1_[i] = ok_ ? b_ : 0.0f;                                                                  \
+                const f32x2 a_ = v_[i] * (i == 0 ? ml_ : i == 9 ? mr_ : mm_) + (i == 0 ? al_ : i == 9 ? ar_ : am_); \
+                v_[i][0] = fmaxf(a_[0], relu_floor);                                                       \
+                v_[i][1] = fmaxf(a_[1], relu_floor);                                                       \
             }                                                                                              \
         }                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                   \
-            v0_[i] *= x_scale;                                                                             \
-            v1_[i] *= x_scale;                                                                             \
-            sat_ += !(fabsf(v0_[i]) <= 0.5f * F16_CLAMP) + !(fabsf(v1_[i]) <= 0.5f * F16_CLAMP);  /* NaN counts */ \
+            v_[i] *= x_scale;                                                                              \
+            xmax_ = fmaxf(fmaxf(xmax_, fabsf(v_[i][0])), fabsf(v_[i][1]));   /* (v_max3_f32; a NaN is caught by the hi halves below) */ \
         }                                                                                                  \
         _Float16 *xd_ = Xs + (cp >> 2) * WN_XBLK + srow * 32 + (cp & 3) * 2;                               \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
-            const float t0_[4] = {v0_[2 * q] - v0_[2 * q + 2], v0_[2 * q + 1] + v0_[2 * q + 2],            \
-                                  v0_[2 * q + 2] - v0_[2 * q + 1], v0_[2 * q + 1] - v0_[2 * q + 3]};       \
-            const float t1_[4] = {v1_[2 * q] - v1_[2 * q + 2], v1_[2 * q + 1] + v1_[2 * q + 2],            \
-                                  v1_[2 * q + 2] - v1_[2 * q + 1], v1_[2 * q + 1] - v1_[2 * q + 3]};       \
+            const f32x2 t_[4] = {v_[2 * q] - v_[2 * q + 2], v_[2 * q + 1] + v_[2 * q + 2], v_[2 * q + 2] - v_[2 * q + 1],        \
+                                 v_[2 * q + 1] - v_[2 * q + 3]};                                           \
             _Pragma("unroll") for (int pp = 0; pp < 4; ++pp) {                                             \
-                _Float16 h0_, l0_, h1_, l1_;                                                               \
-                split_f16(t0_[pp], h0_, l0_);                                                              \
-                split_f16(t1_[pp], h1_, l1_);                                                              \
-                const half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                           \
+                const half2v hv_ = __builtin_convertvector(t_[pp], half2v);                                \
+                const half2v lv_ = __builtin_convertvector(t_[pp] - __builtin_convertvector(hv_, f32x2), half2v); \
                 *reinterpret_cast<half2v *>(xd_ + pp * 2 * WN_XBLK + q * 8) = hv_;                         \
                 *reinterpret_cast<half2v *>(xd_ + WN_XPART + pp * 2 * WN_XBLK + q * 8) = lv_;              \
             }                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);   /* one output pair at a time: hoisting all 32 conversions above the stores spills */ \
         }                                                                                                  \
     }
 
@@ -235,6 +243,10 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     int dma_s = 0, dma_cg = 0;   // slabs issued so far; its (chunk*9 + group) index into the packed tensor
     const int cg_total = nchunks * WN_NG;
     auto dma_issue = [&]() -> int {   // 3 pieces of 1 KiB per wave; returns the number of vector-memory instructions issued
+#ifdef MPHIP_WN_ABL_NODMA   /* dev (timing only, wrong results): no weight stream */
+        ++dma_s;
+        return 0;
+#endif
         if (dma_s >= s_total) return 0;
         const _Float16 *src = wsrc + (size_t)dma_cg * WN_SLAB_HALFS + wave * 512;
         const unsigned dst = ws_lds + (unsigned)(dma_s & (WN_RING - 1)) * (WN_SLAB_HALFS * 2) + (unsigned)wave * 1024u;
@@ -266,7 +278,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     dma_issue();
     dma_issue();
     WN_LOAD_X(0);
-    WN_WRITE_X(0);
+    if (fuse_in) { WN_WRITE_X(0, true) } else { WN_WRITE_X(0, false) }
     lds_dma_wait<0>();
     lds_barrier();
 
@@ -284,6 +296,9 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     for (int tj = j_first; tj < ntiles; tj += (int)gridDim.x) {
         const int en = n, ed0 = d0, eh0 = h0, ew0 = w0, etile = tile_at(tj);   // this tile (the staging variables move on during its last chunk)
         const bool has_next = tj + (int)gridDim.x < ntiles;
+        int tz = 0;
+        asm volatile("" : "+v"(tz));  // opaque 0, new per tile: keeps the epilogue's per-channel address math / bias loads from being hoisted
+                                      // out of the tile loop into registers (where they were spilled to scratch)
         f32x16 acc[3][2];
 #pragma unroll
         for (int m = 0; m < 3; ++m)
@@ -308,6 +323,13 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             //   bottom   : wait for THIS wave's pieces of slab s+2 (issued one interval ago; younger transfers stay in flight),
             //              barrier s: slab s+2 published, slot of slab s free
 #define WN_TOFF(G) ((((G) / 3) * WN_HH + (G) % 3) * 32)
+#ifdef MPHIP_WN_ABL_NOMFMA   /* dev (timing only, wrong results): everything but the MFMAs */
+#define WN_MFMA(a_, b_, c_) (c_)
+#define WN_ABL_KEEP_FRAGS asm volatile("" ::"v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(al[0]), "v"(al[1]), "v"(al[2]), "v"(bl[0]), "v"(bl[1]), "v"(bh[0][0]), "v"(bh[0][1]), "v"(bh[1][0]), "v"(bh[1][1]));
+#else
+#define WN_ABL_KEEP_FRAGS
+#define WN_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
+#endif
 #define WN_INTERVAL(G)                                                                                                     \
     {                                                                                                                      \
         constexpr int cur_ = (G) & 1;                                                                                      \
@@ -321,7 +343,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[cur_][t], acc[m][t], 0, 0, 0);                \
+                acc[m][t] = WN_MFMA(al[m], bh[cur_][t], acc[m][t]);                \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         if (s + 1 < s_total) {                                                                                             \
             _Pragma("unroll") for (int m = 0; m < 3; ++m) al[m] = *reinterpret_cast<const half8 *>(wsn_ + m * 256);        \
@@ -333,10 +355,11 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[cur_][t], acc[m][t], 0, 0, 0);                \
+                acc[m][t] = WN_MFMA(ah[m], bh[cur_][t], acc[m][t]);                \
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
-                acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);                      \
+                acc[m][t] = WN_MFMA(ah[m], bl[t], acc[m][t]);                      \
+        WN_ABL_KEEP_FRAGS                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         WPROF_ADD(1)                                                                                                       \
         /* younger than this wave's pieces of slab s+2: interval 2's halo prefetch (8) and this interval's pieces (3) */   \
@@ -358,22 +381,101 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             WN_INTERVAL(5)
             WN_INTERVAL(6)
             WN_INTERVAL(7)
+#ifdef MPHIP_WN_NO_OVERLAP8   /* dev: same-box A/B — the halo write in its own phase after the chunk's last interval */
             WN_INTERVAL(8)
-#undef WN_INTERVAL
             if (more) {
-                WN_WRITE_X(c + 1);   // every wave is past its last read of the X tile (barrier above)
+                if (fuse_in) { WN_WRITE_X(c + 1, true) } else { WN_WRITE_X(c + 1, false) }   // every wave is past its last read of the X tile
                 WPROF_ADD(4)
                 lds_barrier();
 #pragma unroll
                 for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
                 WPROF_ADD(5)
             }
+#else
+            {
+                // The chunk's last interval carries the NEXT chunk's halo write: once this interval's fragments are in registers nobody reads
+                // the X tile any more, so after one early barrier the tile may be rewritten while the interval's 18 MFMAs run.  The two
+                // waves of a SIMD — (p, ch = 0) and (p, ch = 1): a workgroup's waves go round the SIMDs, wave w and w + 4 meet — take the
+                // two jobs in OPPOSITE order: one issues its MFMAs while the other transforms, splits and stores its share of the halo
+                // (VALU + LDS), then they swap.  The MFMAs stay ONE straight-line copy (accumulators that merge from two branches cost
+                // hipcc 70-160 spilled registers, and so did interleaving both jobs in one instruction stream); only the staging code
+                // sits under the wave-uniform conditions.  A tile's last chunk (!more) has nothing to stage here: the next tile's halo is
+                // written after the output transform, which uses the X region.
+                const int issued_ = dma_issue();
+                const _Float16 *wsb_ = Ws + (s & (WN_RING - 1)) * WN_SLAB_HALFS + a_base;
+                const _Float16 *wsn_ = Ws + ((s + 1) & (WN_RING - 1)) * WN_SLAB_HALFS + a_base + WN_PART_HALFS;
+#pragma unroll
+                for (int m = 0; m < 3; ++m) ah[m] = *reinterpret_cast<const half8 *>(wsb_ + m * 256);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bl[t] = *reinterpret_cast<const half8 *>(Xs + WN_XPART + b_base[t] + WN_TOFF(8));
+                if (more) {
+                    lds_barrier();   // every wave holds its last X fragments: the tile may be rewritten
+                    WPROF_ADD(3)
+                    if (ch != 0) {
+                        if (fuse_in) { WN_WRITE_X(c + 1, true) } else { WN_WRITE_X(c + 1, false) }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[m][t] = WN_MFMA(al[m], bh[0][t], acc[m][t]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < s_total) {
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) al[m] = *reinterpret_cast<const half8 *>(wsn_ + m * 256);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[m][t] = WN_MFMA(ah[m], bh[0][t], acc[m][t]);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[m][t] = WN_MFMA(ah[m], bl[t], acc[m][t]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more && ch == 0) {
+                    if (fuse_in) { WN_WRITE_X(c + 1, true) } else { WN_WRITE_X(c + 1, false) }
+                }
+                WN_ABL_KEEP_FRAGS
+                __builtin_amdgcn_sched_barrier(0);
+                WPROF_ADD(1)
+                if (issued_) lds_dma_wait<3>(); else lds_dma_wait<0>();
+                WPROF_ADD(2)
+                lds_barrier();   // slab s+2 published, slot of slab s free, the new halo visible
+                ++s;
+                if (more) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+                }
+                WPROF_ADD(5)
+            }
+#endif
+#undef WN_INTERVAL
         }
 
         // ---- output transform + epilogue: three rounds (one 32-channel row tile each) through the dead X region ---------------------
+#ifdef MPHIP_WN_ABL_NOEPI   /* dev (timing only, wrong results): no output transform / stores */
+        if (tiles_total > 0) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(acc[m][t]));
+            if (has_next) {
+                if (fuse_in) { WN_WRITE_X(0, true) } else { WN_WRITE_X(0, false) }
+                lds_barrier();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
+            }
+            continue;
+        }
+#endif
         const int gn_rows = tiles_total * 2;   // channel-major [Co][tile * 2 + ch][2] (the finalize kernel reads rows of it)
         if (gn_part && etile == 0 && tid == 0) gn_part[(size_t)gn_rows * Co * 2] = unscale;   // (behind the partials)
-        float *const dsto = y + (size_t)en * Co * DHW + (size_t)(ed0 + 2 * ch) * HW + (size_t)(eh0 + (j >> 2)) * W + ew0 + 2 * (j & 3);
+        const bool odd = (lane & 1) != 0;
+        // (row start of this lane's QUAD of voxels: lanes 2k / 2k+1 store the 4 voxels 4k..4k+3 of a row, for different channels)
+        float *const dsto = y + (size_t)en * Co * DHW + (size_t)(ed0 + 2 * ch) * HW + (size_t)(eh0 + (j >> 2)) * W + ew0 + 2 * (j & 2);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of both column tiles; wave p keeps unit p
@@ -390,7 +492,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             float ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             float bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[co0 + m * 32 + 8 * p + 4 * kgl + i] : 0.0f;
+            for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[co0 + m * 32 + 8 * p + 4 * kgl + i + tz] : 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 M[4];
@@ -404,16 +506,30 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
                         for (int i = 0; i < 4; ++i) M[q][i] = acc[m][t][4 * q + i];
                     }
                 }
+                float y0[4], y1[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float y0 = (M[0][i] + M[1][i]) + M[2][i];
-                    const float y1 = (M[1][i] - M[2][i]) - M[3][i];
-                    ssum[i] += y0 + y1;
-                    qsum[i] = __builtin_fmaf(y0, y0, qsum[i]);
-                    qsum[i] = __builtin_fmaf(y1, y1, qsum[i]);
-                    const int co = co0 + m * 32 + 8 * p + 4 * kgl + i;
-                    *reinterpret_cast<float2 *>(dsto + (size_t)co * DHW + (size_t)t * HW) = make_float2(y0 * unscale + bv[i], y1 * unscale + bv[i]);
+                    const float r0 = (M[0][i] + M[1][i]) + M[2][i];
+                    const float r1 = (M[1][i] - M[2][i]) - M[3][i];
+                    ssum[i] += r0 + r1;
+                    qsum[i] = __builtin_fmaf(r0, r0, qsum[i]);
+                    qsum[i] = __builtin_fmaf(r1, r1, qsum[i]);
+                    y0[i] = r0 * unscale + bv[i];
+                    y1[i] = r1 * unscale + bv[i];
                 }
+                // 16-byte stores: a lane holds one output pair (2 voxels) of 4 channels; lanes 2k / 2k+1 hold neighbouring pairs of a row.
+                // They trade halves (quad_perm [1,0,3,2]): the even lane ends up with 4 consecutive voxels of channels 0-1, the odd lane
+                // with those of channels 2-3 — two dwordx4 stores per lane instead of four dwordx2 (the epilogue is store-ISSUE bound:
+                // 8-byte stores of 32-byte row pieces ran at ~7 B/clk/CU, MI355X_MICROARCH.md "epilogue store tail").
+#define WN_SWAP(v_) __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), 0xB1, 0xf, 0xf, false))
+                const float g0 = WN_SWAP(odd ? y0[0] : y0[2]), g1 = WN_SWAP(odd ? y1[0] : y1[2]);
+                const float g2 = WN_SWAP(odd ? y0[1] : y0[3]), g3 = WN_SWAP(odd ? y1[1] : y1[3]);
+#undef WN_SWAP
+                const f32x4 va = {odd ? g0 : y0[0], odd ? g1 : y1[0], odd ? y0[2] : g0, odd ? y1[2] : g1};
+                const f32x4 vb = {odd ? g2 : y0[1], odd ? g3 : y1[1], odd ? y0[3] : g2, odd ? y1[3] : g3};
+                float *const dq = dsto + (size_t)(co0 + m * 32 + 8 * p + 4 * kgl + (odd ? 2 : 0) + tz) * DHW + (size_t)t * HW;
+                *reinterpret_cast<f32x4 *>(dq) = va;
+                *reinterpret_cast<f32x4 *>(dq + DHW) = vb;
             }
             if (gn_part) {
                 // per-channel (sum, sum of squares) of the RAW transformed accumulators over this wave's 2 x 64 voxels of the channel:
@@ -432,7 +548,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
                 if (j == 0) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int co = co0 + m * 32 + 8 * p + 4 * kgl + i;
+                        const int co = co0 + m * 32 + 8 * p + 4 * kgl + i + tz;
                         *reinterpret_cast<float2 *>(gn_part + ((size_t)co * gn_rows + (size_t)etile * 2 + ch) * 2) = make_float2(ssum[i], qsum[i]);
                     }
                 }
@@ -442,7 +558,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 
         WPROF_ADD(6)
         if (has_next) {
-            WN_WRITE_X(0);   // the next tile's first halo chunk (prefetched during this tile's last chunk)
+            if (fuse_in) { WN_WRITE_X(0, true) } else { WN_WRITE_X(0, false) }   // the next tile's first halo chunk (prefetched during this tile's last chunk)
             WPROF_ADD(4)
             lds_barrier();
 #pragma unroll
@@ -453,8 +569,10 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #undef WN_LOAD_X
 #undef WN_WRITE_X
 #undef WN_TOFF
-    if (__builtin_amdgcn_ballot_w64(sat_ != 0) != 0) {  // never taken in normal operation
-        unsigned tot = sat_;
+    // operands outside the f16 range (non-finite inputs, or finite ones beyond a wrong caller-supplied descriptor) are not clamped — they
+    // propagate as Inf / NaN — but they are counted: here per thread that saw any (the direct kernel counts elements)
+    if (__builtin_amdgcn_ballot_w64(!(xmax_ <= 0.5f * F16_CLAMP)) != 0) {  // never taken in normal operation (NaN -> counted)
+        unsigned tot = !(xmax_ <= 0.5f * F16_CLAMP);
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft, 64);
         if (lane == 0) atomicAdd(&g_f16x3_wino_saturated, (unsigned long long)tot);

@@ -228,7 +228,7 @@ const void *packed(Ctx &c, ConvW &cw, int prec) {
 // measurement: bracket the NEXT conv launch (the conv kernel itself) with a pair of events of the given kind
 void prof_arm(Ctx &c, const ConvW &cw, int d, int h, int w, int kind) {
     Plan *p = c.p;
-    if (c.dry || !p->profile || cw.ci != 96 || cw.co != 96 || cw.k != 3 || d != p->D || h != p->H || w != p->W) return;
+    if (c.dry || c.rc != MPHIP_OK /* the launch this would time is skipped (RUN): do not arm */ || !p->profile || cw.ci != 96 || cw.co != 96 || cw.k != 3 || d != p->D || h != p->H || w != p->W) return;
     if (p->prof_used[kind] + 2 > p->prof_ev[kind].size())
         for (int i = 0; i < 2; ++i) {
             hipEvent_t e;

@@ -484,19 +484,36 @@ class _HotSliceRunner:
 
         # one plan per caller stream: a plan owns ONE side stream and one fork/join event pair, so callers that keep several batches in
         # flight on several streams get independent generator lanes (and their own packed weights: ~230 MB per plan)
-        key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators), bool(self.full_final_conv),
-               torch.cuda.current_stream(vs.device).cuda_stream)
+        shape_key = (tuple(vs.shape[1:]), vs.device, bool(self.overlap_generators), bool(self.full_final_conv))
+        key = shape_key + (torch.cuda.current_stream(vs.device).cuda_stream,)
         table = self.__dict__.setdefault("_plans", {})
+        if torch.cuda.is_current_stream_capturing():
+            # torch.cuda.graph() switches to its own capture stream: a plan made HERE would hipMalloc, copy tables synchronously and pack
+            # weights inside the capture (illegal, or recorded into every replay).  Take the plan that was warmed up for this shape —
+            # its launches go to whatever stream is current — and refuse to build one while capturing.  
+            for k in reversed(list(table)):
+                if k[:len(shape_key)] == shape_key:
+                    return table[k]
+            raise RuntimeError("GbaseHotSlice: no warmed-up plan for this shape while a stream is capturing — run one forward of the same "
+                               "shape before torch.cuda.graph() (model.GraphedHotSlice does)")
         pl = table.pop(key, None)
         if pl is None:
             pl = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators,
                                     full_final_conv=self.full_final_conv)
+            if len(table) >= 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 and not _HotSliceRunner._warned_queues:
+                _HotSliceRunner._warned_queues = True
+                logging.warning("mphip: several batches in flight (one plan per caller stream = 2 HIP streams each) but GPU_MAX_HW_QUEUES=%s: "
+                                "the ROCm runtime multiplexes streams onto that many in-order hardware queues, so one batch's generator chain "
+                                "waits behind another's convs (measured: 3.65 -> 3.55 ms per step with 8).  Export GPU_MAX_HW_QUEUES=8 before "
+                                "the HIP runtime starts (importing megaportrait_hack_amd before the first CUDA call does it).",
+                                os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"))
         table[key] = pl   # (most recently used last)
         while len(table) > self._MAX_PLANS:   # a caller that keeps making new streams must not keep every plan's packed weights
             torch.cuda.synchronize(vs.device)
             table.pop(next(iter(table))).close()
         return pl
 
+    _warned_queues = False
     _MAX_PLANS = 6
 
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):

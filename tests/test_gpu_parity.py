@@ -981,7 +981,7 @@ def test_bench_line_contract_on_one_gpu():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "2", "--no-cpu-baseline",
-                        "--extras-budget", "1"], capture_output=True, text=True, timeout=900)
+                        "--extras-budget", "1", "--repeats", "2"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -1002,3 +1002,10 @@ def test_bench_line_contract_on_one_gpu():
     assert one["dominant_conv"]["launch_ms"] == roof["launch_ms"] and roof["in_two_batch_loop"]["launches_timed"] == 4
     assert one["value"] > 0 and one["step_ms"]["min"] <= one["step_ms"]["median"] <= one["step_ms"]["max"]
     assert roof["demand_driven_launch"]["launches_timed"] == 2
+    # the graded shape runs in the F(2,3) domain: 2 f16 FLOPs issued per algorithmic FLOP (3 split products x 2/3)
+    assert "wino" in roof["kernel"] and roof["f16_flops_issued_per_algorithmic_flop"] == 2.0
+    # counters are quoted only when stamped with the sources of this build (tools/collect_profiles.sh)
+    assert (roof["traffic"] is None) == bool(roof["stale"])
+    reps = line["repeats"]
+    assert len(reps["ms_per_step"]) == 2 and reps["min"] <= reps["median"] <= reps["max"]
+    assert "hot_slice_tflops" not in line and line["hot_slice_tflops_executed"] < line["hot_slice_tflops_reference_graph"]

@@ -199,6 +199,31 @@ def test_plan_graph_capture(dev, M):
     assert torch.equal(out, want)
 
 
+def test_graphed_hot_slice_goes_through_the_warmed_plan(dev, M):
+    """model.GraphedHotSlice with the default C-plan path: it warms up on a side stream and captures under
+    torch.cuda.graph(), which switches to a separate capture stream — the plan that was warmed up must be the one that is captured (a
+    plan built during the capture would hipMalloc / copy synchronously / pack weights inside it), replays must follow new inputs and
+    equal the eager forward bit for bit, and asking for an unseen shape while capturing must fail loudly."""
+    hot = _hot(M, dev)
+    assert hot.use_c_plan
+    inp = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 5, D=8, H=16, W=16).items()}
+    inp2 = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 9, D=8, H=16, W=16).items()}
+    with torch.no_grad():
+        want, want2 = hot.forward_any_size(**inp).clone(), hot.forward_any_size(**inp2).clone()
+    plans_before = len(hot.__dict__.get("_plans", {}))
+    graphed = M.GraphedHotSlice(hot, inp, any_size=True)
+    assert len(hot.__dict__["_plans"]) == plans_before + 1          # the warm-up stream's plan; none created under capture
+    assert torch.equal(graphed(**inp), want)
+    assert torch.equal(graphed(**inp2), want2)
+    assert torch.equal(graphed(**inp), want)
+    other = {k: v.to(dev) for k, v in R.seeded_hot_inputs(2, 5, D=8, H=16, W=32).items()}
+    g = torch.cuda.CUDAGraph()
+    with pytest.raises(RuntimeError, match="no warmed-up plan"):
+        with torch.no_grad(), torch.cuda.graph(g):
+            hot.forward_any_size(**other)
+    torch.cuda.synchronize()
+
+
 def test_plan_from_plain_c(plan_c_exe):
     """tests/c_abi/plan_smoke.c: K2 coordinates / indices / values bit-exact vs the C oracle, K3, an f16x3 3x3x3 conv with a
     caller-built range descriptor, and the whole slice through mphip_hot_slice_plan_* against the committed oracle golden

@@ -174,3 +174,32 @@ def test_bench_self_launches_ranks():
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
     assert lines == [{"stub_worker": True, "ranks": 2, "n_gpus": 2, "sum": 3.0}]   # exactly ONE line, from rank 0
+
+
+def test_hot_kernels_have_no_scratch():
+    """the kernels the default schedule launches on the hot path must not touch scratch memory — a spilled
+    register in a persistent MFMA kernel is a round trip to HBM-backed memory per tile.  Compiles the four hot translation
+    units to gfx950 assembly (no GPU needed, ~1 minute) and reads hipcc's kernel metadata (tools/register_table.py; the
+    per-round table is profiles/rNN_register_tables.json).  One documented exception: the direct kernel's 512-voxel-tile
+    instantiation <4,8,16,8,1> — since r04 a fallback (layers the F(2,3) kernel takes no longer reach it: Ci <= 256 on launches
+    that fill the chip) whose 60-odd spilled registers sit in its per-tile prologue / epilogue; its scratch must not grow."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import register_table
+
+    table = register_table.collect(["conv3d_f16x3_wino.hip", "conv3d_f16x3.hip", "conv3d_bwd_f16x3.hip", "warp.hip"])
+    kernels = {k["demangled"]: k for t in table.values() for k in t["kernels"]}
+    hot = [n for n in kernels if any(s in n for s in ("conv3d_k3_f16x3_wino_kernel", "conv3d_k3_f16x3_kernel", "conv3d_k3_f16x3_third_kernel",
+                                                       "conv3d_k1_f16x3_kernel", "conv_bwd_weight_f16x3_kernel", "conv_bwd_weight_k1_f16x3_kernel",
+                                                       "warp_gather", "warp_coords_kernel", "warp_field_coords_kernel"))]
+    assert len(hot) >= 12, sorted(kernels)
+    fallback = "conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>"
+    for n in hot:
+        scratch = kernels[n].get("private_segment_fixed_size", 0)
+        if fallback in n:
+            assert scratch <= 256, (n, scratch)
+        else:
+            assert scratch == 0 and kernels[n].get("vgpr_spill_count", 0) == 0, (n, kernels[n])
+    wino = next(k for n, k in kernels.items() if "conv3d_k3_f16x3_wino_kernel" in n)
+    assert wino["group_segment_fixed_size"] <= 160 * 1024 and wino["vgpr_count"] <= 256

@@ -13,11 +13,22 @@ KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr
 
 
 def demangle(names):
-    try:
-        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, check=True).stdout
-        return out.strip().splitlines()
-    except Exception:
-        return list(names)
+    """kernel name + integer template arguments, e.g. conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1> (binutils' c++filt does not know the _Float16
+    mangling DF16_ in the argument lists, so the names are decoded here: _ZN5mphip<len><name>[I<Li..E / Lb..E>...E]...)."""
+    out = []
+    for n in names:
+        m = re.match(r"_ZN5mphip(\d+)", n)
+        if not m:
+            out.append(n)
+            continue
+        ln = int(m.group(1))
+        base, rest = n[m.end():m.end() + ln], n[m.end() + ln:]
+        args = ""
+        if rest.startswith("I"):
+            vals = re.findall(r"L[ib](\d+)E", rest[:rest.index("EE") + 1] if "EE" in rest else rest)
+            args = "<" + ", ".join(vals) + ">"
+        out.append(base + args)
+    return out
 
 
 def one(path):
@@ -57,7 +68,7 @@ def one(path):
                 k[key[1:]] = int(mm.group(1))
         kernels.append(k)
     for k, d in zip(kernels, demangle([k["name"] for k in kernels])):
-        k["demangled"] = re.sub(r"\(.*$", "", d)
+        k["demangled"] = d
     return {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "kernels": kernels}
 
 
