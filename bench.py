@@ -374,12 +374,8 @@ def roofline_hbm(hot, inp, B):
         w_s2c = hot.warp_generator_s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
     table = {"faithful": w_s2c, "smooth": BW.fields(B)["smooth"]}
     res = BW.measure(B, iters=20, quiet=True, field_override=table)
-    try:
-        name = "r03_pmc_warps.json" if os.path.isfile(os.path.join(ROOT, "profiles", "r03_pmc_warps.json")) else "r02_pmc_warps.json"
-        with open(os.path.join(ROOT, "profiles", name)) as f:
-            pmc = json.load(f)["kernels"]
-    except Exception:
-        pmc = {}
+    rec_, stale = pmc_record("r04_pmc_warps.json", ["warp.hip"])   # (counters are quoted only when stamped with this build's warp.hip)
+    pmc = rec_.get("kernels", {}) if rec_ else {}
     out = {}
     for key, rec in res.items():
         kname, kind = key.split(" / ")
@@ -398,7 +394,7 @@ def roofline_hbm(hot, inp, B):
             "kernels": kernels, "bound": "hbm", "launch_ms": rec["ms"], "achieved": counted if counted else rec["algorithmic_GBps"],
             "peak": 8000.0, "unit": "GB/s", "frac": round(counted / 8000.0, 4) if counted else rec["frac_of_8TBps"],
             "accounting": "counted bytes (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/)" if counted else "algorithmic bytes",
-            "traffic": traffic, "algorithmic_GBps": rec["algorithmic_GBps"], "algorithmic_frac": rec["frac_of_8TBps"]}
+            "traffic": traffic, "stale": bool(stale), "algorithmic_GBps": rec["algorithmic_GBps"], "algorithmic_frac": rec["frac_of_8TBps"]}
     return out
 
 
