@@ -448,6 +448,10 @@ int mphip_conv3d_kernel_variant(int N, int Ci, int Co, int D, int H, int W, int 
  * workgroups * 8 * iters * 162 MFMAs (32768 FLOP each); sink: >= workgroups * 512 floats (keeps the result alive).        */
 int mphip_debug_mfma_sol(float *sink, int workgroups, int iters, int mode, void *stream);
 
+/* Measurement only (tools/dma_stream.py): LDS-DMA streaming of an L2-resident tensor of `slabs_in_tensor` 24-KiB slabs the way the F(2,3) conv
+ * streams its weights (8 waves x 3 pieces per slab, ring of four, a wave waits for the pieces it issued `lag` slabs ago, optional barrier).      */
+int mphip_debug_dma_stream(const void *weights, int slabs_in_tensor, int slabs, int lag, int barrier, float *sink, int workgroups, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

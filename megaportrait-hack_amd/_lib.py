@@ -106,6 +106,7 @@ SIGNATURES = {
     "mphip_hot_slice_plan_destroy": (None, [_p]),
     "mphip_debug_mfma_sol": (_i, [_p, _i, _i, _i, _p]),
     "mphip_conv3d_kernel_variant": (_i, [_i] * 8),
+    "mphip_debug_dma_stream": (_i, [_p, _i, _i, _i, _i, _p, _i, _p]),
 }
 
 _lib = None

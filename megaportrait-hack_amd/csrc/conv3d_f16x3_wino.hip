@@ -173,12 +173,28 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             return (unsigned)((((long)n * Ci + 2 * cp) * DHW + (long)gd * HW + gh * W + w0) * 4);
         return OOB;
     };
+#ifdef MPHIP_WN_ABL_NOXLOAD   /* dev (timing only, wrong results): the halo loads are issued out of range — no cache / memory access behind them */
+#define WN_ABL_XOFF(o__) (tiles_total > 0 ? OOB : (o__))
+#else
+#define WN_ABL_XOFF(o__) (o__)
+#endif
+#ifdef MPHIP_WN_ABL_NOXLOAD   /* ... and the registers get pseudo-random values instead (all-zero operands would also make the MFMAs cheaper) */
+#define WN_ABL_FAKE_X(chunk)                                                                               \
+    {                                                                                                      \
+        unsigned h_ = (unsigned)tid * 2654435761u + (unsigned)(chunk) * 40503u + (unsigned)d0 * 977u;      \
+        auto nx_ = [&]() { h_ = h_ * 1664525u + 1013904223u; return ((float)(h_ >> 8) * (1.0f / 8388608.0f) - 1.0f) * 2.0f; }; \
+        _Pragma("unroll") for (int k = 0; k < 4; ++k) { xa0[k] += nx_(); xb0[k] += nx_(); xa1[k] += nx_(); xb1[k] += nx_(); } \
+        xl0 += nx_(); xr0 += nx_(); xl1 += nx_(); xr1 += nx_();                                            \
+    }
+#else
+#define WN_ABL_FAKE_X(chunk)
+#endif
     f32x4 xa0, xb0, xa1, xb1;   // channels 2cp / 2cp+1: voxels w0..w0+3, w0+4..w0+7
     float xl0, xr0, xl1, xr1;   // ... w0-1, w0+8
 #define WN_LOAD_X(chunk)                                                                                   \
     {                                                                                                      \
         const unsigned soff_ = (unsigned)((long)(chunk) * WN_KC * DHW * 4);                                \
-        const unsigned o_ = row_off();                                                                     \
+        const unsigned o_ = WN_ABL_XOFF(row_off());                                                        \
         const unsigned o1_ = o_ == OOB ? OOB : o_ + chan_stride;                                           \
         const bool lft_ = o_ != OOB && w0 > 0, rgt_ = o_ != OOB && w0 + WN_TW < W;                         \
         xa0 = buf_load_f4(rsrc, o_, soff_);                                                                \
@@ -189,8 +205,10 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         xr0 = buf_load_f(rsrc, rgt_ ? o_ + 32u : OOB, soff_);                                              \
         xl1 = buf_load_f(rsrc, lft_ ? o1_ - 4u : OOB, soff_);                                              \
         xr1 = buf_load_f(rsrc, rgt_ ? o1_ + 32u : OOB, soff_);                                             \
+        WN_ABL_FAKE_X(chunk)                                                                               \
     }
-    float xmax_ = 0.0f;   // max |scaled halo value| this thread staged: beyond 2^15 the transformed values can leave the f16 range
+    unsigned xmax_ = 0;   // max |scaled halo value| this thread staged, as bits (NaN sorts above Inf above finite): beyond 2^15 the
+                          // transformed values can leave the f16 range
     // registers -> (fused GroupNorm + ReLU) -> scale -> F(2,3) input transform -> split -> LDS
 #ifdef MPHIP_WN_ABL_NOWRITE   /* dev (timing only, wrong results): no halo transform / split / LDS stores */
 #define WN_STAGER_ON (stager && tiles_total < 0)
@@ -221,7 +239,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         }                                                                                                  \
         _Pragma("unroll") for (int i = 0; i < 10; ++i) {                                                   \
             v_[i] *= x_scale;                                                                              \
-            xmax_ = fmaxf(fmaxf(xmax_, fabsf(v_[i][0])), fabsf(v_[i][1]));   /* (v_max3_f32; a NaN is caught by the hi halves below) */ \
+            xmax_ = max(xmax_, max(__float_as_uint(v_[i][0]) & 0x7fffffffu, __float_as_uint(v_[i][1]) & 0x7fffffffu));   /* |bits|: NaN > Inf > finite */ \
         }                                                                                                  \
         _Float16 *xd_ = Xs + (cp >> 2) * WN_XBLK + srow * 32 + (cp & 3) * 2;                               \
         _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                    \
@@ -571,8 +589,9 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #undef WN_TOFF
     // operands outside the f16 range (non-finite inputs, or finite ones beyond a wrong caller-supplied descriptor) are not clamped — they
     // propagate as Inf / NaN — but they are counted: here per thread that saw any (the direct kernel counts elements)
-    if (__builtin_amdgcn_ballot_w64(!(xmax_ <= 0.5f * F16_CLAMP)) != 0) {  // never taken in normal operation (NaN -> counted)
-        unsigned tot = !(xmax_ <= 0.5f * F16_CLAMP);
+    const unsigned xlim_ = __float_as_uint(0.5f * F16_CLAMP);
+    if (__builtin_amdgcn_ballot_w64(xmax_ > xlim_) != 0) {  // never taken in normal operation
+        unsigned tot = xmax_ > xlim_;
 #pragma unroll
         for (int sft = 32; sft >= 1; sft >>= 1) tot += __shfl_xor(tot, sft, 64);
         if (lane == 0) atomicAdd(&g_f16x3_wino_saturated, (unsigned long long)tot);

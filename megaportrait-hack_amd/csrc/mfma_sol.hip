@@ -99,3 +99,38 @@ extern "C" int mphip_debug_mfma_sol(float *sink, int workgroups, int iters, int 
         hipLaunchKernelGGL(mphip::mfma_sol_kernel<0>, dim3(workgroups), dim3(512), 0, (hipStream_t)stream, sink, iters);
     return mphip::check_launch("mfma_sol");
 }
+
+// Measurement only: the rate at which a workgroup can stream an L2-resident weight tensor into LDS by LDS-DMA the way the F(2,3) conv
+// does (8 waves x 3 pieces of 1 KiB per 24 KiB slab, ring of four slabs, a wave waits for the pieces it issued `lag` slabs ago, optional
+// barrier per slab).  No MFMAs, no LDS reads: the ceiling of the weight stream alone.
+namespace mphip {
+template <int LAG, int BARRIER>
+__global__ void __launch_bounds__(512) dma_stream_kernel(const _Float16 *__restrict__ w, int slabs_in_tensor, int slabs, float *__restrict__ sink) {
+    __shared__ __attribute__((aligned(16))) _Float16 ring[4 * 12288];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)ring;
+    const _Float16 *src0 = w + lane * 8 + wave * 512;
+    for (int s = 0; s < slabs; ++s) {
+        const _Float16 *src = src0 + (size_t)(s % slabs_in_tensor) * 12288;
+        const unsigned dst = lds0 + (unsigned)(s & 3) * 24576u + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) lds_dma16(src + q * 8 * 512, dst + (unsigned)q * 8192u);
+        lds_dma_wait<3 * LAG>();
+        if (BARRIER) lds_barrier();
+    }
+    lds_dma_wait<0>();
+    __syncthreads();
+    sink[blockIdx.x * 512 + threadIdx.x] = (float)ring[threadIdx.x];
+}
+}  // namespace mphip
+
+extern "C" int mphip_debug_dma_stream(const void *weights, int slabs_in_tensor, int slabs, int lag, int barrier, float *sink, int workgroups, void *stream) {
+    MPHIP_REQUIRE(weights && sink && slabs > 0 && slabs_in_tensor > 0 && workgroups > 0, "dma_stream: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const _Float16 *w = (const _Float16 *)weights;
+#define DS_LAUNCH(L_, B_) hipLaunchKernelGGL((mphip::dma_stream_kernel<L_, B_>), dim3(workgroups), dim3(512), 0, s, w, slabs_in_tensor, slabs, sink)
+    if (lag == 1 && barrier) DS_LAUNCH(1, 1); else if (lag == 2 && barrier) DS_LAUNCH(2, 1); else if (lag == 3 && barrier) DS_LAUNCH(3, 1);
+    else if (lag == 1) DS_LAUNCH(1, 0); else if (lag == 2) DS_LAUNCH(2, 0); else DS_LAUNCH(3, 0);
+#undef DS_LAUNCH
+    return mphip::check_launch("dma_stream");
+}

@@ -210,6 +210,69 @@ def test_conv3d_f16x3_is_fp32_class(ops, _libmod, dev, case, stress):
         assert e16 < 2 * e32 + 1e-6 and e16 < 1e-5
 
 
+WINO_CASES = [(1, 96, 96, 16, 64, 64), (8, 96, 192, 8, 32, 32), (8, 192, 192, 8, 32, 32), (8, 192, 96, 8, 32, 32), (3, 96, 96, 16, 64, 64),
+              (1, 256, 96, 16, 64, 64)]
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_f16x3_winograd_domain_is_fp32_class(ops, _libmod, dev, case):
+    """The launches that fill the chip run the split-f16 arithmetic in the 1-D Winograd F(2,3) domain (conv3d_f16x3_wino.hip: 2/3 of the
+    MFMAs; G3d's levels 0-1 at the graded batch, Eapp's 3-D tail).  Same bar as the direct kernel: against the fp64 truth no worse than
+    twice the exact-fp32 MFMA kernel's own rounding; the GroupNorm statistics its epilogue leaves (the partials of its two plane pairs
+    per tile) against float64 statistics of the truth; the direct kernel (MPHIP_WINOGRAD=0) beside it; and — bwd-data is the same kernel
+    on the transposed pack — the input gradient against conv_transpose3d in float64."""
+    N, Ci, Co, D, H, W = case
+    lib = _libmod.load()
+    assert lib.mphip_conv3d_kernel_variant(N, Ci, Co, D, H, W, 3, 1) == 5      # the F(2,3) kernel takes this shape
+    x = R.seeded_tensor((N, Ci, D, H, W), 431, scale=1.7)
+    wt = R.seeded_tensor((Co, Ci, 3, 3, 3), 432, scale=(Ci * 27) ** -0.5)
+    bias = R.seeded_tensor((Co,), 433, scale=0.1)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    truth = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    xd = x.to(dev)
+    e32 = maxabs(ops.conv3d(xd, pc, precision=0), truth)
+    y, st = ops.conv3d(xd, pc, precision=1, gn_groups=32)
+    ew = maxabs(y, truth)
+    os.environ["MPHIP_WINOGRAD"] = "0"
+    try:
+        assert lib.mphip_conv3d_kernel_variant(N, Ci, Co, D, H, W, 3, 1) in (1, 2)
+        ed = maxabs(ops.conv3d(xd, pc, precision=1), truth)
+    finally:
+        del os.environ["MPHIP_WINOGRAD"]
+    print(f"max-abs vs fp64: fp32-MFMA {e32:.2e}, direct f16x3 {ed:.2e}, F(2,3) f16x3 {ew:.2e} (max|y| = {truth.abs().max().item():.1f})")
+    assert ew < 2 * e32 + 1e-6 and ew < 2e-5
+    tr = truth.reshape(N, 32, -1)
+    assert maxabs(st[:, 0], tr.mean(-1).reshape(-1)) < 1e-6
+    assert maxabs(st[:, 1], (1.0 / torch.sqrt(tr.var(-1, unbiased=False) + 1e-5)).reshape(-1)) < 1e-5
+    # bwd-data: dy [N,Co,..] -> dx [N,Ci,..] when that launch fills the chip too
+    if lib.mphip_conv3d_kernel_variant(N, Co, Ci, D, H, W, 3, 1) == 5:
+        dy = R.seeded_tensor((N, Co, D, H, W), 434, scale=3e-3)
+        dy[:, :, : D // 2] *= 1e-3                                            # a gradient's dynamic range
+        want = F.conv_transpose3d(dy.double(), wt.double(), padding=1)
+        _, scale = ops.grad_prep(dy.to(dev), want_bias=False)
+        dx = ops.conv3d_bwd_data(dy.to(dev), ops.PackedConv(wt.to(dev), None, transposed=True), scale)
+        assert maxabs(dx, want) / want.abs().max().item() < 3e-6
+
+
+def test_conv3d_f16x3_winograd_propagates_non_finite(ops, _libmod, dev):
+    """test_f16x3_propagates_non_finite at a shape the F(2,3) kernel takes: a NaN / Inf input poisons exactly the output voxels the
+    reference's fp32 conv poisons (the transform mixes x[w-1..w+2] into one output pair, but a pair's two outputs use different
+    products: no extra voxel turns non-finite), everything else stays fp32-class, and the diagnostic counter sees it."""
+    x = R.seeded_tensor((1, 96, 16, 64, 64), 835, scale=1.7)
+    w = R.seeded_tensor((96, 96, 3, 3, 3), 836, scale=0.02)
+    assert _libmod.load().mphip_conv3d_kernel_variant(1, 96, 96, 16, 64, 64, 3, 1) == 5
+    pc = ops.PackedConv(w.to(dev), None)
+    for bad, pos in ((float("nan"), (0, 7, 1, 4, 9)), (float("inf"), (0, 50, 15, 63, 0)), (float("-inf"), (0, 3, 8, 17, 63))):
+        xb = x.clone()
+        xb[pos] = bad
+        ops.f16x3_saturation_count(reset=True)
+        got = ops.conv3d(xb.to(dev), pc, precision=1).cpu()
+        want = F.conv3d(xb, w, None, padding=1)
+        assert torch.equal(torch.isfinite(got), torch.isfinite(want))
+        assert (got[torch.isfinite(want)] - want[torch.isfinite(want)]).abs().max().item() < 1e-4
+        assert ops.f16x3_saturation_count(reset=True) >= 1
+
+
 def test_conv3d_vs_c_oracle(ops, dev, oracle_c):
     x = R.seeded_tensor((1, 24, 3, 6, 5), 411, scale=1.7)
     wt = R.seeded_tensor((40, 24, 3, 3, 3), 412, scale=0.04)
