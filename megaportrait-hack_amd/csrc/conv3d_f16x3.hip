@@ -955,7 +955,7 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     }
     const char *force_sp = getenv("MPHIP_F16X3_SPLITS");   // dev: planner sweep (tools/sweep_conv_plans.py)
     if (force_sp && atoi(force_sp) > 0 && nchunks % atoi(force_sp) == 0) sp = atoi(force_sp);   // (whole chunks per split only)
-    if (p.variant == 4) sp = 1;   // (the transformed-domain kernel has no split-K form; it only takes launches that fill the chip)
+    if (p.variant == 4) sp = f16x3_wino_splits(N, Ci, Co, D, H, W);
     p.splits = sp;
     p.chunks_per_split = (nchunks + sp - 1) / sp;
     p.grid = dim3((unsigned)tiles, Co / F16X3_COT, sp);
@@ -1033,12 +1033,12 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
         roi = tile_list;
     }
     if (p.variant == 4) {   // the 1-D Winograd F(2,3) kernel (full launches and demand-driven ones alike: a listed tile carries the full launch's bits)
-        if (in_affine && Ci > 256) {
-            set_error("conv3d_fwd(f16x3, F(2,3)): fused input GroupNorm supports Ci <= 256 (got %d)", Ci);
+        if (in_affine && Ci > 384) {
+            set_error("conv3d_fwd(f16x3, F(2,3)): fused input GroupNorm supports Ci <= 384 (got %d)", Ci);
             return MPHIP_EINVAL;
         }
-        return f16x3_wino_launch(x, (const char *)wpacked + f16x3_direct_bytes(Co, Ci), hdr, bias, dst, N, Ci, Co, D, H, W, in_affine,
-                                 in_relu, x_scale, s, roi, gn_part, t0, t1);
+        return f16x3_wino_launch(x, (const char *)wpacked + f16x3_direct_bytes(Co, Ci), hdr, bias, dst, N, Ci, Co, D, H, W, p.splits,
+                                 in_affine, in_relu, x_scale, s, roi, gn_part, t0, t1);
     }
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles

@@ -51,7 +51,7 @@ constexpr int WN_XBLK = WN_ROWS * 4 * 8 + 16;              // halfs per (part, p
                                                            // + 32 B so that the two k-groups of a staging write sit 8 banks apart
 constexpr int WN_XPART = 4 * 2 * WN_XBLK;                  // halfs per part (hi or lo)
 constexpr int WN_X_HALFS = 2 * WN_XPART;                   // 30976 halfs = 61952 B
-constexpr int WN_AFF_CI = 256;                             // fused input GroupNorm table: Ci <= 256 (LDS: 98304 + 61952 + 2048 B)
+constexpr int WN_AFF_CI = 384;                             // fused input GroupNorm table: Ci <= 384 (LDS: 98304 + 61952 + 3072 B + the range fold's 68)
 constexpr int WN_XLOADS = 8;                               // vector-memory instructions of one halo prefetch (per wave)
 
 // ---- weight packing: OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*9 + (kd*3+kh)][part][position][kg][co][8] f16 ----
@@ -116,8 +116,9 @@ __device__ unsigned long long g_f16x3_wino_prof[8];
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                             const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
-                            unsigned x_bytes, const float *__restrict__ in_affine, int in_relu, const float *__restrict__ x_range,
-                            int tiles_total, int xcd_aware, const int *__restrict__ tile_list, float *__restrict__ gn_part) {
+                            int chunks_per_split, unsigned x_bytes, const float *__restrict__ in_affine, int in_relu,
+                            const float *__restrict__ x_range, int tiles_total, int xcd_aware, const int *__restrict__ tile_list,
+                            float *__restrict__ gn_part) {
     __shared__ __attribute__((aligned(16))) _Float16 smem[WN_RING * WN_SLAB_HALFS + WN_X_HALFS + WN_AFF_CI * 4];
     _Float16 *const Ws = smem;                                   // ring of 4 slabs
     _Float16 *const Xs = smem + WN_RING * WN_SLAB_HALFS;         // [part][position][kg][row*4 + pair][8]
@@ -152,8 +153,12 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     decode_tile(tile_at(j_first));
     const int cot = blockIdx.y;
     const int nchunks = Ci / WN_KC;
+    // split-K (blockIdx.z): launches that cannot give every CU a tile split the input channels in whole chunks; the output transform is
+    // linear, so every split transforms its own partial sums and writes them to its slab [z][N,Co,DHW] (bias added by the ordered reduce)
+    const int c_begin = blockIdx.z * chunks_per_split, c_end = min(nchunks, c_begin + chunks_per_split);
+    if (c_begin >= c_end) return;
     const int nmine = (ntiles - j_first + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles this workgroup walks
-    const int s_total = nmine * nchunks * WN_NG;                                   // slabs it consumes
+    const int s_total = nmine * (c_end - c_begin) * WN_NG;                         // slabs it consumes
 
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)x, 0, (int)x_bytes, 0x00020000);
     const unsigned chan_stride = (unsigned)DHW * 4u;
@@ -258,8 +263,8 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     // ---- weight stream: slab s of this workgroup = (chunk (s / 9) % nchunks, group s % 9), ring slot s & 3 ---------------------
     const unsigned ws_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) _Float16 *)Ws;
     const _Float16 *const wsrc = wslabs + (size_t)cot * nchunks * WN_NG * WN_SLAB_HALFS + (size_t)lane * 8;
-    int dma_s = 0, dma_cg = 0;   // slabs issued so far; its (chunk*9 + group) index into the packed tensor
-    const int cg_total = nchunks * WN_NG;
+    int dma_s = 0, dma_cg = c_begin * WN_NG;   // slabs issued so far; its (chunk*9 + group) index into the packed tensor
+    const int cg_total = c_end * WN_NG;
     auto dma_issue = [&]() -> int {   // 3 pieces of 1 KiB per wave; returns the number of vector-memory instructions issued
 #ifdef MPHIP_WN_ABL_NODMA   /* dev (timing only, wrong results): no weight stream */
         ++dma_s;
@@ -271,7 +276,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #pragma unroll
         for (int q = 0; q < 3; ++q) lds_dma16(src + q * 8 * 512, dst + (unsigned)q * 8192u);
         ++dma_s;
-        if (++dma_cg == cg_total) dma_cg = 0;
+        if (++dma_cg == cg_total) dma_cg = c_begin * WN_NG;
         return 3;
     };
 
@@ -295,8 +300,8 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     dma_issue();
     dma_issue();
     dma_issue();
-    WN_LOAD_X(0);
-    if (fuse_in) { WN_WRITE_X(0, true) } else { WN_WRITE_X(0, false) }
+    WN_LOAD_X(c_begin);
+    if (fuse_in) { WN_WRITE_X(c_begin, true) } else { WN_WRITE_X(c_begin, false) }
     lds_dma_wait<0>();
     lds_barrier();
 
@@ -309,6 +314,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 
     const float unscale = whdr[0] * x_unscale;
     const int co0 = cot * WN_COT;
+    const bool direct = gridDim.z == 1;
     WPROF_ADD(0)
 
     for (int tj = j_first; tj < ntiles; tj += (int)gridDim.x) {
@@ -325,10 +331,10 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
 
-        for (int c = 0; c < nchunks; ++c) {
-            const bool more = c + 1 < nchunks;
+        for (int c = c_begin; c < c_end; ++c) {
+            const bool more = c + 1 < c_end;
             const bool do_load = more || has_next;   // a halo prefetch is issued in this chunk's interval 2 (uniform)
-            const int load_chunk = more ? c + 1 : 0;
+            const int load_chunk = more ? c + 1 : c_begin;
             if (!more && has_next) {
                 decode_tile(tile_at(tj + (int)gridDim.x));   // staging now addresses the next tile
                 // (the affine table was last read by the WRITE_X that ended the previous chunk, a barrier ago)
@@ -481,7 +487,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #pragma unroll
                 for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(acc[m][t]));
             if (has_next) {
-                if (fuse_in) { WN_WRITE_X(0, true) } else { WN_WRITE_X(0, false) }
+                if (fuse_in) { WN_WRITE_X(c_begin, true) } else { WN_WRITE_X(c_begin, false) }
                 lds_barrier();
 #pragma unroll
                 for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
@@ -493,7 +499,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         if (gn_part && etile == 0 && tid == 0) gn_part[(size_t)gn_rows * Co * 2] = unscale;   // (behind the partials)
         const bool odd = (lane & 1) != 0;
         // (row start of this lane's QUAD of voxels: lanes 2k / 2k+1 store the 4 voxels 4k..4k+3 of a row, for different channels)
-        float *const dsto = y + (size_t)en * Co * DHW + (size_t)(ed0 + 2 * ch) * HW + (size_t)(eh0 + (j >> 2)) * W + ew0 + 2 * (j & 2);
+        float *const dsto = (direct ? y : y + (size_t)blockIdx.z * N * Co * DHW) + (size_t)en * Co * DHW + (size_t)(ed0 + 2 * ch) * HW + (size_t)(eh0 + (j >> 2)) * W + ew0 + 2 * (j & 2);
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
             // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of both column tiles; wave p keeps unit p
@@ -510,7 +516,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             float ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
             float bv[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = bias ? bias[co0 + m * 32 + 8 * p + 4 * kgl + i + tz] : 0.0f;
+            for (int i = 0; i < 4; ++i) bv[i] = (direct && bias) ? bias[co0 + m * 32 + 8 * p + 4 * kgl + i + tz] : 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
                 f32x4 M[4];
@@ -576,7 +582,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 
         WPROF_ADD(6)
         if (has_next) {
-            if (fuse_in) { WN_WRITE_X(0, true) } else { WN_WRITE_X(0, false) }   // the next tile's first halo chunk (prefetched during this tile's last chunk)
+            if (fuse_in) { WN_WRITE_X(c_begin, true) } else { WN_WRITE_X(c_begin, false) }   // the next tile's first halo chunk (prefetched during this tile's last chunk)
             WPROF_ADD(4)
             lds_barrier();
 #pragma unroll
@@ -615,7 +621,7 @@ static bool wino_enabled() {   // dev: same-box A/B against the direct kernel (r
 }
 
 // layers that can ever take the transformed-domain kernel get its slabs behind the direct pack (a weight tensor does not know the
-// volume it will meet): Ci <= 256 covers G3d's levels 0-1 and Eapp's 3-D tail, +133 % pack bytes on <= 4 MB tensors
+// volume it will meet): Ci <= 384 covers G3d's levels 0-2 and Eapp's 3-D tail, +133 % pack bytes on <= 16 MB tensors
 size_t f16x3_wino_packed_bytes(int Co, int Ci) {
     static const bool nopack = getenv("MPHIP_WINOGRAD_PACK") && getenv("MPHIP_WINOGRAD_PACK")[0] == '0';   // dev: bisecting (process-wide: set before the first pack)
     if (nopack) return 0;
@@ -623,13 +629,26 @@ size_t f16x3_wino_packed_bytes(int Co, int Ci) {
     return (size_t)(Co / WN_COT) * (Ci / WN_KC) * WN_NG * WN_SLAB_HALFS * sizeof(_Float16);
 }
 
+// split-K factor of a launch (whole chunks only): the largest divisor of the chunk count that keeps the launch inside ONE round of
+// resident workgroups (one per CU) — the direct kernel's r03 rule
+int f16x3_wino_splits(int N, int Ci, int Co, int D, int H, int W) {
+    const long base = (long)N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW) * (Co / WN_COT);
+    const int nchunks = Ci / WN_KC;
+    int sp = 1;
+    if (base < 256)
+        for (int dv = 2; dv <= nchunks; ++dv)
+            if (nchunks % dv == 0 && base * dv <= 256) sp = dv;
+    return sp;
+}
+
 bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W) {
     if (!wino_enabled() || f16x3_wino_packed_bytes(Co, Ci) == 0 || D % WN_TD || H % WN_TH || W % WN_TW) return false;
-    // one workgroup per CU: worth it only when the launch fills the chip (small launches are latency-, not energy-bound)
+    // one workgroup per CU, ~1 us per (kd,kh) slab: worth it when the launch (with its split-K factor) fills the chip and the direct
+    // kernel's advantage — a 512-voxel tile's weight economy, thirds of a tile per CU — does not apply (measured: tools/wino_check.py)
     const long tiles = (long)N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW);
     const char *min_s = getenv("MPHIP_WINOGRAD_MIN_TILES");   // dev: threshold sweep
-    const long min_tiles = min_s ? atol(min_s) : 256;
-    return tiles * (Co / WN_COT) >= min_tiles;
+    const long min_wgs = min_s ? atol(min_s) : 192;
+    return tiles * (Co / WN_COT) * f16x3_wino_splits(N, Ci, Co, D, H, W) >= min_wgs;
 }
 
 void f16x3_wino_pack(const float *w, void *slabs, const void *hdr, int Co, int Ci, int transposed, hipStream_t s) {
@@ -639,20 +658,21 @@ void f16x3_wino_pack(const float *w, void *slabs, const void *hdr, int Co, int C
 }
 
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
-                      int H, int W, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, const int *tile_list,
+                      int H, int W, int splits, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, const int *tile_list,
                       float *gn_part, hipEvent_t t0, hipEvent_t t1) {
     const int tiles = N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW), cots = Co / WN_COT;
-    long gx = (256L + cots - 1) / cots;   // persistent: one workgroup per CU
+    long gx = (256L + cots * splits - 1) / (cots * splits);   // persistent: one workgroup per CU
     if (gx > tiles) gx = tiles;
-    const dim3 grid((unsigned)gx, (unsigned)cots, 1);
+    const dim3 grid((unsigned)gx, (unsigned)cots, (unsigned)splits);
+    const int cps = (Ci / WN_KC + splits - 1) / splits;
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');
     if (t0 && t1)
         hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, t0, t1, 0, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci,
-                              Co, D, H, W, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
+                              Co, D, H, W, cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
     else
         hipLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W,
-                           xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
+                           cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
     return check_launch("conv3d_fwd(f16x3, F(2,3))");
 }
 

@@ -368,15 +368,18 @@ __device__ __forceinline__ void gather8x4(const float *__restrict__ img, const T
     const float4 q5 = *reinterpret_cast<const float4 *>(p + t.dz + t.dx);
     const float4 q6 = *reinterpret_cast<const float4 *>(p + t.dz + t.dy);
     const float4 q7 = *reinterpret_cast<const float4 *>(p + t.dz + t.dy + t.dx);
-#define MPHIP_ACC4(comp, k)                                                                        \
-    {                                                                                              \
-        float a_ = 0.0f;                                                                           \
-        a_ += q0.comp * tw[0]; a_ += q1.comp * tw[1]; a_ += q2.comp * tw[2]; a_ += q3.comp * tw[3];     \
-        a_ += q4.comp * tw[4]; a_ += q5.comp * tw[5]; a_ += q6.comp * tw[6]; a_ += q7.comp * tw[7];     \
-        out[k] = a_;                                                                               \
+    // channel pairs on the packed fp32 pipe (v_pk_mul_f32 / v_pk_add_f32: per channel still acc = 0; acc += q_k * w_k in tap order,
+    // one rounding per op — the same bits as the scalar sequence at half the instructions; K3 on the reference's fields 52.7 -> 48.4 us, r04)
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    const float4 q[8] = {q0, q1, q2, q3, q4, q5, q6, q7};
+    f32x2_ lo = {0.0f, 0.0f}, hi = {0.0f, 0.0f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2_ wk = {tw[k], tw[k]};
+        lo += f32x2_{q[k].x, q[k].y} * wk;
+        hi += f32x2_{q[k].z, q[k].w} * wk;
     }
-    MPHIP_ACC4(x, 0) MPHIP_ACC4(y, 1) MPHIP_ACC4(z, 2) MPHIP_ACC4(w, 3)
-#undef MPHIP_ACC4
+    out[0] = lo[0]; out[1] = lo[1]; out[2] = hi[0]; out[3] = hi[1];
 }
 
 // channel pitch of the staged image: a multiple of 4 floats (16-byte tap reads) whose quarter is odd, so lanes
@@ -462,14 +465,43 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
             stage_box_planar(vb, lds, bx, c0, cs, H, W, vol);
             __syncthreads();
             if (active) {
+                // The four positions of a thread run as two PAIRS on the packed fp32 pipe: a pair's k-th taps and weights are
+                // (pos, pos + 1) register pairs, and `acc += p * w` is v_pk_mul_f32 + v_pk_add_f32 — per position exactly gather8's
+                // op sequence (acc = 0; acc += p_k * w_k, one rounding per op), i.e. the same bits, at half the VALU instructions.
+                // (r04 counters, profiles/r04_pmc_k2.txt: the kernel spends its time about half in the LDS pipe and half in the VALU,
+                //  one after the other at two waves per SIMD; 11 % of its LDS cycles are bank conflicts.  Halving the VALU instructions
+                //  alone measured +-0; a hand-pipelined channel loop — next channel's 32 tap reads issued before this channel's
+                //  arithmetic — measured 75 -> 97 us and was dropped.)
+                typedef float f32x2_ __attribute__((ext_vector_type(2)));
+                f32x2_ wa[8], wb[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    wa[k] = f32x2_{taps[0].w[k], taps[1].w[k]};
+                    wb[k] = f32x2_{taps[2].w[k], taps[3].w[k]};
+                }
+                int off[4][8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const TapOff &o = lt[i];
+                    off[i][0] = o.base; off[i][1] = o.base + o.dx; off[i][2] = o.base + o.dy; off[i][3] = o.base + o.dy + o.dx;
+                    off[i][4] = o.base + o.dz; off[i][5] = o.base + o.dz + o.dx; off[i][6] = o.base + o.dz + o.dy;
+                    off[i][7] = o.base + o.dz + o.dy + o.dx;
+                }
+                unsigned mb2 = 0;
                 for (int c = 0; c < cs; ++c) {
                     const float *src = lds + c * bvol;
-                    float4 r;
-                    r.x = gather8_lds(src, lt[0], taps[0].w); r.y = gather8_lds(src, lt[1], taps[1].w);
-                    r.z = gather8_lds(src, lt[2], taps[2].w); r.w = gather8_lds(src, lt[3], taps[3].w);
+                    f32x2_ ra = {0.0f, 0.0f}, rb = {0.0f, 0.0f};
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const f32x2_ pa = {src[off[0][k]], src[off[1][k]]}, pb = {src[off[2][k]], src[off[3][k]]};
+                        ra += pa * wa[k];
+                        rb += pb * wb[k];
+                    }
+                    const float4 r = make_float4(ra[0], ra[1], rb[0], rb[1]);
                     *reinterpret_cast<float4 *>(ob + (size_t)(c0 + c) * vol) = r;
-                    mbits = max(max(mbits, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
+                    mb2 = max(max(mb2, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
                 }
+                mbits = max(mbits, mb2);
             }
         }
     }

@@ -58,6 +58,7 @@ def check_gnin(N, Ci, Co, D, H, W):
 
 
 def timeit(N, Ci, Co, D, H, W, wino, iters=20):
+    os.environ["MPHIP_WINOGRAD_MIN_TILES"] = "1"   # (timing: force the F(2,3) kernel wherever its tiling applies)
     x = torch.randn(N, Ci, D, H, W, device=dev)
     pc = ops.PackedConv(torch.randn(Co, Ci, 3, 3, 3, device=dev) * 0.02, torch.randn(Co, device=dev))
     for _ in range(3):
@@ -78,14 +79,16 @@ if __name__ == "__main__":
     good = True
     if "--time-only" not in sys.argv:
         for case in [(2, 96, 96, 4, 8, 8), (1, 96, 96, 16, 64, 64), (2, 96, 192, 8, 32, 32), (1, 192, 96, 8, 32, 64), (8, 192, 192, 8, 32, 32),
-                     (3, 16, 96, 4, 16, 8), (1, 256, 96, 8, 24, 40)]:
+                     (3, 16, 96, 4, 16, 8), (1, 256, 96, 8, 24, 40), (8, 384, 384, 4, 16, 16), (8, 192, 384, 4, 16, 16), (8, 384, 192, 4, 16, 16), (1, 96, 192, 8, 32, 32)]:
             os.environ["MPHIP_WINOGRAD_MIN_TILES"] = "1"
             good &= check(*case)
         good &= check_gnin(2, 96, 96, 8, 32, 32)
         good &= check_gnin(1, 192, 192, 8, 16, 24)
+        good &= check_gnin(8, 384, 384, 4, 16, 16)
         os.environ.pop("MPHIP_WINOGRAD_MIN_TILES", None)
     for case in [(8, 96, 96, 16, 64, 64), (8, 96, 192, 8, 32, 32), (8, 192, 192, 8, 32, 32), (8, 192, 96, 8, 32, 32), (1, 96, 96, 16, 64, 64),
-                 (4, 96, 96, 16, 64, 64)]:
+                 (4, 96, 96, 16, 64, 64), (8, 192, 384, 4, 16, 16), (8, 384, 384, 4, 16, 16), (8, 384, 192, 4, 16, 16), (8, 192, 192, 4, 16, 16),
+                 (1, 96, 192, 8, 32, 32), (1, 192, 192, 8, 32, 32), (1, 192, 96, 8, 32, 32), (2, 96, 192, 8, 32, 32), (2, 384, 384, 4, 16, 16)]:
         for rep in range(2):
             td, tw = timeit(*case, False), timeit(*case, True)
             fl = 2.0 * case[0] * case[3] * case[4] * case[5] * case[1] * case[2] * 27
