@@ -104,7 +104,7 @@ constexpr int PK_LDS_FLOATS = PK_CO * (F16X3_KC * 27 + 1);   // forward: 32 rows
 static_assert(PK_LDS_FLOATS >= F16X3_KC * (PK_CO * 27 + 1), "pack tile");
 __global__ void __launch_bounds__(256)
 f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in, float *__restrict__ hdr_out, int Co,
-                  int Ci, int transposed) {
+                  int Ci, int transposed, _Float16 *__restrict__ wino_out /* the F(2,3) kernel's slabs (conv3d_f16x3_wino.hip) or nullptr */) {
     __shared__ __attribute__((aligned(16))) float tile[PK_LDS_FLOATS];
     const float scale = weight_scale(hdr_in[2]);
     const int nchunks = Ci / F16X3_KC, subs = F16X3_COT / PK_CO;
@@ -157,6 +157,39 @@ f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const
         const size_t inner = (((size_t)tg * 2 + kg) * F16X3_COT + sub * PK_CO + co) * 8;
         *reinterpret_cast<half8 *>(out + slab * SLAB_HALFS + inner) = hi;
         *reinterpret_cast<half8 *>(out + slab * SLAB_HALFS + SLAB_HALFS / 2 + inner) = lo;
+    }
+    // The F(2,3) kernel's slabs from the SAME staged tile (training re-packs every weight every step: a second kernel that gathered the
+    // 27-float-strided taps again took 0.49 ms of a 12 ms step): slabs[(cot*nchunks + chunk)*9 + (kd*3+kh)][part][position][kg][co][8],
+    // filter transform u0 = g0, u1 = (g0+g1+g2)/2, u2 = (g0-g1+g2)/2, u3 = g2 along kw, exact in double, then the same split
+    if (wino_out) {
+        constexpr int WSLAB = 2 * 4 * 2 * F16X3_COT * 8;
+        for (int i = threadIdx.x; i < 9 * 4 * 2 * PK_CO; i += 256) {
+            const int co = i % PK_CO;
+            int r = i / PK_CO;
+            const int kg = r % 2; r /= 2;
+            const int p = r % 4;
+            const int g = r / 4;
+            half8 hi, lo;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ci = kg * 8 + e;
+                double t[3];
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int tap = g * 3 + kw;
+                    t[kw] = transposed ? tile[ci * pitch + co * 27 + (26 - tap)] : tile[co * pitch + ci * 27 + tap];
+                }
+                const double u = p == 0 ? t[0] : p == 1 ? 0.5 * (t[0] + t[1] + t[2]) : p == 2 ? 0.5 * (t[0] - t[1] + t[2]) : t[2];
+                const double us = u * (double)scale;
+                const _Float16 h = (_Float16)(float)us;
+                hi[e] = h;
+                lo[e] = (fabs(us) <= (double)F16_CLAMP) ? (_Float16)(float)(us - (double)(float)h) : (_Float16)0.0f;
+            }
+            const size_t slab = ((size_t)cot * nchunks + chunk) * 9 + g;
+            const size_t inner = ((size_t)(p * 2 + kg) * F16X3_COT + sub * PK_CO + co) * 8;
+            *reinterpret_cast<half8 *>(wino_out + slab * WSLAB + inner) = hi;
+            *reinterpret_cast<half8 *>(wino_out + slab * WSLAB + WSLAB / 2 + inner) = lo;
+        }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         hdr_out[0] = 1.0f / scale;
@@ -988,8 +1021,8 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed,
                            Ci, transposed);
     else {
         hipLaunchKernelGGL(f16x3_pack_kernel, dim3((unsigned)((Co / PK_CO) * (Ci / F16X3_KC))), dim3(256), 0, s, w,
-                           (_Float16 *)((char *)out + 16), hdr, (float *)out, Co, Ci, transposed);
-        if (f16x3_wino_packed_bytes(Co, Ci)) f16x3_wino_pack(w, (char *)out + f16x3_direct_bytes(Co, Ci), hdr, Co, Ci, transposed, s);
+                           (_Float16 *)((char *)out + 16), hdr, (float *)out, Co, Ci, transposed,
+                           f16x3_wino_packed_bytes(Co, Ci) ? (_Float16 *)((char *)out + f16x3_direct_bytes(Co, Ci)) : (_Float16 *)nullptr);
     }
     return check_launch("pack_conv_weight(f16x3)");
 }

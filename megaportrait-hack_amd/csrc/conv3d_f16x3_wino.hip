@@ -54,48 +54,9 @@ constexpr int WN_X_HALFS = 2 * WN_XPART;                   // 30976 halfs = 6195
 constexpr int WN_AFF_CI = 384;                             // fused input GroupNorm table: Ci <= 384 (LDS: 98304 + 61952 + 3072 B + the range fold's 68)
 constexpr int WN_XLOADS = 8;                               // vector-memory instructions of one halo prefetch (per wave)
 
-// ---- weight packing: OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*9 + (kd*3+kh)][part][position][kg][co][8] f16 ----
-// (scale: the per-tensor power of two of the direct pack's header, max|w|*scale < 2^15, so |u|*scale < 1.5 * 2^15 < 65504)
-__global__ void __launch_bounds__(256)
-f16x3_wino_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *__restrict__ hdr, int Co, int Ci,
-                       int transposed) {
-    const float scale = weight_scale(hdr[2]);
-    const int nchunks = Ci / WN_KC;
-    const size_t total = (size_t)(Co / WN_COT) * nchunks * WN_NG * 4 * 2 * WN_COT;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        size_t r = i;
-        const int co = (int)(r % WN_COT); r /= WN_COT;
-        const int kg = (int)(r % 2); r /= 2;
-        const int p = (int)(r % 4); r /= 4;
-        const int g = (int)(r % WN_NG); r /= WN_NG;
-        const int chunk = (int)(r % nchunks);
-        const int cot = (int)(r / nchunks);
-        const int kd = g / 3, kh = g % 3, cog = cot * WN_COT + co;
-        half8 hi, lo;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int ci = chunk * WN_KC + kg * 8 + e;
-            double g0, g1, g2;
-            if (!transposed) {
-                const float *q = w + ((size_t)cog * Ci + ci) * 27 + kd * 9 + kh * 3;
-                g0 = q[0]; g1 = q[1]; g2 = q[2];
-            } else {   // w is the original conv's [Ci][Co][27] weight, this pack its bwd-data conv (taps reversed)
-                const float *q = w + ((size_t)ci * Co + cog) * 27 + (2 - kd) * 9 + (2 - kh) * 3;
-                g0 = q[2]; g1 = q[1]; g2 = q[0];
-            }
-            const double u = p == 0 ? g0 : p == 1 ? 0.5 * (g0 + g1 + g2) : p == 2 ? 0.5 * (g0 - g1 + g2) : g2;
-            const double us = u * (double)scale;
-            const _Float16 h = (_Float16)(float)us;                  // (the filter transform itself is exact in double)
-            const float rem = (float)(us - (double)(float)h);
-            hi[e] = h;
-            lo[e] = (fabs(us) <= (double)F16_CLAMP) ? (_Float16)rem : (_Float16)0.0f;
-        }
-        const size_t slab = ((size_t)cot * nchunks + chunk) * WN_NG + g;
-        const size_t inner = ((size_t)(p * 2 + kg) * WN_COT + co) * 8;
-        *reinterpret_cast<half8 *>(out + slab * WN_SLAB_HALFS + inner) = hi;
-        *reinterpret_cast<half8 *>(out + slab * WN_SLAB_HALFS + WN_PART_HALFS + inner) = lo;
-    }
-}
+// Weight layout (written by f16x3_pack_kernel in conv3d_f16x3.hip, from the tile it stages for the direct slabs):
+//   slabs[(cot*nchunks + chunk)*9 + (kd*3+kh)][part][position][kg][co][8] f16, behind the direct slabs of the same pack;
+//   scale: the per-tensor power of two of the pack's header, max|w|*scale < 2^15, so |u|*scale < 1.5 * 2^15 < 65504.
 
 __device__ unsigned long long g_f16x3_wino_saturated;
 
@@ -649,12 +610,6 @@ bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W) {
     const char *min_s = getenv("MPHIP_WINOGRAD_MIN_TILES");   // dev: threshold sweep
     const long min_wgs = min_s ? atol(min_s) : 192;
     return tiles * (Co / WN_COT) * f16x3_wino_splits(N, Ci, Co, D, H, W) >= min_wgs;
-}
-
-void f16x3_wino_pack(const float *w, void *slabs, const void *hdr, int Co, int Ci, int transposed, hipStream_t s) {
-    const size_t total = (size_t)(Co / WN_COT) * (Ci / WN_KC) * WN_NG * 4 * 2 * WN_COT;
-    hipLaunchKernelGGL(f16x3_wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, (_Float16 *)slabs,
-                       (const unsigned *)hdr, Co, Ci, transposed);
 }
 
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,

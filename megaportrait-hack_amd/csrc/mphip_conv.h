@@ -43,8 +43,6 @@ int f16x3_tile_waves(const F16x3Plan &p);
 size_t f16x3_wino_packed_bytes(int Co, int Ci);
 bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W);
 int f16x3_wino_splits(int N, int Ci, int Co, int D, int H, int W);
-void f16x3_wino_pack(const float *w_oidhw, void *slabs, const void *hdr /* the direct pack's 16-byte header (max|w|) */, int Co, int Ci,
-                     int transposed, hipStream_t s);
 int f16x3_wino_saturation(unsigned long long *count, int reset);
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
                       int H, int W, int splits /* f16x3_wino_splits: dst = [splits] slabs when > 1 */, const float *in_affine, int in_relu,
