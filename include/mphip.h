@@ -352,7 +352,8 @@ int mphip_warp_volume_coords(const float *v, const float *coords, float *out, fl
  *                                     touch (all 8 trilinear corners, zero-weight ones included)
  *   mphip_upsample_trilinear2_roi / mphip_conv3d_fwd_roi: produce only the output tiles (of the conv kernel's own tiling,
  *                                     mphip_conv3d_roi_granule) a box touches, and of the upsample only those tiles' halos; every
- *                                     other voxel of y is LEFT UNTOUCHED (uninitialised memory).  roi_frames == 0: box b belongs to
+ *                                     other voxel of y is UNSPECIFIED (left untouched by an unsplit launch; a split-K shape's ordered reduce
+ *                                     writes every voxel, unlisted ones from uninitialised slabs).  roi_frames == 0: box b belongs to
  *                                     frame b; roi_frames > 0: N == 1 volume serves that many boxes (1 source x many drivers).
  *                                     Shapes / precisions without a tiled kernel (granule() == 0) compute everything.
  *   mphip_warp_volume_dsum_coords(v, coords) = mphip_warp_volume_dsum with the coordinate pass already done.

@@ -111,12 +111,21 @@ SIGNATURES = {
 
 _lib = None
 
+# The ABI version the SIGNATURES table above mirrors.  Checked against the library at load time, and against include/mphip.h by
+# tests/test_host.py — NOT read from the header at run time: a relocated / installed package ships libmphip.so without the repository's
+# include/ directory.
+EXPECTED_ABI_VERSION = 9
+
 
 def header_abi_version() -> int:
-    """MPHIP_ABI_VERSION of include/mphip.h (the header this binding's SIGNATURES table mirrors)."""
+    """MPHIP_ABI_VERSION of include/mphip.h when the header is there (a source checkout), else the version this binding was written
+    for (EXPECTED_ABI_VERSION)."""
     import re
 
-    with open(os.path.join(os.path.dirname(_HERE), "include", "mphip.h")) as f:
+    path = os.path.join(os.path.dirname(_HERE), "include", "mphip.h")
+    if not os.path.isfile(path):
+        return EXPECTED_ABI_VERSION
+    with open(path) as f:
         m = re.search(r"#define\s+MPHIP_ABI_VERSION\s+(\d+)", f.read())
     if m is None:
         raise RuntimeError("include/mphip.h does not define MPHIP_ABI_VERSION")

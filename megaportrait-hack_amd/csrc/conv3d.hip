@@ -657,11 +657,13 @@ static int conv3d_run(const float *x, const float *in_affine, int in_relu, const
         int *tile_list = nullptr;
         if (roi) {   // the tile list lives at the END of the caller's workspace (mphip_conv3d_roi_workspace_bytes)
             const size_t list_bytes = (((size_t)fp.grid.x + 1) * sizeof(int) + 255) / 256 * 256;
-            if (workspace_bytes < slab_bytes + gn_bytes + list_bytes) {
+            if (workspace_bytes < (slab_bytes + gn_bytes + 255) / 256 * 256 + list_bytes) {
                 set_error("conv3d_fwd_roi: workspace too small for the tile list (query mphip_conv3d_roi_workspace_bytes)");
                 return MPHIP_EWORKSPACE;
             }
-            tile_list = (int *)((char *)workspace + workspace_bytes - list_bytes);
+            // at a fixed 256-byte-aligned offset behind the slabs / statistics partials (not "the end of whatever the caller passed": a
+            // larger workspace whose size is not a multiple of 4 would misalign the int list — ADVICE r3)
+            tile_list = (int *)((char *)workspace + (slab_bytes + gn_bytes + 255) / 256 * 256);
         }
         rc = f16x3_launch(fp, x, w_packed, bias, dst, N, Ci, Co, D, H, W, in_affine, in_relu, x_range, s, roi, roi_frames, tile_list, roi_dilate,
                           gn_in_epilogue ? (float *)gn_ws : nullptr, stamp ? te0 : nullptr, stamp ? te1 : nullptr);

@@ -67,6 +67,8 @@ class HotSlicePlan:
 
     def _tables(self, tensors):
         self._keep = tensors   # the plan holds raw pointers: keep the tensors alive
+        live = dict(self.module.named_parameters())
+        self._params = [live[k] for k in tensors]   # same order as the key below
         names = (ctypes.c_char_p * len(tensors))(*[k.encode() for k in tensors])
         ptrs = (_P * len(tensors))(*[t.data_ptr() for t in tensors.values()])
         return names, ptrs
@@ -83,8 +85,15 @@ class HotSlicePlan:
 
     def _sync_weights(self):
         """Re-pack (on the forward's stream) when a parameter changed: in-place update, load_state_dict, .to(), or
-        ops.invalidate_packs() — the same conditions under which model._PackCache rebuilds its packs."""
+        ops.invalidate_packs() — the same conditions under which model._PackCache rebuilds its packs.
+        The per-forward check reads (data_ptr, _version) of the ~200 parameter tensors the plan bound (a B=1 step is 1.2 ms: walking
+        named_parameters() and detaching every tensor each call cost more host time than the check needs — ADVICE r3); the module tree
+        is walked again only when that fingerprint or the pack epoch moved.  Replacing a Parameter OBJECT of the module (rather than
+        its contents) needs ops.invalidate_packs(), like every other cache keyed on the tensors."""
         self._sync_precision()
+        fast = (ops.weight_epoch(),) + tuple((q.data_ptr(), q._version) for q in self._params)   # (the live Parameters: .to() shows as a new pointer)
+        if fast == self._key and not ops.repacking():
+            return
         tensors = _hot_tensors(self.module, self.g3d_only)
         key = self._weights_key(tensors)
         if key != self._key or ops.repacking():

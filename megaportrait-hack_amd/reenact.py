@@ -125,6 +125,17 @@ def launch_ranks(args, argv) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def shard_plan(job: dict, n_drivers: int, rank: int, world: int):
+    """What rank `rank` of `world` does (`--gpus N`: drivers sharded by frame, contiguous ranges, no collective): (begin, end, the files
+    it writes).  Pure host logic — tests/test_dp.py checks that the ranks' ranges and outputs partition the job exactly."""
+    from . import dp
+
+    b, e = dp.shard_range(n_drivers, rank, world)
+    if job["output_tensor"]:
+        return b, e, [job["output_tensor"] if world == 1 else f"{job['output_tensor']}.rank{rank}"]
+    return b, e, [job["output_files"][i] if job["output_files"] else os.path.join(job["output_dir"], f"frame_{i:05d}.png") for i in range(b, e)]
+
+
 def run(job: dict, args, rank: int, world: int) -> List[str]:
     import torch
 
@@ -144,7 +155,7 @@ def run(job: dict, args, rank: int, world: int) -> List[str]:
         g.channels_last_2d()
     xs = _load_tensor(job["source_tensor"]) if job["source_tensor"] else _load_image(job["source"])
     n = _load_tensor(job["drivers_tensor"]).shape[0] if job["drivers_tensor"] else len(job["drivers"])
-    b, e = dp.shard_range(n, rank, world)
+    b, e, outputs = shard_plan(job, n, rank, world)
     if job["drivers_tensor"]:
         xd = _load_tensor(job["drivers_tensor"])[b:e]
     else:
@@ -155,13 +166,11 @@ def run(job: dict, args, rank: int, world: int) -> List[str]:
     frames = g.reenact(xs.to(dev), xd.to(dev), chunk=args.chunk, fp16=args.fp16)   # this rank's shard; no collective
     written = []
     if job["output_tensor"]:
-        path = job["output_tensor"] if world == 1 else f"{job['output_tensor']}.rank{rank}"
-        torch.save({"begin": b, "end": e, "frames": frames.cpu()}, path)
-        written.append(path)
+        torch.save({"begin": b, "end": e, "frames": frames.cpu()}, outputs[0])
+        written.append(outputs[0])
     else:
         os.makedirs(job["output_dir"], exist_ok=True)
-        for i in range(b, e):
-            path = job["output_files"][i] if job["output_files"] else os.path.join(job["output_dir"], f"frame_{i:05d}.png")
+        for i, path in zip(range(b, e), outputs):
             _save_image(path, frames[i - b], args.unit_range)
             written.append(path)
     return written

@@ -285,6 +285,39 @@ def test_demand_driven_conv_and_upsample_equal_the_full_ops_inside_the_boxes(dev
     assert need.float().mean().item() < 1.0 or shape[2] <= 4
 
 
+def test_demand_driven_conv_on_a_travelling_field_costs_what_the_full_launch_costs(dev):
+    """when the final warp's samples travel through the whole volume the boxes are the volume and the demand-driven
+    launch lists every tile — it must then cost what the plain launch costs (r03: three workgroups per listed tile re-staged X three
+    times).  Since r04 both are the SAME kernel (the F(2,3) kernel walks either the full range or the list): within 8 % of each other
+    on the graded shape (the list launch adds the 5 us tile-list kernel and loses the XCD-aware tile order), same bits."""
+    from megaportrait_hack_amd import ops
+
+    n, c, d, h, w = 8, 96, 16, 64, 64
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(n, c, d, h, w, generator=gen).to(dev)
+    pc = ops.PackedConv((torch.randn(96, c, 3, 3, 3, generator=gen) * 0.03).to(dev), torch.randn(96, generator=gen).to(dev))
+    boxes = torch.tensor([[0, 0, 0, w, h, d, 0, 0]] * n, dtype=torch.int32).to(dev)
+    rng = ops.absmax_range(x)
+
+    def timed(fn):
+        for _ in range(3):
+            y = fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            y = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / 10, y
+
+    t_full, y_full = timed(lambda: ops.conv3d(x, pc, precision=1, x_range=rng))
+    t_roi, y_roi = timed(lambda: ops.conv3d_roi(x, pc, boxes, x_range=rng))
+    assert torch.equal(y_roi, y_full)
+    print(f"full launch {t_full:.3f} ms, demand-driven launch listing every tile {t_roi:.3f} ms")
+    assert t_roi <= 1.08 * t_full, (t_roi, t_full)
+
+
 def test_demand_driven_plan_never_reads_what_it_did_not_compute(dev, M):
     """The plan's workspace is pre-filled with NaN: if the final warp (or anything else) read a voxel the demand-driven tail
     skipped, the output would carry it.  Same bits as the full evaluation, reference-like fields and a batch that mixes them

@@ -32,7 +32,7 @@ def test_header_symbols_are_exported(lib):
         assert hasattr(raw, name), f"{name} declared in mphip.h but not exported by libmphip.so"
     assert declared == set(_lib.SIGNATURES), "ctypes signature table out of sync with mphip.h"
     # the library reports the ABI version it was built with; the binding refuses a mismatch with the header
-    assert lib.mphip_version() == _lib.header_abi_version() >= 3
+    assert lib.mphip_version() == _lib.header_abi_version() == _lib.EXPECTED_ABI_VERSION >= 3
 
 
 def test_stale_library_is_refused(lib, monkeypatch):
