@@ -1080,7 +1080,9 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     static const bool thirds_off = getenv("MPHIP_ROI_THIRDS") && getenv("MPHIP_ROI_THIRDS")[0] == '0';   // dev: same-box A/B
     const bool thirds = roi && p.variant == 0 && p.td == 4 && !gn_part && !thirds_off;
     const long others = (long)p.grid.y * (thirds ? 3 : 1) * p.grid.z;
-    long gx = (256L * per_cu + others - 1) / others;
+    static const char *cus_s = getenv("MPHIP_CONV_CUS");   // dev: persistent grid size (leave CUs to another batch's small kernels)
+    const long cus = cus_s ? atol(cus_s) : 256;
+    long gx = (cus * per_cu + others - 1) / others;
     if (gx < 1) gx = 1;
     if (gx > tiles_total || getenv("MPHIP_F16X3_NO_PERSIST")) gx = tiles_total;
     dim3 grid((unsigned)gx, p.grid.y * (thirds ? 3 : 1), p.grid.z);

@@ -616,7 +616,9 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
                       int H, int W, int splits, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, const int *tile_list,
                       float *gn_part, hipEvent_t t0, hipEvent_t t1) {
     const int tiles = N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW), cots = Co / WN_COT;
-    long gx = (256L + cots * splits - 1) / (cots * splits);   // persistent: one workgroup per CU
+    static const char *cus_s = getenv("MPHIP_CONV_CUS");   // dev: persistent grid size (leave CUs to another batch's small kernels)
+    const long cus = cus_s ? atol(cus_s) : 256;
+    long gx = (cus + cots * splits - 1) / (cots * splits);   // persistent: one workgroup per CU
     if (gx > tiles) gx = tiles;
     const dim3 grid((unsigned)gx, (unsigned)cots, (unsigned)splits);
     const int cps = (Ci / WN_KC + splits - 1) / splits;

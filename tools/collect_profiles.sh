@@ -31,6 +31,11 @@ rocprofv3 --kernel-trace -d $out/kt -- python tools/run_plan_steps.py 1 30 > /de
 db=$(find $out/kt -name "*.db" | head -1)
 python tools/lane_timeline.py $db 1.6 > $out/${R}_timeline_plan_b1.txt
 rm -rf $out/kt
+# 1b. training step of config 3's shard (eager launches: 10 timed + 2 warm-up steps, every one the same kernels)
+rocprofv3 --kernel-trace -d $out/kt -- python bench.py --mode train --batch 4 --steps 10 --warmup 2 > $out/train_under_trace.log 2>&1
+db=$(find $out/kt -name "*.db" | head -1)
+python tools/agg_summary.py $db 12 40 > $out/${R}_train_kernel_agg.txt
+rm -rf $out/kt
 # 2. the same line without the profiler, same box
 python bench.py --no-cpu-baseline --extras-budget 30 --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${R}_bench_line_same_box_as_trace.json
 # 3. SQ / HBM counters of the dominant conv (the F(2,3) kernel; separate passes, MI355X_MICROARCH.md)
