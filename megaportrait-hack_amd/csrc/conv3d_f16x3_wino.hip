@@ -315,6 +315,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 #define WN_ABL_KEEP_FRAGS
 #define WN_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
 #endif
+#ifdef MPHIP_WN_DMA_FIRST   /* dev: same-box A/B — r04's first order: DMA issue and fragment reads in front of the interval's first MFMAs */
 #define WN_INTERVAL(G)                                                                                                     \
     {                                                                                                                      \
         constexpr int cur_ = (G) & 1;                                                                                      \
@@ -358,6 +359,56 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         WPROF_ADD(3)                                                                                                       \
         ++s;                                                                                                               \
     }
+#else
+            // The interval's first six MFMAs (Wlo(s) x Xhi: both fetched during the previous interval) are issued straight after the
+            // barrier; the DMA pieces, the halo prefetch and all of the interval's fragment reads are issued into their shadow — an LDS-DMA
+            // piece costs its wave 60-185 issue cycles (MI355X_MICROARCH.md), which the MFMA pipe sat out when they came first.
+#define WN_INTERVAL(G)                                                                                                     \
+    {                                                                                                                      \
+        constexpr int cur_ = (G) & 1;                                                                                      \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                acc[m][t] = WN_MFMA(al[m], bh[cur_][t], acc[m][t]);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        const _Float16 *wsb_ = Ws + (s & (WN_RING - 1)) * WN_SLAB_HALFS + a_base;                                          \
+        const _Float16 *wsn_ = Ws + ((s + 1) & (WN_RING - 1)) * WN_SLAB_HALFS + a_base + WN_PART_HALFS;                    \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m) ah[m] = *reinterpret_cast<const half8 *>(wsb_ + m * 256);            \
+        _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                      \
+            bl[t] = *reinterpret_cast<const half8 *>(Xs + WN_XPART + b_base[t] + WN_TOFF(G));                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if ((G) == 2 && do_load) { WN_LOAD_X(load_chunk); }   /* (before the DMA: hipcc's own vmcnt(k) waits on the   */ \
+        const int issued_ = dma_issue();                       /*  registers it reloads then only cover landed pieces) */ \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        if (s + 1 < s_total) {                                                                                             \
+            _Pragma("unroll") for (int m = 0; m < 3; ++m) al[m] = *reinterpret_cast<const half8 *>(wsn_ + m * 256);        \
+        }                                                                                                                  \
+        if ((G) < 8) {                                                                                                     \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                bh[cur_ ^ 1][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t] + WN_TOFF(((G) < 8 ? (G) + 1 : 0)));     \
+        }                                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                acc[m][t] = WN_MFMA(ah[m], bh[cur_][t], acc[m][t]);                \
+        _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
+                acc[m][t] = WN_MFMA(ah[m], bl[t], acc[m][t]);                      \
+        WN_ABL_KEEP_FRAGS                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                                 \
+        WPROF_ADD(1)                                                                                                       \
+        /* younger than this wave's pieces of slab s+2: interval 2's halo prefetch (8) and this interval's pieces (3) */   \
+        if ((G) == 2 && do_load) {                                                                                         \
+            if (issued_) lds_dma_wait<WN_XLOADS + 3>(); else lds_dma_wait<WN_XLOADS>();                                    \
+        } else {                                                                                                           \
+            if (issued_) lds_dma_wait<3>(); else lds_dma_wait<0>();                                                        \
+        }                                                                                                                  \
+        WPROF_ADD(2)                                                                                                       \
+        lds_barrier();                                                                                                     \
+        WPROF_ADD(3)                                                                                                       \
+        ++s;                                                                                                               \
+    }
+#endif
             WN_INTERVAL(0)
             WN_INTERVAL(1)
             WN_INTERVAL(2)
@@ -386,6 +437,14 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
                 // hipcc 70-160 spilled registers, and so did interleaving both jobs in one instruction stream); only the staging code
                 // sits under the wave-uniform conditions.  A tile's last chunk (!more) has nothing to stage here: the next tile's halo is
                 // written after the output transform, which uses the X region.
+#ifndef MPHIP_WN_DMA_FIRST
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int m = 0; m < 3; ++m)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) acc[m][t] = WN_MFMA(al[m], bh[0][t], acc[m][t]);
+                __builtin_amdgcn_sched_barrier(0);
+#endif
                 const int issued_ = dma_issue();
                 const _Float16 *wsb_ = Ws + (s & (WN_RING - 1)) * WN_SLAB_HALFS + a_base;
                 const _Float16 *wsn_ = Ws + ((s + 1) & (WN_RING - 1)) * WN_SLAB_HALFS + a_base + WN_PART_HALFS;
@@ -401,11 +460,13 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef MPHIP_WN_DMA_FIRST
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[m][t] = WN_MFMA(al[m], bh[0][t], acc[m][t]);
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (s + 1 < s_total) {
 #pragma unroll
                     for (int m = 0; m < 3; ++m) al[m] = *reinterpret_cast<const half8 *>(wsn_ + m * 256);
