@@ -26,6 +26,9 @@ SIGNATURES = {
     "mphip_rt_theta": (_i, [_p, _p, _p, _i, _i, _p]),
     "mphip_warp_field_compose": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _p]),
     "mphip_warp_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "mphip_warp_corner_image_bytes": (_sz, [_i, _i]),
+    "mphip_warp_corner_image": (_i, [_p, _p, _sz] + [_i] * 5 + [_p]),
+    "mphip_warp_volume_coords_img": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p, _p]),
     "mphip_warp_volume": (_i, [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_volume_dsum": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
     "mphip_warp_volume_dsum_shared": (_i, [_p, _p, _p, _p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _i, _p, _sz, _p]),
@@ -114,7 +117,7 @@ _lib = None
 # The ABI version the SIGNATURES table above mirrors.  Checked against the library at load time, and against include/mphip.h by
 # tests/test_host.py — NOT read from the header at run time: a relocated / installed package ships libmphip.so without the repository's
 # include/ directory.
-EXPECTED_ABI_VERSION = 9
+EXPECTED_ABI_VERSION = 10
 
 
 def header_abi_version() -> int:

@@ -673,6 +673,9 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
     // under final_conv any more (G3d's persistent conv workgroups own every register of a CU: a side-stream kernel only runs in
     // the gaps between conv launches) — it runs beside the equally latency-bound S2C chain, in lockstep (see GenLane).  With the
     // full tail the old order stands: critical path first, the C2D generator's ~25 launches behind G3d's first conv.
+    // K2's corner image (warp.hip): vs is an input, so the copy runs here, beside the generators' latency-bound chains, not in front of K2
+    Buf cimg = take(cm, mphip_warp_corner_image_bytes(B, p->C));
+    RUN(cm, mphip_warp_corner_image(vs, cimg.p, mphip_warp_corner_image_bytes(B, p->C), B, p->C, p->D, p->H, p->W, s));
     Buf coords, box, c_s2c;
     bool c2d_issued = false;
     auto finish_c2d = [&] {   // the per-frame box of voxels K3 will read (demand-driven final_conv)
@@ -718,10 +721,11 @@ int run_slice(Plan *p, const float *vs, const float *es, const float *Rs, const 
     {
         const size_t wsb = mphip_warp_workspace_bytes(B, p->D, p->H, p->W);   // (covers the per-tile marks of the gather passes)
         Buf ws = take(cm, wsb);
-        RUN(cm, mphip_warp_volume_coords(vs, c_s2c.p, vc.data.p, vc.range.p, B, p->C, p->D, p->H, p->W, ws.p, wsb, s));
+        RUN(cm, mphip_warp_volume_coords_img(vs, c_s2c.p, vc.data.p, vc.range.p, B, p->C, p->D, p->H, p->W, ws.p, wsb, cimg.p, s));
         give(cm, ws);
     }
     give(cm, c_s2c);
+    give(cm, cimg);
     int join_rc = MPHIP_OK;
     auto tail = [&]() -> Roi {   // the boxes are needed from here on: join the side stream before G3d's last upsample
         if (overlap && (hipEventRecord(p->ev_join, p->side) != hipSuccess || hipStreamWaitEvent(s, p->ev_join, 0) != hipSuccess)) {

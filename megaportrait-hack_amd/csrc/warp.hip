@@ -399,15 +399,89 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
 // (r03: a [voxel][channel] image with four channels per ds_read_b128 tap — K3's gather8x4, 2 LDS reads per output value instead of
 //  8 — measured 82 vs 77 us for the whole op at B=8, same box: LDS issue is not what bounds this kernel; removed.  A plain fill of
 //  the same 201 MB runs at 7.6 TB/s on this chip (tools/probe_write_bw.py), the gather writes at 3.8.)
-constexpr int K2_TH = 32, K2_TW = 32;
-constexpr int K2_DIRECT_SPLIT = 4;  // channel groups of the direct gather (warp_gather_direct_body)
-constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a 32 x 32 tile up to which the column walk is used
-__global__ void __launch_bounds__(256)
+constexpr int K2_TH = 16, K2_TW = 32;   // 512 positions per workgroup, two per thread
+#ifndef MPHIP_K2_UNROLL
+#define MPHIP_K2_UNROLL 2
+#endif
+constexpr int K2_UNROLL = MPHIP_K2_UNROLL;   // channels per trip of the gather loop (their offsets are immediates)
+constexpr int K2_STAGE_FLOATS = 8192;    // 32 KB of LDS for the staged box: four workgroups (16 waves) per CU
+constexpr int K2_DIRECT_SPLIT = 2;  // channel groups of the direct gather (warp_gather_direct_body)
+constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a tile up to which the column walk is used
+// r04: the r03 kernel (32 x 32 tile, four positions per thread, planar image, 142 registers, two waves per SIMD) ran its channel loop
+// as one dependent chain per wave — 32 address adds -> 32 tap reads -> wait -> 64 multiply / adds -> store, ~960 cycles per channel — with
+// nothing to overlap it with: ablations on the reference's fields (tools/k2_ablate.sh): no stores 62 -> 59 us (the 201 MB written are NOT
+// what bounds it), no tap reads 37 us.  Now: two positions per thread (half the chain, < 128 registers -> four waves per SIMD), the image
+// [box voxel][channel] with an ODD channel pitch so that the channel is an IMMEDIATE offset of the tap read (no address arithmetic in the
+// loop; two channels per ds_read2_b32), 32 KB of LDS per workgroup.
+// The reference's own fields sample the LOW CORNER of the volume: every workgroup of a frame stages the same
+// few voxels of all its channel planes — 1.5 k scattered 128-byte lines per workgroup in r03 — after it has loaded its coordinates
+// and reduced its box: three dependent memory round trips before the first store.  Wall-clock stamps per workgroup
+// (tools/dbg_k2_trace.py, B=8): the gather loops themselves write at ~7.7 TB/s, the speed of a plain fill, but they covered less than
+// half of a workgroup's life, and a tail of workgroups whose staging loads queued behind the others' stores ended at 60 us when the
+// median had ended at 34.  So the corner [0,E)^3 of every frame is copied ONCE per call into a compact image that already has the
+// LDS layout, [frame][channel group][cell][K2_CG + 1] (28 KB per block, contiguous: all L2 channels), and a workgroup brings its block
+// in with 28 LDS-DMA instructions issued FIRST THING — under its coordinate loads and box reduction.  A box that leaves the corner
+// (not the reference's fields) is staged by stage_box after all.
+constexpr int K2_CORNER_E = 6;
+constexpr int K2_CORNER_CELLS = K2_CORNER_E * K2_CORNER_E * K2_CORNER_E;
+constexpr int K2_CG = 32;                       // channels per workgroup (blockIdx.y)
+constexpr int K2_CGP = K2_CG | 1;               // odd channel pitch: lanes that read different cells fall on different banks
+constexpr int K2_IMG_FLOATS = K2_CORNER_CELLS * K2_CGP;   // 7128 floats = 28512 B (a multiple of 16)
+__global__ void __launch_bounds__(128)
+warp_corner_image_kernel(const float *__restrict__ v, float *__restrict__ img, int C, int D, int H, int W, int groups) {
+    const int cell = blockIdx.x, b = blockIdx.y;
+    const int z = cell / (K2_CORNER_E * K2_CORNER_E), y = (cell / K2_CORNER_E) % K2_CORNER_E, x = cell % K2_CORNER_E;
+    const bool inside = z < D && y < H && x < W;
+    const size_t vol = (size_t)D * H * W;
+    for (int c = threadIdx.x; c < groups * K2_CGP; c += 128) {   // (the pad slot and channels >= C: zeros, the block is copied whole)
+        const int g = c / K2_CGP, cl = c - g * K2_CGP, ch = g * K2_CG + cl;
+        const bool real = inside && cl < K2_CG && ch < C;
+        img[(((size_t)b * groups + g) * K2_CORNER_CELLS + cell) * K2_CGP + cl] = real ? v[((size_t)b * C + ch) * vol + ((size_t)z * H + y) * W + x] : 0.0f;
+    }
+}
+// one block of the corner image -> LDS, as LDS-DMA (16 bytes per lane, 1 KiB per wave and instruction, no registers); issued by hand:
+// the compiler would wait for each transfer before the next LDS access.  The caller waits (vmcnt(0)) before its barrier.
+__device__ __forceinline__ void k2_dma_image(const float *__restrict__ blk, float *lds) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
+    constexpr int PIECES = (K2_IMG_FLOATS * 4 + 1023) / 1024;   // 28
+    for (int q = wave; q < PIECES; q += 4) {
+        const int f = q * 256 + lane * 4;   // float index of this lane's 16 bytes
+        if (f < K2_IMG_FLOATS) {
+            const float *src = blk + f;
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + (unsigned)q * 1024u) : "memory");
+        }
+    }
+}
+
+// (the product as an opaque instruction: hipcc's SLP vectoriser otherwise re-packs the two channels of a tap into v_pk_mul_f32 /
+//  v_pk_add_f32 on DUPLICATED weight pairs — 180 more registers' worth of pressure, 700 B of scratch at four waves per SIMD — and the
+//  packed fp32 ops are no faster than two scalar ones on this chip: r04 measured +-0 for half the instructions)
+__device__ __forceinline__ float k2_mul(float a, float b) {
+    float m;
+    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ float k2_add(float a, float b) {
+    float m;
+    asm("v_add_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+    return m;
+}
+#ifdef MPHIP_K2_TRACE   /* dev: wall-clock (100 MHz) stamps per workgroup: start, box known, first image staged, done */
+__device__ unsigned long long g_k2_trace[4096 * 4];
+#define K2_STAMP(i) if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) g_k2_trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64();
+#else
+#define K2_STAMP(i)
+#endif
+__global__ void __launch_bounds__(256, 4)
 warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                    float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */,
-                   int *__restrict__ todo, int B, int C, int D, int H, int W) {
-    __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
+                   int *__restrict__ todo, int B, int C, int D, int H, int W,
+                   const float *__restrict__ img /* optional corner image (warp_corner_image_kernel; then cg == K2_CG) */,
+                   int cg /* channels per blockIdx.y */) {
+    __shared__ __attribute__((aligned(16))) float lds[K2_STAGE_FLOATS];
     __shared__ int red[24];
+    K2_STAMP(0)
     const int HW = H * W;
     const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
     // XCD-aware order: consecutive logical ids (d fastest, then tile, then frame) run on the same XCD, so the source planes two
@@ -416,25 +490,44 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     const int d = (int)(bid % (unsigned)D);
     const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
     const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
-    const int h = (tile / tiles_w) * K2_TH + (int)(threadIdx.x >> 3);
-    const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x & 7) * 4;
-    const bool active = h < H && w < W;  // W % 4 == 0 -> a thread's 4 positions share validity
+    // The image is fetched only if the tile's FIRST sample lies in the corner (one scalar load): a field that travels through the volume
+    // (not the reference's) would otherwise pay 28 KB of transfers per workgroup for nothing.
+    bool dma = false;
+    if (img) {
+        const float *c0p = coords + (((size_t)b * D + d) * HW + (size_t)(tile / tiles_w) * K2_TH * W + (tile % tiles_w) * K2_TW) * 3;
+        const float fx = c0p[0], fy = c0p[1], fz = c0p[2];
+        dma = fx >= 0.0f && fx < (float)(K2_CORNER_E - 1) && fy >= 0.0f && fy < (float)(K2_CORNER_E - 1) && fz >= 0.0f && fz < (float)(K2_CORNER_E - 1);
+    }
+    // (channel groups > 0 exist for the corner image's sake: elsewhere group 0 does the tile alone, with `cg` = all channels)
+    if (img && !dma) {
+        if (blockIdx.y > 0) {
+            if (out_range) range_note_block(0u, out_range, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+            return;
+        }
+        cg = C;
+    }
+#ifndef MPHIP_K2_ABL_NOSTAGE   /* dev ablations (timing only, wrong results): tools/k2_ablate.sh */
+    if (dma) k2_dma_image(img + ((size_t)b * gridDim.y + blockIdx.y) * K2_IMG_FLOATS, lds);   // lands under the coordinate loads / box reduction
+#endif
+    const int h = (tile / tiles_w) * K2_TH + (int)(threadIdx.x / (K2_TW / 2));
+    const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x % (K2_TW / 2)) * 2;
+    const bool active = h < H && w < W;  // W % 4 == 0 -> a thread's 2 positions share validity
     const int p0 = h * W + w;
     const size_t vol = (size_t)D * HW;
 
-    Taps taps[4];
-    int x0[4], y0[4], z0[4];
+    Taps taps[2];
+    int x0[2], y0[2], z0[2];
     int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
     if (active) {
-        const float *cp = coords + (((size_t)b * D + d) * HW + p0) * 3;
-        float cf[12];
+        const float *cp = coords + (((size_t)b * D + d) * HW + p0) * 3;   // (p0 even: 8-byte aligned)
+        float cf[6];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
-            float4 t4 = *reinterpret_cast<const float4 *>(cp + q * 4);
-            cf[q * 4] = t4.x; cf[q * 4 + 1] = t4.y; cf[q * 4 + 2] = t4.z; cf[q * 4 + 3] = t4.w;
+            const float2 t2 = *reinterpret_cast<const float2 *>(cp + q * 2);
+            cf[q * 2] = t2.x; cf[q * 2 + 1] = t2.y;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             Coord3 c{cf[i * 3], cf[i * 3 + 1], cf[i * 3 + 2]};
             taps[i] = make_taps(c, D, H, W);
             x0[i] = (int)floorf(c.x); y0[i] = (int)floorf(c.y); z0[i] = (int)floorf(c.z);
@@ -443,69 +536,111 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
         }
     }
     const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
-    const int bvol = bx.ex * bx.ey * bx.ez;
-    const int cs_max = bvol > 0 ? STAGE_FLOATS / bvol : 0;  // channels that fit one pass of the planar image
+    K2_STAMP(1)
+    // blockIdx.y = channel group of cg channels: three times the workgroups (the dispatcher back-fills CUs as workgroups end; with ONE
+    // resident round a tail of slow workgroups set the kernel's time) and a group's image of a <= 6^3 box fits one pass (a second pass
+    // waits for the first pass's stores: vmcnt counts them too)
+    const int cg0 = (int)blockIdx.y * cg, Cg = min(C - cg0, cg);
+    // block-uniform: the whole tile samples the corner whose image is on its way into the LDS
+    const bool in_corner = dma && bx.ox + bx.ex <= K2_CORNER_E && bx.oy + bx.ey <= K2_CORNER_E && bx.oz + bx.ez <= K2_CORNER_E;
+    const Box ibx = in_corner ? Box{0, 0, 0, K2_CORNER_E, K2_CORNER_E, K2_CORNER_E} : bx;   // the box the LDS image holds
+    const int bvol = ibx.ex * ibx.ey * ibx.ez;
+    const int pfit = bvol > 0 ? K2_STAGE_FLOATS / bvol : 0;   // floats per box voxel that fit
+    const bool one_pass = (Cg | 1) <= pfit;
+    const int pitch = in_corner ? K2_CGP : one_pass ? (Cg | 1) : ((pfit - 1) | 1);   // odd: lanes that read different voxels fall on different banks
+    const int cs_max = (in_corner || one_pass) ? Cg : (pitch & ~7);
     const float *vb = v + (size_t)b * C * vol;
     float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
     unsigned mbits = 0;
-    const bool staged = cs_max >= 8 || cs_max >= C;  // block-uniform
+    // block-uniform.  With a corner image, only corner tiles are gathered here: a box elsewhere that happens to fit the LDS would be
+    // staged line by line from global memory in several passes — slower than the column walk that takes the tile otherwise
+    const bool staged = in_corner || (!img && cs_max >= 8);
     // 0: done here; 1: a box of moderate size = a smooth field that travels -> warp_gather_columns_body (plane reuse down the
     // slices); 2: no locality to exploit (a box like the whole volume) -> warp_gather_direct_body (most loads in flight)
-    if (threadIdx.x == 0) todo[bid] = staged ? 0 : (bvol <= K2_COLUMNS_MAX_BOX ? 1 : 2);
+    if (threadIdx.x == 0) todo[bid] = staged ? 0 : (bx.ex * bx.ey * bx.ez <= K2_COLUMNS_MAX_BOX ? 1 : 2);
 
+    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the corner image has landed (or must have, before it is overwritten)
     if (staged) {
-        TapOff lt[4];
+        int tb[2][8];   // tap addresses in the image (floats, premultiplied by the pitch)
         if (active) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) lt[i] = rebase(taps[i], x0[i], y0[i], z0[i], bx, 1);
+            for (int i = 0; i < 2; ++i) {
+                const TapOff o = rebase(taps[i], x0[i], y0[i], z0[i], ibx, pitch);
+                tb[i][0] = o.base; tb[i][1] = o.base + o.dx; tb[i][2] = o.base + o.dy; tb[i][3] = o.base + o.dy + o.dx;
+                tb[i][4] = o.base + o.dz; tb[i][5] = o.base + o.dz + o.dx; tb[i][6] = o.base + o.dz + o.dy;
+                tb[i][7] = o.base + o.dz + o.dy + o.dx;
+            }
         }
-        for (int c0 = 0; c0 < C; c0 += cs_max) {
-            const int cs = min(cs_max, C - c0);
-            if (c0) __syncthreads();
-            stage_box_planar(vb, lds, bx, c0, cs, H, W, vol);
+        for (int c0 = cg0; c0 < cg0 + Cg; c0 += cs_max) {
+            const int cs = min(cs_max, cg0 + Cg - c0);
+            if (c0 != cg0 || (dma && !in_corner)) __syncthreads();   // (every wave's part of the unused image has landed)
+#ifndef MPHIP_K2_ABL_NOSTAGE
+            if (!in_corner) stage_box(vb, lds, bx, c0, cs, pitch, H, W, vol);
+#endif
             __syncthreads();
+            if (c0 == cg0) { K2_STAMP(2) }
+#ifdef MPHIP_K2_ABL_NOLOOP
+            if (active && bvol == 12345) {
+#else
             if (active) {
-                // The four positions of a thread run as two PAIRS on the packed fp32 pipe: a pair's k-th taps and weights are
-                // (pos, pos + 1) register pairs, and `acc += p * w` is v_pk_mul_f32 + v_pk_add_f32 — per position exactly gather8's
-                // op sequence (acc = 0; acc += p_k * w_k, one rounding per op), i.e. the same bits, at half the VALU instructions.
-                // (r04 counters, profiles/r04_pmc_k2.txt: the kernel spends its time about half in the LDS pipe and half in the VALU,
-                //  one after the other at two waves per SIMD; 11 % of its LDS cycles are bank conflicts.  Halving the VALU instructions
-                //  alone measured +-0; a hand-pipelined channel loop — next channel's 32 tap reads issued before this channel's
-                //  arithmetic — measured 75 -> 97 us and was dropped.)
-                typedef float f32x2_ __attribute__((ext_vector_type(2)));
-                f32x2_ wa[8], wb[8];
-#pragma unroll
-                for (int k = 0; k < 8; ++k) {
-                    wa[k] = f32x2_{taps[0].w[k], taps[1].w[k]};
-                    wb[k] = f32x2_{taps[2].w[k], taps[3].w[k]};
-                }
-                int off[4][8];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const TapOff &o = lt[i];
-                    off[i][0] = o.base; off[i][1] = o.base + o.dx; off[i][2] = o.base + o.dy; off[i][3] = o.base + o.dy + o.dx;
-                    off[i][4] = o.base + o.dz; off[i][5] = o.base + o.dz + o.dx; off[i][6] = o.base + o.dz + o.dy;
-                    off[i][7] = o.base + o.dz + o.dy + o.dx;
-                }
+#endif
                 unsigned mb2 = 0;
-                for (int c = 0; c < cs; ++c) {
-                    const float *src = lds + c * bvol;
-                    f32x2_ ra = {0.0f, 0.0f}, rb = {0.0f, 0.0f};
+                // per channel and position exactly gather8's op sequence (acc = 0; acc += p_k * w_k in tap order, one rounding per op)
+                auto two_channels = [&](const float *src, int c) {
+                    float pa[2][8], pb[2][8];
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const f32x2_ pa = {src[off[0][k]], src[off[1][k]]}, pb = {src[off[2][k]], src[off[3][k]]};
-                        ra += pa * wa[k];
-                        rb += pb * wb[k];
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            pa[i][k] = src[tb[i][k]];
+                            pb[i][k] = src[tb[i][k] + 1];
+                        }
+                    float ra[2], rb[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        ra[i] = 0.0f; rb[i] = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) {
+                            ra[i] = k2_add(ra[i], k2_mul(pa[i][k], taps[i].w[k]));
+                            rb[i] = k2_add(rb[i], k2_mul(pb[i][k], taps[i].w[k]));
+                        }
                     }
-                    const float4 r = make_float4(ra[0], ra[1], rb[0], rb[1]);
-                    *reinterpret_cast<float4 *>(ob + (size_t)(c0 + c) * vol) = r;
-                    mb2 = max(max(mb2, range_bits(r.x)), max(range_bits(r.y), max(range_bits(r.z), range_bits(r.w))));
+#ifdef MPHIP_K2_ABL_NOSTORE
+                    if (ra[0] == 1.2345e30f)
+#endif
+                    {
+                        *reinterpret_cast<float2 *>(ob + (size_t)(c0 + c) * vol) = make_float2(ra[0], ra[1]);
+                        *reinterpret_cast<float2 *>(ob + (size_t)(c0 + c + 1) * vol) = make_float2(rb[0], rb[1]);
+                    }
+                    mb2 = max(max(mb2, range_bits(ra[0])), max(range_bits(ra[1]), max(range_bits(rb[0]), range_bits(rb[1]))));
+                    __builtin_amdgcn_sched_barrier(0);   // one channel pair at a time (hoisting the next pairs' reads spills)
+                };
+                auto one_channel = [&](const float *src, int c) {   // (odd tail)
+                    float r[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        r[i] = 0.0f;
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) r[i] += src[tb[i][k]] * taps[i].w[k];
+                    }
+                    *reinterpret_cast<float2 *>(ob + (size_t)(c0 + c) * vol) = make_float2(r[0], r[1]);
+                    mb2 = max(mb2, max(range_bits(r[0]), range_bits(r[1])));
+                };
+                int c = 0;
+                for (; c + K2_UNROLL <= cs; c += K2_UNROLL) {
+                    const float *src = lds + c;
+#pragma unroll
+                    for (int u = 0; u < K2_UNROLL; u += 2) two_channels(src + u, c + u);
                 }
+                for (; c + 2 <= cs; c += 2) two_channels(lds + c, c);
+                if (c < cs) one_channel(lds + c, c);
                 mbits = max(mbits, mb2);
             }
         }
     }
-    if (out_range) range_note_block(mbits, out_range, blockIdx.x, gridDim.x);  // (the follow-up kernels fold into these slots)
+    // (slot = group * tiles + tile: the follow-up kernels fold into group 0's slots)
+    if (out_range) range_note_block(mbits, out_range, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    K2_STAMP(3)
 }
 
 // The tiles warp_gather_kernel marked: one position per lane, lanes running along w, so for a smooth field every tap load of
@@ -524,13 +659,14 @@ warp_gather_direct_body(const float *__restrict__ v, const float *__restrict__ c
         const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
         const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
         const size_t vol = (size_t)D * HW;
-        const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x & 31);
-        const int hb = (tile / tiles_w) * K2_TH + (int)(threadIdx.x >> 5);  // rows hb, hb+8, hb+16, hb+24
-        Taps t[4];
-        bool act[4];
+        constexpr int RPP = 256 / K2_TW, NP = K2_TH / RPP;   // rows per pass of the 256 threads, passes
+        const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x % K2_TW);
+        const int hb = (tile / tiles_w) * K2_TH + (int)(threadIdx.x / K2_TW);  // rows hb, hb+RPP, ...
+        Taps t[NP];
+        bool act[NP];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int h = hb + 8 * i;
+        for (int i = 0; i < NP; ++i) {
+            const int h = hb + RPP * i;
             act[i] = h < H && w < W;
             if (act[i]) {
                 const float *cq = coords + (((size_t)b * D + d) * HW + h * W + w) * 3;
@@ -546,10 +682,10 @@ warp_gather_direct_body(const float *__restrict__ v, const float *__restrict__ c
         for (int c = (int)blk_y * cpg; c < c_end; ++c) {
             const float *src = vb + (size_t)c * vol;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NP; ++i) {
                 if (act[i]) {
                     const float r = W >= 2 ? gather8_pairs(src, t[i]) : gather8(src, t[i]);
-                    ob[(size_t)c * vol + 8 * i * W] = r;
+                    ob[(size_t)c * vol + RPP * i * W] = r;
                     mbits = max(mbits, range_bits(r));
                 }
             }
@@ -765,10 +901,17 @@ static size_t k2_tiles(int B, int D, int H, int W) {
     return (size_t)B * D * ((H + K2_TH - 1) / K2_TH) * ((W + K2_TW - 1) / K2_TW);
 }
 
+static size_t k2_todo_bytes(int B, int D, int H, int W) { return ((k2_tiles(B, D, H, W) * sizeof(int) + 15) / 16) * 16; }
 // coordinates [B,D,H,W,3] + one int per K2 tile (which of the two gather kernels takes it)
 extern "C" size_t mphip_warp_workspace_bytes(int B, int D, int H, int W) {
     if (B <= 0 || D <= 0 || H <= 0 || W <= 0) return 0;
-    return (size_t)B * D * H * W * 3 * sizeof(float) + ((k2_tiles(B, D, H, W) * sizeof(int) + 15) / 16) * 16;
+    return (size_t)B * D * H * W * 3 * sizeof(float) + k2_todo_bytes(B, D, H, W);
+}
+// K2's optional corner image (warp_corner_image_kernel): a workspace that is this much larger than the entry point's minimum lets the
+// gather stage low-corner boxes — every box of the reference's own fields — from one compact copy per frame
+extern "C" size_t mphip_warp_corner_image_bytes(int B, int C) {
+    if (B <= 0 || C <= 0) return 0;
+    return (size_t)B * cdiv(C, K2_CG) * K2_IMG_FLOATS * sizeof(float);   // [frame][channel group][6^3 cells][33]
 }
 
 static int launch_coords(const float *field, const float *lin_d, const float *lin_h, const float *lin_w, float *coords,
@@ -783,8 +926,8 @@ static int launch_coords(const float *field, const float *lin_d, const float *li
     return check_launch("warp_coords");
 }
 
-static int warp_volume_gather(const float *v, const float *coords, float *out, float *out_range, int *todo, int B, int C, int D, int H, int W,
-                              hipStream_t s);
+static int warp_volume_gather(const float *v, const float *coords, float *out, float *out_range, int *todo, float *corner_img, bool img_ready,
+                              int B, int C, int D, int H, int W, hipStream_t s);
 
 extern "C" int mphip_warp_volume(const float *v, const float *field, const float *lin_d, const float *lin_h,
                                  const float *lin_w, float *out, float *coords_out, int32_t *idx_out, float *out_range, int B,
@@ -800,17 +943,20 @@ extern "C" int mphip_warp_volume(const float *v, const float *field, const float
     }
     float *coords = coords_out ? coords_out : (float *)workspace;
     int *todo = (int *)((char *)workspace + coord_bytes);
+    float *corner_img = workspace_bytes >= need + mphip_warp_corner_image_bytes(B, C) ? (float *)((char *)workspace + need) : nullptr;
     hipStream_t s = (hipStream_t)stream;
     rc = launch_coords(field, lin_d, lin_h, lin_w, coords, idx_out, B, D, H, W, fD, fH, fW, s);
     if (rc) return rc;
-    return warp_volume_gather(v, coords, out, out_range, todo, B, C, D, H, W, s);
+    return warp_volume_gather(v, coords, out, out_range, todo, corner_img, false, B, C, D, H, W, s);
 }
 
-// the gather pass(es) of K2 on given coordinates; todo: one int per 32x32 tile
-static int warp_volume_gather(const float *v, const float *coords, float *out, float *out_range, int *todo, int B, int C, int D, int H, int W,
-                              hipStream_t s) {
+// the gather pass(es) of K2 on given coordinates; todo: one int per tile; corner_img: optional mphip_warp_corner_image_bytes(B, C) bytes
+static int warp_volume_gather(const float *v, const float *coords, float *out, float *out_range, int *todo, float *corner_img, bool img_ready,
+                              int B, int C, int D, int H, int W, hipStream_t s) {
     int rc;
     const size_t nblocks = k2_tiles(B, D, H, W);
+    // channel groups of the staged gather (its range slots: one per workgroup)
+    const unsigned groups = (!out_range || nblocks * cdiv(C, K2_CG) <= RANGE_MAX_PARTS) ? (unsigned)cdiv(C, K2_CG) : 1u;
     if (out_range && (W % 4 != 0 || nblocks > RANGE_MAX_PARTS)) {
         // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
         // max|out| <= max|v|, so v's own range serves
@@ -820,7 +966,11 @@ static int warp_volume_gather(const float *v, const float *coords, float *out, f
     }
     if (W % 4 == 0) {
         const unsigned ncol = (unsigned)((size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * cdiv(C, K2C_CPB));
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W);
+        if (groups == 1 && C > K2_CG) corner_img = nullptr;   // (the image is laid out per channel group)
+        if (corner_img && !img_ready)
+            hipLaunchKernelGGL(warp_corner_image_kernel, dim3(K2_CORNER_CELLS, (unsigned)B), dim3(128), 0, s, v, corner_img, C, D, H, W, (int)groups);
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks, groups), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W,
+                           (const float *)corner_img, groups == 1 ? C : K2_CG);
         // the tiles it marked: smooth travelling fields -> column walk, incoherent ones -> direct gather (workgroups of the other
         // kind, and all of them on the reference's own fields, exit after one load)
         hipLaunchKernelGGL(warp_gather_columns_kernel, dim3(ncol), dim3(256), 0, s, v, (const float *)coords, out, out_range,
@@ -875,12 +1025,41 @@ extern "C" int mphip_warp_volume_coords(const float *v, const float *coords, flo
     MPHIP_REQUIRE(v && coords && out, "warp_volume_coords: null pointer");
     MPHIP_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "warp_volume_coords: bad dims");
     MPHIP_REQUIRE((size_t)D * H * W < (1u << 30), "warp_volume_coords: volume too large for 32-bit tap offsets");
-    const size_t need = ((k2_tiles(B, D, H, W) * sizeof(int) + 15) / 16) * 16;
+    const size_t need = k2_todo_bytes(B, D, H, W);
     if (!workspace || workspace_bytes < need) {
         set_error("warp_volume_coords: workspace %zu bytes < required %zu", workspace_bytes, need);
         return MPHIP_EWORKSPACE;
     }
-    return warp_volume_gather(v, coords, out, out_range, (int *)workspace, B, C, D, H, W, (hipStream_t)stream);
+    float *corner_img = workspace_bytes >= need + mphip_warp_corner_image_bytes(B, C) ? (float *)((char *)workspace + need) : nullptr;
+    return warp_volume_gather(v, coords, out, out_range, (int *)workspace, corner_img, false, B, C, D, H, W, (hipStream_t)stream);
+}
+
+// The corner image on its own: a caller that has `v` long before the coordinates (the hot slice: vs is an INPUT, the coordinates come out
+// of an 18-launch generator chain) builds it early, off the critical path, and hands it to mphip_warp_volume_coords_img.
+extern "C" int mphip_warp_corner_image(const float *v, void *img, size_t img_bytes, int B, int C, int D, int H, int W, void *stream) {
+    MPHIP_REQUIRE(v && img, "warp_corner_image: null pointer");
+    MPHIP_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "warp_corner_image: bad dims");
+    MPHIP_REQUIRE(((uintptr_t)img & 15) == 0, "warp_corner_image: img must be 16-byte aligned");
+    if (img_bytes < mphip_warp_corner_image_bytes(B, C)) {
+        set_error("warp_corner_image: buffer %zu bytes < required %zu", img_bytes, mphip_warp_corner_image_bytes(B, C));
+        return MPHIP_EWORKSPACE;
+    }
+    hipLaunchKernelGGL(warp_corner_image_kernel, dim3(K2_CORNER_CELLS, (unsigned)B), dim3(128), 0, (hipStream_t)stream, v, (float *)img, C, D, H, W,
+                       cdiv(C, K2_CG));
+    return check_launch("warp_corner_image");
+}
+extern "C" int mphip_warp_volume_coords_img(const float *v, const float *coords, float *out, float *out_range, int B, int C, int D, int H, int W,
+                                            void *workspace, size_t workspace_bytes, const void *img, void *stream) {
+    MPHIP_REQUIRE(v && coords && out && img, "warp_volume_coords_img: null pointer");
+    MPHIP_REQUIRE(B > 0 && C > 0 && D > 0 && H > 0 && W > 0, "warp_volume_coords_img: bad dims");
+    MPHIP_REQUIRE((size_t)D * H * W < (1u << 30), "warp_volume_coords_img: volume too large for 32-bit tap offsets");
+    MPHIP_REQUIRE(((uintptr_t)img & 15) == 0, "warp_volume_coords_img: img must be 16-byte aligned");
+    const size_t need = k2_todo_bytes(B, D, H, W);
+    if (!workspace || workspace_bytes < need) {
+        set_error("warp_volume_coords_img: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    return warp_volume_gather(v, coords, out, out_range, (int *)workspace, (float *)img, true, B, C, D, H, W, (hipStream_t)stream);
 }
 
 // K3 with the coordinate pass already done (mphip_warp_coords): lets a caller look at the sample positions BEFORE the volume is
@@ -1778,3 +1957,9 @@ extern "C" int mphip_rt_theta_bwd(const float *rot, const float *tr, const float
                        invert);
     return check_launch("rt_theta_bwd");
 }
+
+#ifdef MPHIP_K2_TRACE
+extern "C" int mphip_debug_k2_trace(unsigned long long *host_out /* 4096 * 4 */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mphip::g_k2_trace), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+#endif

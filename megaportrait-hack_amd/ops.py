@@ -195,7 +195,7 @@ def warp_volume(v: torch.Tensor, field: torch.Tensor, return_coords: bool = Fals
         idx = torch.empty((b, d, h, w, 3), dtype=torch.int32, device=v.device)
     dev = v.device
     lib = _lib.load()
-    ws_bytes = lib.mphip_warp_workspace_bytes(b, d, h, w)
+    ws_bytes = lib.mphip_warp_workspace_bytes(b, d, h, w) + lib.mphip_warp_corner_image_bytes(b, c)   # (+ K2's optional corner image)
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
     _lib.check(lib.mphip_warp_volume(_ptr(v), _ptr(field), _ptr(linspace_table(d, dev)), _ptr(linspace_table(h, dev)),
                                      _ptr(linspace_table(w, dev)), _ptr(out), _ptr(coords), _ptr(idx), _ptr(rng), b, c, d, h, w,

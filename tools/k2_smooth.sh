@@ -1,0 +1,5 @@
+export TMPDIR=/tmp
+for lib in "$@"; do
+  rm -rf /tmp/kt; MPHIP_LIB=$PWD/$lib rocprofv3 --kernel-trace -d /tmp/kt -- python tools/bench_warps.py 8 20 --only smooth > /dev/null 2>&1
+  db=$(find /tmp/kt -name "*.db" | head -1); echo $lib; python tools/agg_summary.py $db 23 12 | grep -i "warp\|total" | head -8
+done
