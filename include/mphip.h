@@ -74,9 +74,9 @@ int mphip_warp_field_compose(const float *theta, const float *em, const float *b
  * idx_out [B,D,H,W,3] int32 (floor indices; requires coords_out). */
 size_t mphip_warp_workspace_bytes(int B, int D, int H, int W);
 /* Optional, K2 only (mphip_warp_volume / mphip_warp_volume_coords): a workspace that is this many bytes LARGER than the entry point's
- * minimum lets the gather stage low-corner sample boxes — every box of the reference's own fields, which sample voxels inside [0,6)^3
- *  — from one compact copy per frame instead of 1.5 k scattered lines per workgroup (K2 at B=8: 63 -> ~35 us).
- * Results are bit-identical either way. */
+ * minimum lets the gather bring the volume's low corner — voxels [0,6)^3, where every sample of the reference's own fields lies
+ *  — into LDS from one compact copy per frame (one contiguous LDS-DMA transfer per workgroup, issued under its
+ * coordinate loads) instead of collecting it from 96 channel planes itself.  Results are bit-identical either way. */
 size_t mphip_warp_corner_image_bytes(int B, int C);
 /* ... or built on its own, early (the hot slice has `v` long before the coordinates), and handed to the gather (img: 16-byte aligned,
  * mphip_warp_corner_image_bytes(B, C) bytes, layout private to the library; workspace as mphip_warp_volume_coords) */

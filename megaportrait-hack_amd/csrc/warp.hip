@@ -254,7 +254,30 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-// Block-wide bounding box of the (x0,y0,z0) corners, extended by the +1 corner and clamped.
+// Block-wide bounding box of the (x0,y0,z0) corners, extended by the +1 corner and clamped (NW waves; red: NW * 6 ints of LDS).
+template <int NW>
+__device__ __forceinline__ Box block_box_n(int lx, int ly, int lz, int hx, int hy, int hz, int D, int H, int W, int *red) {
+    lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
+    hx = wave_max(hx); hy = wave_max(hy); hz = wave_max(hz);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        red[wave * 6 + 0] = lx; red[wave * 6 + 1] = ly; red[wave * 6 + 2] = lz;
+        red[wave * 6 + 3] = hx; red[wave * 6 + 4] = hy; red[wave * 6 + 5] = hz;
+    }
+    __syncthreads();
+    int m[6] = {red[0], red[1], red[2], red[3], red[4], red[5]};
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        m[0] = min(m[0], red[w * 6]); m[1] = min(m[1], red[w * 6 + 1]); m[2] = min(m[2], red[w * 6 + 2]);
+        m[3] = max(m[3], red[w * 6 + 3]); m[4] = max(m[4], red[w * 6 + 4]); m[5] = max(m[5], red[w * 6 + 5]);
+    }
+    Box bx;
+    bx.ox = m[0]; bx.oy = m[1]; bx.oz = m[2];
+    bx.ex = min(m[3] + 1, W - 1) - bx.ox + 1;
+    bx.ey = min(m[4] + 1, H - 1) - bx.oy + 1;
+    bx.ez = min(m[5] + 1, D - 1) - bx.oz + 1;
+    return bx;
+}
 __device__ __forceinline__ Box block_box(int lx, int ly, int lz, int hx, int hy, int hz, int D, int H, int W,
                                          int *red /* >= 24 ints of LDS */) {
     lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
@@ -390,124 +413,132 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
     return p;
 }
 
-// K2: a workgroup owns a compact 32 x 32 tile of (h,w) positions of one (b,d) plane, 4 consecutive w per thread
-// (16-byte stores, a wave writes eight 128-byte rows), all C channels.  If the tile's source box fits the LDS image with
-// >= 8 channels per pass (always, for the reference's own fields: they never leave the 4^3 low corner) it is staged and
-// gathered from LDS.  Any other tile — a field that really travels through the volume — is only MARKED here (todo[tile] = 1)
-// and done by warp_gather_columns_kernel / warp_gather_direct_kernel below: keeping that path out of this kernel keeps it lean (registers: the
-// staged path lost 25 % when both lived in one kernel).
-// (r03: a [voxel][channel] image with four channels per ds_read_b128 tap — K3's gather8x4, 2 LDS reads per output value instead of
-//  8 — measured 82 vs 77 us for the whole op at B=8, same box: LDS issue is not what bounds this kernel; removed.  A plain fill of
-//  the same 201 MB runs at 7.6 TB/s on this chip (tools/probe_write_bw.py), the gather writes at 3.8.)
-constexpr int K2_TH = 16, K2_TW = 32;   // 512 positions per workgroup, two per thread
-#ifndef MPHIP_K2_UNROLL
-#define MPHIP_K2_UNROLL 2
-#endif
-constexpr int K2_UNROLL = MPHIP_K2_UNROLL;   // channels per trip of the gather loop (their offsets are immediates)
-constexpr int K2_STAGE_FLOATS = 8192;    // 32 KB of LDS for the staged box: four workgroups (16 waves) per CU
-constexpr int K2_DIRECT_SPLIT = 2;  // channel groups of the direct gather (warp_gather_direct_body)
+// K2, tiles whose samples all lie in the volume's LOW CORNER — every tile of the reference's own fields (apply_warping_field hands
+// grid_sample coordinates of size ~[-2, 3] as if they were voxel indices).  Any other tile — a field that really
+// travels through the volume — is only MARKED here (todo[tile]) and done by warp_gather_columns_kernel / warp_gather_direct_kernel
+// below: keeping those paths out of this kernel keeps it lean.
+//
+// How it got its shape (r04; wall-clock stamps per workgroup, tools/dbg_k2_trace.py, and ablations, tools/k2_ablate.sh, B=8):
+//   * r03 (32 x 32 tile, four positions per thread, every workgroup staging its own source box line by line from global memory —
+//     1.5 k scattered 128-byte lines, the rows of all 96 planes on the same few L2 channels): 63 us.  Not the stores: without them
+//     59 us.  Not the tap arithmetic either: half the VALU instructions (packed fp32), no address arithmetic in the loop, half the
+//     dependent chain per wave at four waves per SIMD — each +-0.  The stamps: the gather LOOPS wrote at ~7.7 TB/s, the speed of a
+//     plain fill of the same 201 MB, but covered less than half of a workgroup's life; in front of them sat three dependent
+//     round trips (coordinates -> box -> staging loads), and a tail of workgroups whose staging loads queued behind the store flood
+//     of the others ended at 60 us when the median had ended at 34.
+//   * So the corner [0,E)^3 of every frame is copied ONCE per call (warp_corner_image_kernel; the hot slice does it at the start of
+//     its step, vs is an input) into a compact image that already has the LDS layout, [frame][channel group][cell][channels + pad],
+//     contiguous — all L2 channels serve it — and a workgroup brings its block in by LDS-DMA, issued FIRST THING: it lands under
+//     the coordinate loads and the box reduction.  One global round trip in front of the stores instead of three.
+//   * More, smaller workgroups (3072 of 256 threads, three resident rounds) gave 50 us: every workgroup pays the coordinate round
+//     trip (3.7 us) before it stores for 7 us.  One workgroup per CU and launch does better: 1024 threads own a 32 x 64 tile of one
+//     (b,d) plane, two positions per thread, ALL channels (image: 6^3 cells x 97 floats = 84 KB), one prologue, then nothing but
+//     tap reads and stores.  Few tiles (B = 1, 2): the channels are split over blockIdx.y so that every CU has work.
+//   * The image is [cell][channel] with an ODD channel pitch: lanes that read different cells fall on different banks, the channel
+//     is an immediate offset of the tap read (no address arithmetic in the loop) and one ds_read2_b32 brings two channels.
+// Values: per channel and position exactly gather8's op sequence (acc = 0; acc += p_k * w_k in tap order, one rounding per op).
+constexpr int K2_TH = 32, K2_TW = 64;      // 2048 positions per workgroup, two per thread
+constexpr int K2_THREADS = 1024;
+constexpr int K2_DIRECT_SPLIT = 4;         // channel groups of the direct gather (warp_gather_direct_body)
 constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a tile up to which the column walk is used
-// r04: the r03 kernel (32 x 32 tile, four positions per thread, planar image, 142 registers, two waves per SIMD) ran its channel loop
-// as one dependent chain per wave — 32 address adds -> 32 tap reads -> wait -> 64 multiply / adds -> store, ~960 cycles per channel — with
-// nothing to overlap it with: ablations on the reference's fields (tools/k2_ablate.sh): no stores 62 -> 59 us (the 201 MB written are NOT
-// what bounds it), no tap reads 37 us.  Now: two positions per thread (half the chain, < 128 registers -> four waves per SIMD), the image
-// [box voxel][channel] with an ODD channel pitch so that the channel is an IMMEDIATE offset of the tap read (no address arithmetic in the
-// loop; two channels per ds_read2_b32), 32 KB of LDS per workgroup.
-// The reference's own fields sample the LOW CORNER of the volume: every workgroup of a frame stages the same
-// few voxels of all its channel planes — 1.5 k scattered 128-byte lines per workgroup in r03 — after it has loaded its coordinates
-// and reduced its box: three dependent memory round trips before the first store.  Wall-clock stamps per workgroup
-// (tools/dbg_k2_trace.py, B=8): the gather loops themselves write at ~7.7 TB/s, the speed of a plain fill, but they covered less than
-// half of a workgroup's life, and a tail of workgroups whose staging loads queued behind the others' stores ended at 60 us when the
-// median had ended at 34.  So the corner [0,E)^3 of every frame is copied ONCE per call into a compact image that already has the
-// LDS layout, [frame][channel group][cell][K2_CG + 1] (28 KB per block, contiguous: all L2 channels), and a workgroup brings its block
-// in with 28 LDS-DMA instructions issued FIRST THING — under its coordinate loads and box reduction.  A box that leaves the corner
-// (not the reference's fields) is staged by stage_box after all.
 constexpr int K2_CORNER_E = 6;
 constexpr int K2_CORNER_CELLS = K2_CORNER_E * K2_CORNER_E * K2_CORNER_E;
-constexpr int K2_CG = 32;                       // channels per workgroup (blockIdx.y)
-constexpr int K2_CGP = K2_CG | 1;               // odd channel pitch: lanes that read different cells fall on different banks
-constexpr int K2_IMG_FLOATS = K2_CORNER_CELLS * K2_CGP;   // 7128 floats = 28512 B (a multiple of 16)
+constexpr int K2_CG_MAX = 96;              // channels per workgroup at most (LDS: 216 x 97 floats = 83808 B)
+constexpr int K2_LDS_FLOATS = K2_CORNER_CELLS * (K2_CG_MAX | 1);
+// channels per workgroup (blockIdx.y groups): all of them (<= 96) when the tiles alone fill the chip, else 32 or 16
+__host__ __device__ inline int k2_group_channels(size_t tiles, int C) {
+    int cg = min(C, K2_CG_MAX);
+    if (tiles * (size_t)((C + cg - 1) / cg) < 256 && C > 32) cg = 32;
+    if (tiles * (size_t)((C + cg - 1) / cg) < 256 && C > 16) cg = 16;
+    return cg;
+}
+// image: [frame][group][cell][cg | 1] floats, a group's block padded to a multiple of 16 bytes
+__host__ __device__ inline size_t k2_block_floats(int cg) { return ((size_t)K2_CORNER_CELLS * (cg | 1) + 3) / 4 * 4; }
 __global__ void __launch_bounds__(128)
-warp_corner_image_kernel(const float *__restrict__ v, float *__restrict__ img, int C, int D, int H, int W, int groups) {
+warp_corner_image_kernel(const float *__restrict__ v, float *__restrict__ img, int C, int D, int H, int W, int cg, int groups) {
     const int cell = blockIdx.x, b = blockIdx.y;
     const int z = cell / (K2_CORNER_E * K2_CORNER_E), y = (cell / K2_CORNER_E) % K2_CORNER_E, x = cell % K2_CORNER_E;
     const bool inside = z < D && y < H && x < W;
-    const size_t vol = (size_t)D * H * W;
-    for (int c = threadIdx.x; c < groups * K2_CGP; c += 128) {   // (the pad slot and channels >= C: zeros, the block is copied whole)
-        const int g = c / K2_CGP, cl = c - g * K2_CGP, ch = g * K2_CG + cl;
-        const bool real = inside && cl < K2_CG && ch < C;
-        img[(((size_t)b * groups + g) * K2_CORNER_CELLS + cell) * K2_CGP + cl] = real ? v[((size_t)b * C + ch) * vol + ((size_t)z * H + y) * W + x] : 0.0f;
+    const size_t vol = (size_t)D * H * W, blk = k2_block_floats(cg);
+    const int cgp = cg | 1;
+    for (int c = threadIdx.x; c < groups * cgp; c += 128) {   // (the pad slot and channels >= C: zeros, the block is copied whole)
+        const int g = c / cgp, cl = c - g * cgp, ch = g * cg + cl;
+        const bool real = inside && cl < cg && ch < C;
+        img[((size_t)b * groups + g) * blk + (size_t)cell * cgp + cl] = real ? v[((size_t)b * C + ch) * vol + ((size_t)z * H + y) * W + x] : 0.0f;
     }
 }
 // one block of the corner image -> LDS, as LDS-DMA (16 bytes per lane, 1 KiB per wave and instruction, no registers); issued by hand:
 // the compiler would wait for each transfer before the next LDS access.  The caller waits (vmcnt(0)) before its barrier.
-__device__ __forceinline__ void k2_dma_image(const float *__restrict__ blk, float *lds) {
+__device__ __forceinline__ void k2_dma_image(const float *__restrict__ blk, float *lds, int floats) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) float *)lds;
-    constexpr int PIECES = (K2_IMG_FLOATS * 4 + 1023) / 1024;   // 28
-    for (int q = wave; q < PIECES; q += 4) {
+    const int pieces = (floats + 255) / 256;
+    for (int q = wave; q < pieces; q += K2_THREADS / 64) {
         const int f = q * 256 + lane * 4;   // float index of this lane's 16 bytes
-        if (f < K2_IMG_FLOATS) {
+        if (f < floats) {
             const float *src = blk + f;
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds0 + (unsigned)q * 1024u) : "memory");
         }
     }
 }
+// ... and without an image (a caller whose workspace has no room for it): the workgroup collects its block itself
+__device__ __forceinline__ void k2_stage_corner(const float *__restrict__ vb, float *lds, int c0, int cs, int cgp, int D, int H, int W) {
+    const size_t vol = (size_t)D * H * W;
+    for (int i = threadIdx.x; i < K2_CORNER_CELLS * cs; i += K2_THREADS) {
+        const int c = i / K2_CORNER_CELLS, cell = i - c * K2_CORNER_CELLS;   // lanes along cells: neighbours share lines
+        const int z = cell / (K2_CORNER_E * K2_CORNER_E), y = (cell / K2_CORNER_E) % K2_CORNER_E, x = cell % K2_CORNER_E;
+        lds[cell * cgp + c] = (z < D && y < H && x < W) ? vb[(size_t)(c0 + c) * vol + ((size_t)z * H + y) * W + x] : 0.0f;
+    }
+}
 
-// (the product as an opaque instruction: hipcc's SLP vectoriser otherwise re-packs the two channels of a tap into v_pk_mul_f32 /
-//  v_pk_add_f32 on DUPLICATED weight pairs — 180 more registers' worth of pressure, 700 B of scratch at four waves per SIMD — and the
-//  packed fp32 ops are no faster than two scalar ones on this chip: r04 measured +-0 for half the instructions)
-__device__ __forceinline__ float k2_mul(float a, float b) {
-    float m;
-    asm("v_mul_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+// The tap arithmetic on the PACKED fp32 pipe, two channels per instruction: the (c, c+1) pair of a tap is exactly what one ds_read2_b32
+// returns, and the tap's weight is broadcast to both halves by op_sel — weights stay single registers (pairs {w_2j, w_2j+1}, even / odd
+// picked by the instruction's op_sel bits).  Written as inline assembly because hipcc's own packing of this loop duplicates every weight
+// into a register pair (+180 registers, 700 B of scratch at 128).  With the staging gone the loop is VALU-bound (95 -> 52 instructions per
+// channel pair).  Per channel and position still acc = 0; acc = acc + p_k * w_k in tap order, one rounding per op.
+typedef float k2_f2 __attribute__((ext_vector_type(2)));
+template <int ODD>
+__device__ __forceinline__ k2_f2 k2_pk_mul(k2_f2 p, k2_f2 wpair) {
+    k2_f2 m;
+    if (ODD) asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(m) : "v"(p), "v"(wpair));
+    else     asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(m) : "v"(p), "v"(wpair));
     return m;
 }
-__device__ __forceinline__ float k2_add(float a, float b) {
-    float m;
-    asm("v_add_f32_e32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+__device__ __forceinline__ k2_f2 k2_pk_add(k2_f2 a, k2_f2 b) {
+    k2_f2 m;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
     return m;
 }
-#ifdef MPHIP_K2_TRACE   /* dev: wall-clock (100 MHz) stamps per workgroup: start, box known, first image staged, done */
+#ifdef MPHIP_K2_TRACE   /* dev: wall-clock (100 MHz) stamps per workgroup: start, box known, image staged, done */
 __device__ unsigned long long g_k2_trace[4096 * 4];
 #define K2_STAMP(i) if (threadIdx.x == 0 && blockIdx.y * gridDim.x + blockIdx.x < 4096) g_k2_trace[(blockIdx.y * gridDim.x + blockIdx.x) * 4 + (i)] = wall_clock64();
 #else
 #define K2_STAMP(i)
 #endif
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(K2_THREADS)
 warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords, float *__restrict__ out,
                    float *__restrict__ out_range /* optional range descriptor of `out`: G3d's first conv reads it */,
                    int *__restrict__ todo, int B, int C, int D, int H, int W,
-                   const float *__restrict__ img /* optional corner image (warp_corner_image_kernel; then cg == K2_CG) */,
-                   int cg /* channels per blockIdx.y */) {
-    __shared__ __attribute__((aligned(16))) float lds[K2_STAGE_FLOATS];
-    __shared__ int red[24];
+                   const float *__restrict__ img /* optional corner image (warp_corner_image_kernel, same cg) */, int cg /* channels per blockIdx.y */) {
+    __shared__ __attribute__((aligned(16))) float lds[K2_LDS_FLOATS];
+    __shared__ int red[(K2_THREADS / 64) * 6];
     K2_STAMP(0)
     const int HW = H * W;
     const int tiles_w = (W + K2_TW - 1) / K2_TW, tiles_h = (H + K2_TH - 1) / K2_TH;
-    // XCD-aware order: consecutive logical ids (d fastest, then tile, then frame) run on the same XCD, so the source planes two
-    // neighbouring output slices share meet in that XCD's L2
+    // XCD-aware order: consecutive logical ids (d fastest, then tile, then frame) run on the same XCD
     const unsigned bid = xcd_remap(blockIdx.x, gridDim.x);
     const int d = (int)(bid % (unsigned)D);
     const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
     const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
+    const int cg0 = (int)blockIdx.y * cg, Cg = min(C - cg0, cg), cgp = cg | 1;
     // The image is fetched only if the tile's FIRST sample lies in the corner (one scalar load): a field that travels through the volume
-    // (not the reference's) would otherwise pay 28 KB of transfers per workgroup for nothing.
-    bool dma = false;
-    if (img) {
-        const float *c0p = coords + (((size_t)b * D + d) * HW + (size_t)(tile / tiles_w) * K2_TH * W + (tile % tiles_w) * K2_TW) * 3;
-        const float fx = c0p[0], fy = c0p[1], fz = c0p[2];
-        dma = fx >= 0.0f && fx < (float)(K2_CORNER_E - 1) && fy >= 0.0f && fy < (float)(K2_CORNER_E - 1) && fz >= 0.0f && fz < (float)(K2_CORNER_E - 1);
-    }
-    // (channel groups > 0 exist for the corner image's sake: elsewhere group 0 does the tile alone, with `cg` = all channels)
-    if (img && !dma) {
-        if (blockIdx.y > 0) {
-            if (out_range) range_note_block(0u, out_range, blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-            return;
-        }
-        cg = C;
-    }
+    // (not the reference's) would otherwise pay for the transfers for nothing.
+    const float *c0p = coords + (((size_t)b * D + d) * HW + (size_t)(tile / tiles_w) * K2_TH * W + (tile % tiles_w) * K2_TW) * 3;
+    const float fx = c0p[0], fy = c0p[1], fz = c0p[2];
+    const bool maybe = fx >= 0.0f && fx < (float)(K2_CORNER_E - 1) && fy >= 0.0f && fy < (float)(K2_CORNER_E - 1) && fz >= 0.0f && fz < (float)(K2_CORNER_E - 1);
+    const bool dma = maybe && img != nullptr;
 #ifndef MPHIP_K2_ABL_NOSTAGE   /* dev ablations (timing only, wrong results): tools/k2_ablate.sh */
-    if (dma) k2_dma_image(img + ((size_t)b * gridDim.y + blockIdx.y) * K2_IMG_FLOATS, lds);   // lands under the coordinate loads / box reduction
+    if (dma) k2_dma_image(img + ((size_t)b * gridDim.y + blockIdx.y) * k2_block_floats(cg), lds, (int)k2_block_floats(cg));
 #endif
     const int h = (tile / tiles_w) * K2_TH + (int)(threadIdx.x / (K2_TW / 2));
     const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x % (K2_TW / 2)) * 2;
@@ -535,107 +566,83 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
             hx = max(hx, x0[i]); hy = max(hy, y0[i]); hz = max(hz, z0[i]);
         }
     }
-    const Box bx = block_box(lx, ly, lz, hx, hy, hz, D, H, W, red);
+    const Box bx = block_box_n<K2_THREADS / 64>(lx, ly, lz, hx, hy, hz, D, H, W, red);
     K2_STAMP(1)
-    // blockIdx.y = channel group of cg channels: three times the workgroups (the dispatcher back-fills CUs as workgroups end; with ONE
-    // resident round a tail of slow workgroups set the kernel's time) and a group's image of a <= 6^3 box fits one pass (a second pass
-    // waits for the first pass's stores: vmcnt counts them too)
-    const int cg0 = (int)blockIdx.y * cg, Cg = min(C - cg0, cg);
-    // block-uniform: the whole tile samples the corner whose image is on its way into the LDS
-    const bool in_corner = dma && bx.ox + bx.ex <= K2_CORNER_E && bx.oy + bx.ey <= K2_CORNER_E && bx.oz + bx.ez <= K2_CORNER_E;
-    const Box ibx = in_corner ? Box{0, 0, 0, K2_CORNER_E, K2_CORNER_E, K2_CORNER_E} : bx;   // the box the LDS image holds
-    const int bvol = ibx.ex * ibx.ey * ibx.ez;
-    const int pfit = bvol > 0 ? K2_STAGE_FLOATS / bvol : 0;   // floats per box voxel that fit
-    const bool one_pass = (Cg | 1) <= pfit;
-    const int pitch = in_corner ? K2_CGP : one_pass ? (Cg | 1) : ((pfit - 1) | 1);   // odd: lanes that read different voxels fall on different banks
-    const int cs_max = (in_corner || one_pass) ? Cg : (pitch & ~7);
-    const float *vb = v + (size_t)b * C * vol;
-    float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
-    unsigned mbits = 0;
-    // block-uniform.  With a corner image, only corner tiles are gathered here: a box elsewhere that happens to fit the LDS would be
-    // staged line by line from global memory in several passes — slower than the column walk that takes the tile otherwise
-    const bool staged = in_corner || (!img && cs_max >= 8);
+    // block-uniform: every sample of the tile (all eight corners of each) inside the corner the image holds
+    const bool in_corner = bx.ox + bx.ex <= K2_CORNER_E && bx.oy + bx.ey <= K2_CORNER_E && bx.oz + bx.ez <= K2_CORNER_E;
     // 0: done here; 1: a box of moderate size = a smooth field that travels -> warp_gather_columns_body (plane reuse down the
     // slices); 2: no locality to exploit (a box like the whole volume) -> warp_gather_direct_body (most loads in flight)
-    if (threadIdx.x == 0) todo[bid] = staged ? 0 : (bx.ex * bx.ey * bx.ez <= K2_COLUMNS_MAX_BOX ? 1 : 2);
-
-    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the corner image has landed (or must have, before it is overwritten)
-    if (staged) {
-        int tb[2][8];   // tap addresses in the image (floats, premultiplied by the pitch)
+    if (threadIdx.x == 0 && blockIdx.y == 0) todo[bid] = in_corner ? 0 : (bx.ex * bx.ey * bx.ez <= K2_COLUMNS_MAX_BOX ? 1 : 2);
+    unsigned mbits = 0;
+    if (dma) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the image have landed
+    if (in_corner) {
+        float *ob = out + (size_t)b * C * vol + (size_t)d * HW + p0;
+#ifndef MPHIP_K2_ABL_NOSTAGE
+        if (!dma) k2_stage_corner(v + (size_t)b * C * vol, lds, cg0, Cg, cgp, D, H, W);
+#endif
+        __syncthreads();
+        K2_STAMP(2)
         if (active) {
+            int tb[2][8];   // tap addresses in the image (floats, premultiplied by the pitch)
+            const Box cbx{0, 0, 0, K2_CORNER_E, K2_CORNER_E, K2_CORNER_E};
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const TapOff o = rebase(taps[i], x0[i], y0[i], z0[i], ibx, pitch);
+                const TapOff o = rebase(taps[i], x0[i], y0[i], z0[i], cbx, cgp);
                 tb[i][0] = o.base; tb[i][1] = o.base + o.dx; tb[i][2] = o.base + o.dy; tb[i][3] = o.base + o.dy + o.dx;
                 tb[i][4] = o.base + o.dz; tb[i][5] = o.base + o.dz + o.dx; tb[i][6] = o.base + o.dz + o.dy;
                 tb[i][7] = o.base + o.dz + o.dy + o.dx;
             }
-        }
-        for (int c0 = cg0; c0 < cg0 + Cg; c0 += cs_max) {
-            const int cs = min(cs_max, cg0 + Cg - c0);
-            if (c0 != cg0 || (dma && !in_corner)) __syncthreads();   // (every wave's part of the unused image has landed)
-#ifndef MPHIP_K2_ABL_NOSTAGE
-            if (!in_corner) stage_box(vb, lds, bx, c0, cs, pitch, H, W, vol);
-#endif
-            __syncthreads();
-            if (c0 == cg0) { K2_STAMP(2) }
-#ifdef MPHIP_K2_ABL_NOLOOP
-            if (active && bvol == 12345) {
-#else
-            if (active) {
-#endif
-                unsigned mb2 = 0;
-                // per channel and position exactly gather8's op sequence (acc = 0; acc += p_k * w_k in tap order, one rounding per op)
-                auto two_channels = [&](const float *src, int c) {
-                    float pa[2][8], pb[2][8];
+            k2_f2 wp[2][4];   // the taps' weights in pairs
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            pa[i][k] = src[tb[i][k]];
-                            pb[i][k] = src[tb[i][k] + 1];
-                        }
-                    float ra[2], rb[2];
+                for (int j = 0; j < 4; ++j) wp[i][j] = k2_f2{taps[i].w[2 * j], taps[i].w[2 * j + 1]};
+            auto two_channels = [&](const float *src, int c) {
+                k2_f2 pv[2][8];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        ra[i] = 0.0f; rb[i] = 0.0f;
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            ra[i] = k2_add(ra[i], k2_mul(pa[i][k], taps[i].w[k]));
-                            rb[i] = k2_add(rb[i], k2_mul(pb[i][k], taps[i].w[k]));
-                        }
+                    for (int k = 0; k < 8; ++k) pv[i][k] = k2_f2{src[tb[i][k]], src[tb[i][k] + 1]};
+                k2_f2 acc[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[i] = k2_f2{0.0f, 0.0f};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i] = k2_pk_add(acc[i], k2_pk_mul<0>(pv[i][2 * j], wp[i][j]));
+                        acc[i] = k2_pk_add(acc[i], k2_pk_mul<1>(pv[i][2 * j + 1], wp[i][j]));
                     }
-#ifdef MPHIP_K2_ABL_NOSTORE
-                    if (ra[0] == 1.2345e30f)
-#endif
-                    {
-                        *reinterpret_cast<float2 *>(ob + (size_t)(c0 + c) * vol) = make_float2(ra[0], ra[1]);
-                        *reinterpret_cast<float2 *>(ob + (size_t)(c0 + c + 1) * vol) = make_float2(rb[0], rb[1]);
-                    }
-                    mb2 = max(max(mb2, range_bits(ra[0])), max(range_bits(ra[1]), max(range_bits(rb[0]), range_bits(rb[1]))));
-                    __builtin_amdgcn_sched_barrier(0);   // one channel pair at a time (hoisting the next pairs' reads spills)
-                };
-                auto one_channel = [&](const float *src, int c) {   // (odd tail)
-                    float r[2];
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        r[i] = 0.0f;
-#pragma unroll
-                        for (int k = 0; k < 8; ++k) r[i] += src[tb[i][k]] * taps[i].w[k];
-                    }
-                    *reinterpret_cast<float2 *>(ob + (size_t)(c0 + c) * vol) = make_float2(r[0], r[1]);
-                    mb2 = max(mb2, max(range_bits(r[0]), range_bits(r[1])));
-                };
-                int c = 0;
-                for (; c + K2_UNROLL <= cs; c += K2_UNROLL) {
-                    const float *src = lds + c;
-#pragma unroll
-                    for (int u = 0; u < K2_UNROLL; u += 2) two_channels(src + u, c + u);
                 }
-                for (; c + 2 <= cs; c += 2) two_channels(lds + c, c);
-                if (c < cs) one_channel(lds + c, c);
-                mbits = max(mbits, mb2);
+#ifdef MPHIP_K2_ABL_NOSTORE
+                if (acc[0][0] == 1.2345e30f)
+#endif
+                {
+                    *reinterpret_cast<float2 *>(ob + (size_t)(cg0 + c) * vol) = make_float2(acc[0][0], acc[1][0]);
+                    *reinterpret_cast<float2 *>(ob + (size_t)(cg0 + c + 1) * vol) = make_float2(acc[0][1], acc[1][1]);
+                }
+                mbits = max(max(mbits, range_bits(acc[0][0])), max(range_bits(acc[0][1]), max(range_bits(acc[1][0]), range_bits(acc[1][1]))));
+                __builtin_amdgcn_sched_barrier(0);   // one channel pair at a time (hoisting the next pairs' reads spills)
+            };
+            int c = 0;
+#ifndef MPHIP_K2_ABL_NOLOOP
+            for (; c + 8 <= Cg; c += 8) {   // (eight channels per trip: their offsets are immediates of the tap reads)
+                const float *src = lds + c;
+#pragma unroll
+                for (int u = 0; u < 8; u += 2) two_channels(src + u, c + u);
             }
+            for (; c + 2 <= Cg; c += 2) two_channels(lds + c, c);
+            if (c < Cg) {   // odd tail
+                float r[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    r[i] = 0.0f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) r[i] += lds[c + tb[i][k]] * taps[i].w[k];
+                }
+                *reinterpret_cast<float2 *>(ob + (size_t)(cg0 + c) * vol) = make_float2(r[0], r[1]);
+                mbits = max(mbits, max(range_bits(r[0]), range_bits(r[1])));
+            }
+#endif
         }
     }
     // (slot = group * tiles + tile: the follow-up kernels fold into group 0's slots)
@@ -659,9 +666,13 @@ warp_gather_direct_body(const float *__restrict__ v, const float *__restrict__ c
         const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
         const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
         const size_t vol = (size_t)D * HW;
-        constexpr int RPP = 256 / K2_TW, NP = K2_TH / RPP;   // rows per pass of the 256 threads, passes
+        // a workgroup takes four passes of 256 positions (RPP rows each): blk_y = (row part of the tile) * K2_DIRECT_SPLIT + channel group
+        constexpr int RPP = 256 / K2_TW, NP = 4;
+        static_assert(K2_TH % (NP * RPP) == 0, "tile rows");
+        const int part = (int)blk_y / K2_DIRECT_SPLIT;
+        blk_y %= K2_DIRECT_SPLIT; grid_y = K2_DIRECT_SPLIT;
         const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x % K2_TW);
-        const int hb = (tile / tiles_w) * K2_TH + (int)(threadIdx.x / K2_TW);  // rows hb, hb+RPP, ...
+        const int hb = (tile / tiles_w) * K2_TH + part * NP * RPP + (int)(threadIdx.x / K2_TW);  // rows hb, hb+RPP, ...
         Taps t[NP];
         bool act[NP];
 #pragma unroll
@@ -911,7 +922,10 @@ extern "C" size_t mphip_warp_workspace_bytes(int B, int D, int H, int W) {
 // gather stage low-corner boxes — every box of the reference's own fields — from one compact copy per frame
 extern "C" size_t mphip_warp_corner_image_bytes(int B, int C) {
     if (B <= 0 || C <= 0) return 0;
-    return (size_t)B * cdiv(C, K2_CG) * K2_IMG_FLOATS * sizeof(float);   // [frame][channel group][6^3 cells][33]
+    size_t fl = 0;   // [frame][channel group][6^3 cells][cg | 1], for whichever grouping the launch picks
+    for (int cg : {min(C, K2_CG_MAX), 32, 16})
+        if (cg <= C) fl = std::max(fl, (size_t)cdiv(C, cg) * k2_block_floats(cg));
+    return (size_t)B * fl * sizeof(float);
 }
 
 static int launch_coords(const float *field, const float *lin_d, const float *lin_h, const float *lin_w, float *coords,
@@ -955,9 +969,10 @@ static int warp_volume_gather(const float *v, const float *coords, float *out, f
                               int B, int C, int D, int H, int W, hipStream_t s) {
     int rc;
     const size_t nblocks = k2_tiles(B, D, H, W);
-    // channel groups of the staged gather (its range slots: one per workgroup)
-    const unsigned groups = (!out_range || nblocks * cdiv(C, K2_CG) <= RANGE_MAX_PARTS) ? (unsigned)cdiv(C, K2_CG) : 1u;
-    if (out_range && (W % 4 != 0 || nblocks > RANGE_MAX_PARTS)) {
+    // channel groups of the corner gather (its range slots: one per workgroup)
+    const int cg = k2_group_channels(nblocks, C);
+    const unsigned groups = (unsigned)cdiv(C, cg);
+    if (out_range && (W % 4 != 0 || nblocks * groups > RANGE_MAX_PARTS)) {
         // (scalar fallback kernel / more workgroups than partial slots) the warp is a convex combination of v's voxels:
         // max|out| <= max|v|, so v's own range serves
         rc = absmax_range_launch(v, (size_t)B * C * D * H * W, out_range, s);
@@ -966,16 +981,15 @@ static int warp_volume_gather(const float *v, const float *coords, float *out, f
     }
     if (W % 4 == 0) {
         const unsigned ncol = (unsigned)((size_t)B * ((H + 15) / 16) * ((W + 15) / 16) * cdiv(C, K2C_CPB));
-        if (groups == 1 && C > K2_CG) corner_img = nullptr;   // (the image is laid out per channel group)
         if (corner_img && !img_ready)
-            hipLaunchKernelGGL(warp_corner_image_kernel, dim3(K2_CORNER_CELLS, (unsigned)B), dim3(128), 0, s, v, corner_img, C, D, H, W, (int)groups);
-        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks, groups), dim3(256), 0, s, v, coords, out, out_range, todo, B, C, D, H, W,
-                           (const float *)corner_img, groups == 1 ? C : K2_CG);
+            hipLaunchKernelGGL(warp_corner_image_kernel, dim3(K2_CORNER_CELLS, (unsigned)B), dim3(128), 0, s, v, corner_img, C, D, H, W, cg, (int)groups);
+        hipLaunchKernelGGL(warp_gather_kernel, dim3((unsigned)nblocks, groups), dim3(K2_THREADS), 0, s, v, coords, out, out_range, todo, B, C, D, H, W,
+                           (const float *)corner_img, cg);
         // the tiles it marked: smooth travelling fields -> column walk, incoherent ones -> direct gather (workgroups of the other
         // kind, and all of them on the reference's own fields, exit after one load)
         hipLaunchKernelGGL(warp_gather_columns_kernel, dim3(ncol), dim3(256), 0, s, v, (const float *)coords, out, out_range,
                            (const int *)todo, B, C, D, H, W);
-        hipLaunchKernelGGL(warp_gather_direct_kernel, dim3((unsigned)nblocks, K2_DIRECT_SPLIT), dim3(256), 0, s, v, (const float *)coords,
+        hipLaunchKernelGGL(warp_gather_direct_kernel, dim3((unsigned)nblocks, K2_DIRECT_SPLIT * (K2_TH / (4 * (256 / K2_TW)))), dim3(256), 0, s, v, (const float *)coords,
                            out, out_range, (const int *)todo, B, C, D, H, W);
     } else {
         const int cpb = C >= 48 ? 12 : C;
@@ -1044,8 +1058,9 @@ extern "C" int mphip_warp_corner_image(const float *v, void *img, size_t img_byt
         set_error("warp_corner_image: buffer %zu bytes < required %zu", img_bytes, mphip_warp_corner_image_bytes(B, C));
         return MPHIP_EWORKSPACE;
     }
+    const int cg = k2_group_channels(k2_tiles(B, D, H, W), C);
     hipLaunchKernelGGL(warp_corner_image_kernel, dim3(K2_CORNER_CELLS, (unsigned)B), dim3(128), 0, (hipStream_t)stream, v, (float *)img, C, D, H, W,
-                       cdiv(C, K2_CG));
+                       cg, cdiv(C, cg));
     return check_launch("warp_corner_image");
 }
 extern "C" int mphip_warp_volume_coords_img(const float *v, const float *coords, float *out, float *out_range, int B, int C, int D, int H, int W,
