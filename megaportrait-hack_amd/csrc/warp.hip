@@ -432,10 +432,13 @@ __device__ __forceinline__ int lds_pitch_for(int channels) {
 //     the coordinate loads and the box reduction.  One global round trip in front of the stores instead of three.
 //   * More, smaller workgroups (3072 of 256 threads, three resident rounds) gave 50 us: every workgroup pays the coordinate round
 //     trip (3.7 us) before it stores for 7 us.  One workgroup per CU and launch does better: 1024 threads own a 32 x 64 tile of one
-//     (b,d) plane, two positions per thread, ALL channels (image: 6^3 cells x 97 floats = 84 KB), one prologue, then nothing but
+//     (b,d) plane, two positions per thread, ALL channels (image: 6^3 cells x 98 floats = 85 KB), one prologue, then nothing but
 //     tap reads and stores.  Few tiles (B = 1, 2): the channels are split over blockIdx.y so that every CU has work.
-//   * The image is [cell][channel] with an ODD channel pitch: lanes that read different cells fall on different banks, the channel
-//     is an immediate offset of the tap read (no address arithmetic in the loop) and one ds_read2_b32 brings two channels.
+//   * The image is [cell][channel], channel pitch = channels + 2 (98): a tap's (c, c+1) pair is ONE 8-byte-aligned ds_read_b64 whose
+//     channel is an immediate offset (no address arithmetic in the loop), and lanes that read different cells fall on different
+//     bank pairs.  What bounds the loop now is its arithmetic — 16 fp32 multiplies / adds per output value, kept as separate,
+//     separately rounded ops for ATen's bits: 20 us of the chip's fp32 pipe at B=8, 34 us with addressing and stores; the packed ops
+//     (v_pk_mul_f32 / v_pk_add_f32, half the instructions) measured the same time as scalar ones.
 // Values: per channel and position exactly gather8's op sequence (acc = 0; acc += p_k * w_k in tap order, one rounding per op).
 constexpr int K2_TH = 32, K2_TW = 64;      // 2048 positions per workgroup, two per thread
 constexpr int K2_THREADS = 1024;
@@ -443,8 +446,8 @@ constexpr int K2_DIRECT_SPLIT = 4;         // channel groups of the direct gathe
 constexpr int K2_COLUMNS_MAX_BOX = 16384;  // source-box voxels of a tile up to which the column walk is used
 constexpr int K2_CORNER_E = 6;
 constexpr int K2_CORNER_CELLS = K2_CORNER_E * K2_CORNER_E * K2_CORNER_E;
-constexpr int K2_CG_MAX = 96;              // channels per workgroup at most (LDS: 216 x 97 floats = 83808 B)
-constexpr int K2_LDS_FLOATS = K2_CORNER_CELLS * (K2_CG_MAX | 1);
+constexpr int K2_CG_MAX = 96;              // channels per workgroup at most (LDS: 216 x 98 floats = 84672 B)
+constexpr int K2_LDS_FLOATS = K2_CORNER_CELLS * (K2_CG_MAX + 2);
 // channels per workgroup (blockIdx.y groups): all of them (<= 96) when the tiles alone fill the chip, else 32 or 16
 __host__ __device__ inline int k2_group_channels(size_t tiles, int C) {
     int cg = min(C, K2_CG_MAX);
@@ -452,15 +455,19 @@ __host__ __device__ inline int k2_group_channels(size_t tiles, int C) {
     if (tiles * (size_t)((C + cg - 1) / cg) < 256 && C > 16) cg = 16;
     return cg;
 }
-// image: [frame][group][cell][cg | 1] floats, a group's block padded to a multiple of 16 bytes
-__host__ __device__ inline size_t k2_block_floats(int cg) { return ((size_t)K2_CORNER_CELLS * (cg | 1) + 3) / 4 * 4; }
+// channel pitch of the image: EVEN (a tap's channel pair is one 8-byte-aligned ds_read_b64: 256 B/clk, twice ds_read2_b32) and = 2 mod 32
+// for the channel counts in use (98, 34, 18 -> cell * pitch mod 64 takes 32 different even values: the 32 lanes of a read group that
+// hit different cells fall on different bank pairs)
+__host__ __device__ inline int k2_pitch(int cg) { return ((cg + 1) & ~1) + 2; }
+// image: [frame][group][cell][k2_pitch(cg)] floats, a group's block padded to a multiple of 16 bytes
+__host__ __device__ inline size_t k2_block_floats(int cg) { return ((size_t)K2_CORNER_CELLS * k2_pitch(cg) + 3) / 4 * 4; }
 __global__ void __launch_bounds__(128)
 warp_corner_image_kernel(const float *__restrict__ v, float *__restrict__ img, int C, int D, int H, int W, int cg, int groups) {
     const int cell = blockIdx.x, b = blockIdx.y;
     const int z = cell / (K2_CORNER_E * K2_CORNER_E), y = (cell / K2_CORNER_E) % K2_CORNER_E, x = cell % K2_CORNER_E;
     const bool inside = z < D && y < H && x < W;
     const size_t vol = (size_t)D * H * W, blk = k2_block_floats(cg);
-    const int cgp = cg | 1;
+    const int cgp = k2_pitch(cg);
     for (int c = threadIdx.x; c < groups * cgp; c += 128) {   // (the pad slot and channels >= C: zeros, the block is copied whole)
         const int g = c / cgp, cl = c - g * cgp, ch = g * cg + cl;
         const bool real = inside && cl < cg && ch < C;
@@ -530,16 +537,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     const int d = (int)(bid % (unsigned)D);
     const int tile = (int)((bid / (unsigned)D) % (unsigned)(tiles_w * tiles_h));
     const int b = (int)(bid / ((unsigned)D * (unsigned)(tiles_w * tiles_h)));
-    const int cg0 = (int)blockIdx.y * cg, Cg = min(C - cg0, cg), cgp = cg | 1;
-    // The image is fetched only if the tile's FIRST sample lies in the corner (one scalar load): a field that travels through the volume
-    // (not the reference's) would otherwise pay for the transfers for nothing.
-    const float *c0p = coords + (((size_t)b * D + d) * HW + (size_t)(tile / tiles_w) * K2_TH * W + (tile % tiles_w) * K2_TW) * 3;
-    const float fx = c0p[0], fy = c0p[1], fz = c0p[2];
-    const bool maybe = fx >= 0.0f && fx < (float)(K2_CORNER_E - 1) && fy >= 0.0f && fy < (float)(K2_CORNER_E - 1) && fz >= 0.0f && fz < (float)(K2_CORNER_E - 1);
-    const bool dma = maybe && img != nullptr;
-#ifndef MPHIP_K2_ABL_NOSTAGE   /* dev ablations (timing only, wrong results): tools/k2_ablate.sh */
-    if (dma) k2_dma_image(img + ((size_t)b * gridDim.y + blockIdx.y) * k2_block_floats(cg), lds, (int)k2_block_floats(cg));
-#endif
+    const int cg0 = (int)blockIdx.y * cg, Cg = min(C - cg0, cg), cgp = k2_pitch(cg);
     const int h = (tile / tiles_w) * K2_TH + (int)(threadIdx.x / (K2_TW / 2));
     const int w = (tile % tiles_w) * K2_TW + (int)(threadIdx.x % (K2_TW / 2)) * 2;
     const bool active = h < H && w < W;  // W % 4 == 0 -> a thread's 2 positions share validity
@@ -549,14 +547,25 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
     Taps taps[2];
     int x0[2], y0[2], z0[2];
     int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
-    if (active) {
+    float cf[6] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (active) {   // (issued BEFORE the scalar test below is waited for: one round trip for both)
         const float *cp = coords + (((size_t)b * D + d) * HW + p0) * 3;   // (p0 even: 8-byte aligned)
-        float cf[6];
 #pragma unroll
         for (int q = 0; q < 3; ++q) {
             const float2 t2 = *reinterpret_cast<const float2 *>(cp + q * 2);
             cf[q * 2] = t2.x; cf[q * 2 + 1] = t2.y;
         }
+    }
+    // The image is fetched only if the tile's FIRST sample lies in the corner (one scalar load): a field that travels through the volume
+    // (not the reference's) would otherwise pay for the transfers for nothing.
+    const float *c0p = coords + (((size_t)b * D + d) * HW + (size_t)(tile / tiles_w) * K2_TH * W + (tile % tiles_w) * K2_TW) * 3;
+    const float fx = c0p[0], fy = c0p[1], fz = c0p[2];
+    const bool maybe = fx >= 0.0f && fx < (float)(K2_CORNER_E - 1) && fy >= 0.0f && fy < (float)(K2_CORNER_E - 1) && fz >= 0.0f && fz < (float)(K2_CORNER_E - 1);
+    const bool dma = maybe && img != nullptr;
+#ifndef MPHIP_K2_ABL_NOSTAGE   /* dev ablations (timing only, wrong results): tools/k2_ablate.sh */
+    if (dma) k2_dma_image(img + ((size_t)b * gridDim.y + blockIdx.y) * k2_block_floats(cg), lds, (int)k2_block_floats(cg));
+#endif
+    if (active) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             Coord3 c{cf[i * 3], cf[i * 3 + 1], cf[i * 3 + 2]};
@@ -602,7 +611,7 @@ warp_gather_kernel(const float *__restrict__ v, const float *__restrict__ coords
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) pv[i][k] = k2_f2{src[tb[i][k]], src[tb[i][k] + 1]};
+                    for (int k = 0; k < 8; ++k) pv[i][k] = *reinterpret_cast<const k2_f2 *>(src + tb[i][k]);   // (even pitch, even channel: 8-byte aligned)
                 k2_f2 acc[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -922,7 +931,7 @@ extern "C" size_t mphip_warp_workspace_bytes(int B, int D, int H, int W) {
 // gather stage low-corner boxes — every box of the reference's own fields — from one compact copy per frame
 extern "C" size_t mphip_warp_corner_image_bytes(int B, int C) {
     if (B <= 0 || C <= 0) return 0;
-    size_t fl = 0;   // [frame][channel group][6^3 cells][cg | 1], for whichever grouping the launch picks
+    size_t fl = 0;   // [frame][channel group][6^3 cells][k2_pitch(cg)], for whichever grouping the launch picks
     for (int cg : {min(C, K2_CG_MAX), 32, 16})
         if (cg <= C) fl = std::max(fl, (size_t)cdiv(C, cg) * k2_block_floats(cg));
     return (size_t)B * fl * sizeof(float);

@@ -76,7 +76,7 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mphip_conv3d_workspace_bytes(1, 768, 768, 2, 8, 8, 3, 1) > 0
     assert lib.mphip_groupnorm_workspace_bytes(2, 96, 65536, 32) == 2 * 32 * 12 * 16
     assert lib.mphip_warp_workspace_bytes(8, 16, 64, 64) == 8 * 65536 * 12 + 8 * 16 * 2 * 4   # coordinates + one int per 32x64 K2 tile
-    assert lib.mphip_warp_corner_image_bytes(8, 96) == 8 * 6 * 216 * 17 * 4                # K2's optional corner image: [frame][group][6^3][cg|1], largest grouping (6 x 16 channels)
+    assert lib.mphip_warp_corner_image_bytes(8, 96) == 8 * 6 * 216 * 18 * 4                # K2's optional corner image: [frame][group][6^3][channels + 2], largest grouping (6 x 16 channels)
     one_ = ctypes.c_void_p(16)
     assert lib.mphip_warp_volume_dsum(one_, one_, one_, one_, one_, one_, 1, 2, 4, 4, 4, 4, 4, 4, None, 0, None) == -3   # workspace too small
 
