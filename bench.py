@@ -380,7 +380,7 @@ def roofline_hbm(hot, inp, B):
     for key, rec in res.items():
         kname, kind = key.split(" / ")
         short = kname.split()[0]
-        kernels = {"K2": ["warp_coords_kernel", "warp_gather_kernel", "warp_gather_columns_kernel", "warp_gather_direct_kernel"],
+        kernels = {"K2": ["warp_coords_kernel", "warp_corner_image_kernel", "warp_gather_kernel", "warp_gather_columns_kernel", "warp_gather_direct_kernel"],
                    "K3": ["warp_coords_kernel", "warp_gather_dsum_kernel"]}[short]
         traffic = None
         if B == 8:

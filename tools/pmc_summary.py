@@ -6,7 +6,7 @@ import csv, glob, json, os, re, sys
 from collections import defaultdict
 
 root = sys.argv[1]
-KEEP = ("warp_gather_kernel", "warp_gather_columns_kernel", "warp_gather_direct_kernel", "warp_gather_dsum_kernel", "warp_coords_kernel")
+KEEP = ("warp_gather_kernel", "warp_gather_columns_kernel", "warp_gather_direct_kernel", "warp_gather_dsum_kernel", "warp_coords_kernel", "warp_corner_image_kernel")
 out = {}
 for d in sorted(glob.glob(os.path.join(root, "pmc_*_B*_*"))):
     if not os.path.isdir(d):

@@ -5,7 +5,7 @@ import json
 import sys
 
 k = json.load(open(sys.argv[1]))
-FAM = {"K2": ["warp_coords_kernel", "warp_gather_kernel", "warp_gather_columns_kernel", "warp_gather_direct_kernel"],
+FAM = {"K2": ["warp_coords_kernel", "warp_corner_image_kernel", "warp_gather_kernel", "warp_gather_columns_kernel", "warp_gather_direct_kernel"],
        "K3": ["warp_coords_kernel", "warp_gather_dsum_kernel"]}
 ALG = {"K2": 428.0, "K3": 239.0}  # MB at B=8 (53.5 / 29.9 MB per frame)
 reading = {}
