@@ -60,6 +60,12 @@ constexpr int WN_XLOADS = 8;                               // vector-memory inst
 
 __device__ unsigned long long g_f16x3_wino_saturated;
 
+#ifdef MPHIP_WN_TRACE   /* dev: wall-clock (100 MHz) stamps per workgroup — start, end of every tile (up to 14) — tools/dbg_wino_trace.py */
+__device__ unsigned long long g_wn_trace[1024 * 16];
+#define WN_STAMP(i) if (threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && blockIdx.x < 1024 && (i) < 16) g_wn_trace[blockIdx.x * 16 + (i)] = wall_clock64();
+#else
+#define WN_STAMP(i)
+#endif
 #ifdef MPHIP_PROFILE_PHASES
 // dev instrumentation (itself intrusive, ~+10 % wave cycles): shader cycles per phase, summed over all waves:
 // [0] prologue  [1] interval: DMA issue + fragment reads + MFMA issue  [2] interval: wait for this wave's DMA pieces  [3] interval: barrier
@@ -253,6 +259,8 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     };
 
     WPROF_DECL;
+    WN_STAMP(0)
+    [[maybe_unused]] int wn_tile_ = 1;
     // ---- prologue: slabs 0..2 in flight, X(chunk 0) staged ---------------------------------------------------------------------
     if (fuse_in) {
         load_aff();
@@ -603,6 +611,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         }
 
         WPROF_ADD(6)
+        WN_STAMP(wn_tile_) ++wn_tile_;
         if (has_next) {
             if (fuse_in) { WN_WRITE_X(c_begin, true) } else { WN_WRITE_X(c_begin, false) }   // the next tile's first halo chunk (prefetched during this tile's last chunk)
             WPROF_ADD(4)
@@ -704,5 +713,11 @@ extern "C" int mphip_debug_f16x3_wino_profile(unsigned long long *out8, int rese
         if (hipMemcpyToSymbol(HIP_SYMBOL(mphip::g_f16x3_wino_prof), z, 64) != hipSuccess) return -1;
     }
     return 0;
+}
+#endif
+
+#ifdef MPHIP_WN_TRACE
+extern "C" int mphip_debug_wino_trace(unsigned long long *host_out /* 1024 * 16 */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mphip::g_wn_trace), sizeof(unsigned long long) * 1024 * 16) == hipSuccess ? 0 : -1;
 }
 #endif
