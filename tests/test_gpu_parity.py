@@ -886,7 +886,7 @@ def test_range_descriptors_are_correct_bounds(ops, dev):
     v = R.seeded_tensor((2, 8, 16, 64, 64), 863, scale=2.0).to(dev)
     out = ops.warp_volume(v, field)
     assert desc_max(ops.tensor_range(out)) == out.abs().max().item()          # fused into the gather kernels
-    vb = R.seeded_tensor((14, 8, 16, 64, 64), 864, scale=2.0).to(dev)           # 14*16*4 = 896 tiles: one partial slot each
+    vb = R.seeded_tensor((14, 8, 16, 64, 64), 864, scale=2.0).to(dev)           # 14*16*2 = 448 tiles: one partial slot each
     fb = (R.seeded_tensor((14, 3, 64, 64, 64), 865, scale=1.3) + 0.4).to(dev)
     ob = ops.warp_volume(vb, fb)
     assert desc_max(ops.tensor_range(ob)) == ob.abs().max().item()
@@ -895,8 +895,8 @@ def test_range_descriptors_are_correct_bounds(ops, dev):
     travelling[7:] = (R.seeded_tensor((7, 3, 64, 64, 64), 868).to(dev) + 1.0) * 30.0         # incoherent: the direct gather
     ot = ops.warp_volume(vb, travelling)
     assert desc_max(ops.tensor_range(ot)) == ot.abs().max().item()
-    vc = R.seeded_tensor((65, 2, 16, 64, 64), 869, scale=2.0).to(dev)           # 65*16*4 tiles > 4096 partial slots
-    fc = (R.seeded_tensor((1, 3, 64, 64, 64), 870, scale=1.3) + 0.4).to(dev).expand(65, -1, -1, -1, -1).contiguous()
+    vc = R.seeded_tensor((129, 2, 16, 64, 64), 869, scale=2.0).to(dev)          # 129*16*2 tiles (32 x 64 positions each) > 4096 partial slots
+    fc = (R.seeded_tensor((1, 3, 64, 64, 64), 870, scale=1.3) + 0.4).to(dev).expand(129, -1, -1, -1, -1).contiguous()
     oc = ops.warp_volume(vc, fc)
     m = desc_max(ops.tensor_range(oc))
     assert oc.abs().max().item() <= m == vc.abs().max().item()                 # the source's maximum bounds the warp
