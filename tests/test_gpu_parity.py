@@ -130,6 +130,45 @@ def test_warp_volume_indices_bit_exact(ops, dev, oracle_c, kind, shape):
     assert maxabs(got_sum, want.sum(dim=2)) <= 2e-5
 
 
+@pytest.mark.parametrize("B,C", [(1, 96), (2, 40), (8, 96), (3, 7)])
+def test_warp_volume_corner_image_paths_are_bit_identical(ops, dev, oracle_c, B, C):
+    """K2's corner gather (r04) has three ways to its LDS image — the corner image inside a larger workspace, an image built ahead
+    of the call (mphip_warp_corner_image + mphip_warp_volume_coords_img: the plan's way), and no image at all (a caller whose
+    workspace has the old size: the workgroup collects the corner itself) — and splits the channels over 1, 3 or 6 groups depending on
+    the tile count.  All of them must give the C oracle's bits."""
+    import ctypes
+    lib = ops._lib.load()
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    D, H, W = 16, 64, 64
+    field = (R.seeded_tensor((B, 3, 64, 64, 64), 320 + B, scale=1.3) + 0.4)
+    v = R.seeded_tensor((B, C, D, H, W), 330 + C, scale=1.7)
+    want = oracle_c.apply_warping_field(v, field)
+    vd, fd = v.to(dev), field.to(dev)
+    lin = [ops.linspace_table(n, dev) for n in (D, H, W)]
+    base = lib.mphip_warp_workspace_bytes(B, D, H, W)
+    img_bytes = lib.mphip_warp_corner_image_bytes(B, C)
+    assert img_bytes > 0
+    outs = {}
+    for name, extra in (("image in the workspace", img_bytes), ("no image", 0)):
+        ws = torch.empty((base + extra) // 4, dtype=torch.float32, device=dev)
+        out = torch.full_like(vd, float("nan"))
+        rc = lib.mphip_warp_volume(P(vd), P(fd), P(lin[0]), P(lin[1]), P(lin[2]), P(out), None, None, None, B, C, D, H, W, 64, 64, 64,
+                                   P(ws), base + extra, None)
+        assert rc == 0, lib.mphip_last_error()
+        outs[name] = out
+    coords = torch.empty((B, D, H, W, 3), dtype=torch.float32, device=dev)
+    assert lib.mphip_warp_coords(P(fd), P(lin[0]), P(lin[1]), P(lin[2]), P(coords), B, D, H, W, 64, 64, 64, None) == 0
+    img = torch.empty(img_bytes // 4, dtype=torch.float32, device=dev)
+    assert lib.mphip_warp_corner_image(P(vd), P(img), img_bytes, B, C, D, H, W, None) == 0, lib.mphip_last_error()
+    ws = torch.empty(base // 4, dtype=torch.float32, device=dev)
+    out = torch.full_like(vd, float("nan"))
+    assert lib.mphip_warp_volume_coords_img(P(vd), P(coords), P(out), None, B, C, D, H, W, P(ws), base, P(img), None) == 0, lib.mphip_last_error()
+    outs["image built ahead"] = out
+    torch.cuda.synchronize()
+    for name, out in outs.items():
+        assert torch.equal(out.cpu(), want), name
+
+
 def test_apply_warping_field_golden(ops, M, dev, hot, sd):
     g = gold("apply_warping_field")
     inp = R.seeded_hot_inputs(1, INPUT_SEED)
