@@ -175,6 +175,13 @@ int mphip_flowfield_conv_gn_supported(int Ci, int Co, int D, int H, int W, int C
 int mphip_flowfield_conv_gn(const float *x, const float *w, const float *b, const float *gamma, const float *beta, const float *w2,
                             const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci, int Co,
                             int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu, void *stream);
+/* Level 1 (4x1x1 volumes: only the taps (kd, 1, 1) exist) from a compact copy [Co][Ci][3] of the weights — same bits, a ninth of the weight traffic;
+ * mphip_flowfield_compact_weight_bytes() is 0 for every other level. */
+size_t mphip_flowfield_compact_weight_bytes(int Ci, int Co, int D, int H, int W);
+int mphip_flowfield_compact_weight(const float *w, void *w_compact, int Ci, int Co, void *stream);
+int mphip_flowfield_conv_gn_compact(const float *x, const void *w_compact, const float *b, const float *gamma, const float *beta, const float *w2,
+                                    const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci, int Co,
+                                    int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu, void *stream);
 /* FlowField's output head (model.py:458-465): em = tanh(relu(GroupNorm(1, 3)(Conv3d(32, 3, 3)(x)))), x [N,32,16,16,16] -> em [N,3,16,16,16]:
  * a direct 3-channel conv (one workgroup per depth slice, partial sums in double) + one normalising pass; w [3,32,3,3,3] as stored. */
 size_t mphip_flowfield_out_workspace_bytes(int N);

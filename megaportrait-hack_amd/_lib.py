@@ -87,6 +87,9 @@ SIGNATURES = {
     "mphip_flowfield_out_workspace_bytes": (_sz, [_i]),
     "mphip_flowfield_out": (_i, [_p] * 6 + [_i, ctypes.c_float, _p, _sz, _p]),
     "mphip_flowfield_conv_gn": (_i, [_p] * 11 + [_i] * 11 + [ctypes.c_float, _i, _p]),
+    "mphip_flowfield_compact_weight_bytes": (_sz, [_i] * 5),
+    "mphip_flowfield_compact_weight": (_i, [_p, _p, _i, _i, _p]),
+    "mphip_flowfield_conv_gn_compact": (_i, [_p] * 11 + [_i] * 11 + [ctypes.c_float, _i, _p]),
     "mphip_warp_volume_coords": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_warp_sample_box": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_conv3d_roi_granule": (_i, [_i] * 8 + [_p]),

@@ -109,8 +109,12 @@ __device__ __forceinline__ void ff_fold(const float *__restrict__ red_, float *_
 
 // ---- PLANE: thread = (channel c of the group, input-channel slice k); KS = NT / CPG slices (a slice is 1-4 input channels: the
 // loop is a chain of dependent global-load round trips, so the workgroup is made as wide as the channel count allows) --------------------------------------
-template <int D, int H, int W, int CPG, int NT>
+// WC (level 1 only, r04): p.w is the COMPACT copy [Co][Ci][3] of the three taps (kd, 1, 1) a 4x1x1 volume can use (mphip_flowfield_compact_weight).  From
+// the [Co][Ci][27] tensor the kernel touches every 128-byte line of its group's rows for 12 of every 108 bytes: 113 MB of L2 reads per launch at B=8
+// for 12.6 MB of weights, and that traffic IS the launch (16-22 us -> see DESIGN.md).
+template <int D, int H, int W, int CPG, int NT, bool WC = false>
 __global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
+    static_assert(!WC || (H == 1 && W == 1), "compact taps: only (kd, 1, 1) exist");
     constexpr int S = D * H * W, KS = NT / CPG;
     static_assert(S % 4 == 0 && S <= 32, "plane mapping: the input plane lives in registers");
     const int tid = threadIdx.x, c = tid % CPG, k = tid / CPG;
@@ -133,9 +137,17 @@ __global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
             const float4 v = xs[q];
             xp[q * 4] = v.x; xp[q * 4 + 1] = v.y; xp[q * 4 + 2] = v.z; xp[q * 4 + 3] = v.w;
         }
-        const float *wp = p.w + ((size_t)(c0 + c) * p.Ci + ci) * 27;
+        if (WC) {
+            const float *wp = p.w + ((size_t)(c0 + c) * p.Ci + ci) * 3;
 #pragma unroll
-        for (int t = 0; t < 27; ++t) wv[t] = wp[t];   // (taps that no output of this shape can use are never loaded: dead after unrolling)
+            for (int t = 0; t < 27; ++t) wv[t] = 0.0f;
+#pragma unroll
+            for (int kd = 0; kd < 3; ++kd) wv[kd * 9 + 4] = wp[kd];
+        } else {
+            const float *wp = p.w + ((size_t)(c0 + c) * p.Ci + ci) * 27;
+#pragma unroll
+            for (int t = 0; t < 27; ++t) wv[t] = wp[t];   // (taps that no output of this shape can use are never loaded: dead after unrolling)
+        }
 #pragma unroll
         for (int od = 0; od < D; ++od)
 #pragma unroll
@@ -399,6 +411,13 @@ __global__ void __launch_bounds__(256) ff_out_norm_kernel(const float *__restric
 // GroupNorm: measured as a row-mapped kernel it took 29-35 us per half — every one of the 32 group workgroups of a frame re-reads the
 // frame's whole 256 KB input through L2 and the fp32 FMA work alone is 11 us of a CU — vs 107 us for its five launches, but its 1024-thread
 // workgroups on every CU delayed the other generator's chain and the other batch: B=8 3.91 vs 3.86 ms per step with / without it.)
+__global__ void __launch_bounds__(256) ff_compact_taps_kernel(const float *__restrict__ w, float *__restrict__ wc, size_t pairs) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;   // (co, ci) pair
+    if (i >= pairs) return;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) wc[i * 3 + kd] = w[i * 27 + kd * 9 + 4];
+}
+
 static int ff_level(int Co, int D, int H, int W) {
     if (Co == 256 && D == 4 && H == 1 && W == 1) return 1;
     if (Co == 128 && D == 8 && H == 2 && W == 2) return 2;
@@ -417,10 +436,21 @@ extern "C" int mphip_flowfield_conv_gn_supported(int Ci, int Co, int D, int H, i
     return lv;
 }
 
-extern "C" int mphip_flowfield_conv_gn(const float *x, const float *w, const float *b, const float *gamma, const float *beta, const float *w2,
-                                       const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci,
-                                       int Co, int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu,
-                                       void *stream) {
+// Level 1 (4x1x1 volumes) can run from a compact copy of its weights: [Co][Ci][3], the taps (kd, 1, 1) — bytes, 0 for any other level
+extern "C" size_t mphip_flowfield_compact_weight_bytes(int Ci, int Co, int D, int H, int W) {
+    return (Ci > 0 && ff_level(Co, D, H, W) == 1) ? (size_t)Co * Ci * 3 * sizeof(float) : 0;
+}
+extern "C" int mphip_flowfield_compact_weight(const float *w, void *w_compact, int Ci, int Co, void *stream) {
+    MPHIP_REQUIRE(w && w_compact && Ci > 0 && Co > 0, "flowfield_compact_weight: bad arguments");
+    const size_t pairs = (size_t)Co * Ci;
+    hipLaunchKernelGGL(ff_compact_taps_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, (float *)w_compact, pairs);
+    return check_launch("flowfield_compact_weight");
+}
+
+static int flowfield_conv_gn_impl(const float *x, const float *w, bool w_is_compact, const float *b, const float *gamma, const float *beta, const float *w2,
+                                  const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci,
+                                  int Co, int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu,
+                                  void *stream) {
     MPHIP_REQUIRE(x && w && gamma && beta && y, "flowfield_conv_gn: null pointer");
     MPHIP_REQUIRE((w2 == nullptr) == (b2 == nullptr), "flowfield_conv_gn: w2/b2 must both be set or both NULL");
     MPHIP_REQUIRE((res_x == nullptr) == (res_w == nullptr) && (res_x != nullptr) == (Cr > 0), "flowfield_conv_gn: residual input, weight and Cr go together");
@@ -432,11 +462,30 @@ extern "C" int mphip_flowfield_conv_gn(const float *x, const float *w, const flo
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)(N * groups));
     switch (lv) {
-        case 1: hipLaunchKernelGGL((ff_block_plane_kernel<4, 1, 1, 8, 1024>), grid, dim3(1024), 0, s, p); break;
+        case 1:
+            if (w_is_compact) hipLaunchKernelGGL((ff_block_plane_kernel<4, 1, 1, 8, 1024, true>), grid, dim3(1024), 0, s, p);
+            else hipLaunchKernelGGL((ff_block_plane_kernel<4, 1, 1, 8, 1024>), grid, dim3(1024), 0, s, p);
+            break;
         case 2: hipLaunchKernelGGL((ff_block_plane_kernel<8, 2, 2, 4, 512>), grid, dim3(512), 0, s, p); break;
         default: hipLaunchKernelGGL((ff_block_row_kernel<16, 4, 4, 2, 16>), grid, dim3(1024), 0, s, p); break;
     }
     return check_launch("flowfield_conv_gn");
+}
+
+extern "C" int mphip_flowfield_conv_gn(const float *x, const float *w, const float *b, const float *gamma, const float *beta, const float *w2,
+                                       const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci,
+                                       int Co, int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu,
+                                       void *stream) {
+    return flowfield_conv_gn_impl(x, w, false, b, gamma, beta, w2, b2, res_x, res_w, res_b, y, N, Ci, Co, D, H, W, Cr, uD, uH, uW, groups, eps, relu, stream);
+}
+// the same with `w_compact` = the copy mphip_flowfield_compact_weight made of w (level 1 only: mphip_flowfield_compact_weight_bytes > 0); same bits
+extern "C" int mphip_flowfield_conv_gn_compact(const float *x, const void *w_compact, const float *b, const float *gamma, const float *beta, const float *w2,
+                                               const float *b2, const float *res_x, const float *res_w, const float *res_b, float *y, int N, int Ci,
+                                               int Co, int D, int H, int W, int Cr, int uD, int uH, int uW, int groups, float eps, int relu,
+                                               void *stream) {
+    MPHIP_REQUIRE(mphip_flowfield_compact_weight_bytes(Ci, Co, D, H, W) > 0, "flowfield_conv_gn_compact: not a level with compact weights");
+    return flowfield_conv_gn_impl(x, (const float *)w_compact, true, b, gamma, beta, w2, b2, res_x, res_w, res_b, y, N, Ci, Co, D, H, W, Cr, uD, uH, uW, groups, eps,
+                                  relu, stream);
 }
 
 extern "C" size_t mphip_flowfield_out_workspace_bytes(int N) { return N > 0 ? (size_t)N * FO_G * 2 * sizeof(double) + (size_t)N * 3 * FO_S * sizeof(float) : 0; }

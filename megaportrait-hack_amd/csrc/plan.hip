@@ -420,19 +420,47 @@ void resblock_ada(GenLane (&ln)[L], int blk, T5 (&x)[L], int ud, int uh, int uw)
         mphip_flowfield_conv_gn_supported(b[0]->conv1.ci, b[0]->conv1.co, x[0].d, x[0].h, x[0].w, 0, 32) &&
         mphip_flowfield_conv_gn_supported(b[0]->conv2.ci, b[0]->conv2.co, x[0].d, x[0].h, x[0].w, b[0]->res.ci, 32)) {
         // FlowField's levels: each half of the block is ONE launch (csrc/flowfield.hip; model.ResBlock3D_Adaptive._forward does the same)
+        // level 1 (4x1x1): from the compact copy of the three usable taps (flowfield.hip; kept in the conv's precision-1 pack slot, which these
+        // fp32 layers never use, and refreshed with the other packs)
+        auto compact = [&](Ctx &c, ConvW &cw, int d, int h, int w) -> const void * {
+            const size_t bytes = mphip_flowfield_compact_weight_bytes(cw.ci, cw.co, d, h, w);
+            if (!bytes || c.dry) return nullptr;
+            if (!cw.pk[1]) {
+                void *q = nullptr;
+                if (hipMalloc(&q, bytes) != hipSuccess) { (void)hipGetLastError(); return nullptr; }   // (falls back to the original tensor)
+                c.p->owned.push_back(q);
+                cw.pk[1] = q;
+                cw.fresh[1] = false;
+            }
+            if (!cw.fresh[1]) {
+                RUN(c, mphip_flowfield_compact_weight(cw.w, cw.pk[1], cw.ci, cw.co, c.s));
+                cw.fresh[1] = true;
+            }
+            return cw.pk[1];
+        };
         for (int l = 0; l < L; ++l) {
             Ctx &c = *ln[l].c;
             a[l] = new_t5(c, x[l].n, b[l]->conv1.co, x[l].d, x[l].h, x[l].w, false);
-            RUN(c, mphip_flowfield_conv_gn(x[l].data.p, b[l]->conv1.w, b[l]->conv1.b, b[l]->n1.gw, b[l]->n1.gb, b[l]->n1.w2, b[l]->n1.b2, nullptr,
-                                           nullptr, nullptr, a[l].data.p, x[l].n, b[l]->conv1.ci, b[l]->conv1.co, x[l].d, x[l].h, x[l].w, 0, 1, 1, 1,
-                                           32, GN_EPS, 1, c.s));
+            if (const void *wc = compact(c, b[l]->conv1, x[l].d, x[l].h, x[l].w))
+                RUN(c, mphip_flowfield_conv_gn_compact(x[l].data.p, wc, b[l]->conv1.b, b[l]->n1.gw, b[l]->n1.gb, b[l]->n1.w2, b[l]->n1.b2, nullptr,
+                                                       nullptr, nullptr, a[l].data.p, x[l].n, b[l]->conv1.ci, b[l]->conv1.co, x[l].d, x[l].h, x[l].w, 0, 1, 1,
+                                                       1, 32, GN_EPS, 1, c.s));
+            else
+                RUN(c, mphip_flowfield_conv_gn(x[l].data.p, b[l]->conv1.w, b[l]->conv1.b, b[l]->n1.gw, b[l]->n1.gb, b[l]->n1.w2, b[l]->n1.b2, nullptr,
+                                               nullptr, nullptr, a[l].data.p, x[l].n, b[l]->conv1.ci, b[l]->conv1.co, x[l].d, x[l].h, x[l].w, 0, 1, 1, 1,
+                                               32, GN_EPS, 1, c.s));
         }
         for (int l = 0; l < L; ++l) {
             Ctx &c = *ln[l].c;
             out[l] = new_t5(c, x[l].n, b[l]->conv2.co, x[l].d * ud, x[l].h * uh, x[l].w * uw, false);
-            RUN(c, mphip_flowfield_conv_gn(a[l].data.p, b[l]->conv2.w, b[l]->conv2.b, b[l]->n2.gw, b[l]->n2.gb, b[l]->n2.w2, b[l]->n2.b2,
-                                           x[l].data.p, b[l]->res.w, b[l]->res.b, out[l].data.p, x[l].n, b[l]->conv2.ci, b[l]->conv2.co, x[l].d,
-                                           x[l].h, x[l].w, b[l]->res.ci, ud, uh, uw, 32, GN_EPS, 1, c.s));
+            if (const void *wc = compact(c, b[l]->conv2, x[l].d, x[l].h, x[l].w))
+                RUN(c, mphip_flowfield_conv_gn_compact(a[l].data.p, wc, b[l]->conv2.b, b[l]->n2.gw, b[l]->n2.gb, b[l]->n2.w2, b[l]->n2.b2,
+                                                       x[l].data.p, b[l]->res.w, b[l]->res.b, out[l].data.p, x[l].n, b[l]->conv2.ci, b[l]->conv2.co, x[l].d,
+                                                       x[l].h, x[l].w, b[l]->res.ci, ud, uh, uw, 32, GN_EPS, 1, c.s));
+            else
+                RUN(c, mphip_flowfield_conv_gn(a[l].data.p, b[l]->conv2.w, b[l]->conv2.b, b[l]->n2.gw, b[l]->n2.gb, b[l]->n2.w2, b[l]->n2.b2,
+                                               x[l].data.p, b[l]->res.w, b[l]->res.b, out[l].data.p, x[l].n, b[l]->conv2.ci, b[l]->conv2.co, x[l].d,
+                                               x[l].h, x[l].w, b[l]->res.ci, ud, uh, uw, 32, GN_EPS, 1, c.s));
         }
         for (int l = 0; l < L; ++l) {
             give(*ln[l].c, a[l]);
