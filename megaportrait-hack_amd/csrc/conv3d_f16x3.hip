@@ -222,7 +222,20 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     const int *const tile_list = roi;
     const int ntiles = tile_list ? tile_list[0] : tiles_total;
     auto tile_at = [&](int j) -> int { return tile_list ? tile_list[1 + j] : j; };
-    const int j_first = (tile_list || !xcd_aware) ? (int)blockIdx.x : (int)xcd_remap(blockIdx.x, gridDim.x);
+    // XCD-aware placement over the WHOLE grid (r04): the hardware deals workgroup ids (x fastest, then y, z) round-robin over the 8 XCDs;
+    // xcd_remap over the linear id gives every XCD a contiguous range of logical ids — the tiles of one (96-channel tile, K-split) pair first.  On the 2x8x8 level a pair's 8 tiles (one per frame) share 64 MB of packed weights that no L2 holds: with the
+    // hardware's order they sat on 8 different XCDs and every XCD streamed all of it (343 MB from HBM per launch for 64 MB of weights,
+    // 4.9 TB/s: the launches were HBM-bound, tools/pmc_step_traffic.sh); now each weight slab crosses the fabric once.
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    const unsigned ids = gridDim.x * gridDim.y * gridDim.z;
+    if (!tile_list && xcd_aware) {
+        const unsigned id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const unsigned lg = xcd_remap(id, ids);
+        bx = lg % gridDim.x;
+        by = (lg / gridDim.x) % gridDim.y;
+        bz = lg / (gridDim.x * gridDim.y);
+    }
+    const int j_first = (int)bx;
     if (j_first >= ntiles) return;   // (workgroup-uniform, before any barrier)
     (void)roi_frames;
     float x_scale = X_SCALE, x_unscale = 1.0f / X_SCALE;
@@ -267,9 +280,9 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     // XCD-aware start: workgroup ids go round-robin over the 8 XCDs, so consecutive ids get consecutive RANGES of tiles —
     // neighbouring tiles (which share halo rows) then run on the same XCD and meet in its L2
     decode_tile(tile_at(j_first));
-    const int cot = MTS == 3 ? blockIdx.y : blockIdx.y / 3, mb = MTS == 3 ? 0 : blockIdx.y % 3;
+    const int cot = MTS == 3 ? by : by / 3, mb = MTS == 3 ? 0 : by % 3;
     const int nchunks = Ci / KC;
-    const int c_begin = blockIdx.z * chunks_per_split;
+    const int c_begin = bz * chunks_per_split;
     const int c_end = min(nchunks, c_begin + chunks_per_split);
     if (c_begin >= c_end) return;
 
@@ -605,7 +618,7 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 #undef F16X3_DMA_W
 
     const bool direct = gridDim.z == 1;
-    float *dst = direct ? y : y + (size_t)blockIdx.z * N * Co * DHW;
+    float *dst = direct ? y : y + (size_t)bz * N * Co * DHW;
     const float unscale = whdr[0] * x_unscale;
     const int co0 = cot * F16X3_COT + mb * 32;
     if (gn_part) {
