@@ -4,7 +4,7 @@
 # usage: tools/pmc_step_traffic.sh out_dir
 out=$1; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-for ctr in FETCH_SIZE WRITE_SIZE; do
+for ctr in ${CTRS:-FETCH_SIZE WRITE_SIZE}; do
   rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $out/$ctr -- python tools/run_plan_steps.py 8 6 > $out/$ctr.log 2>&1
 done
 python - <<PY
