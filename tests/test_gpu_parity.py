@@ -130,7 +130,7 @@ def test_warp_volume_indices_bit_exact(ops, dev, oracle_c, kind, shape):
     assert maxabs(got_sum, want.sum(dim=2)) <= 2e-5
 
 
-@pytest.mark.parametrize("B,C", [(1, 96), (2, 40), (8, 96), (3, 7)])
+@pytest.mark.parametrize("B,C", [(1, 96), (2, 40), (8, 96), (3, 7), (8, 200), (1, 130)])
 def test_warp_volume_corner_image_paths_are_bit_identical(ops, dev, oracle_c, B, C):
     """K2's corner gather (r04) has three ways to its LDS image — the corner image inside a larger workspace, an image built ahead
     of the call (mphip_warp_corner_image + mphip_warp_volume_coords_img: the plan's way), and no image at all (a caller whose
