@@ -534,9 +534,20 @@ upsample_trilinear2_kernel(const float *__restrict__ x, float *__restrict__ y, i
             for (int c = 0; c < 4; ++c) v[a][b][c] = row[min(w_lo + c, W - 1)];
         }
     // separable evaluation, identical operand pairs to the nested form: W, then H, then D
-    auto sel3 = [](int k, float q0, float q1, float q2) -> float { return k == 0 ? q0 : (k == 1 ? q1 : q2); };
+    // (sequential selects: the nested-ternary form compiled into ~120 divergent branch ladders — s_and_saveexec / s_cbranch per select —
+    //  instead of v_cndmask chains; r04)
+    auto sel3 = [](int k, float q0, float q1, float q2) -> float {
+        float r = q2;
+        r = k == 1 ? q1 : r;
+        r = k == 0 ? q0 : r;
+        return r;
+    };
     auto sel4 = [](int k, float q0, float q1, float q2, float q3) -> float {
-        return k == 0 ? q0 : (k == 1 ? q1 : (k == 2 ? q2 : q3));
+        float r = q3;
+        r = k == 2 ? q2 : r;
+        r = k == 1 ? q1 : r;
+        r = k == 0 ? q0 : r;
+        return r;
     };
     float wl[3][3][4];  // [src d][src h][out w]
 #pragma unroll
