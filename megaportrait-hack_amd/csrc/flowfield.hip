@@ -198,8 +198,15 @@ __global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
 }
 
 // ---- ROW: thread = (output row (d,h), input-channel slice k); rows * KS = 1024 threads (four waves per SIMD cover the load latency) ----------------------------------------------
+#ifdef MPHIP_FF_TRACE   /* dev: wall-clock (100 MHz) stamps per workgroup of the ROW kernel: start, conv loop, fold, residual loop, fold, end */
+__device__ unsigned long long g_ff_trace[512 * 8];
+#define FF_STAMP(i) if (threadIdx.x == 0 && blockIdx.x < 512) g_ff_trace[blockIdx.x * 8 + (i)] = wall_clock64();
+#else
+#define FF_STAMP(i)
+#endif
 template <int D, int H, int W, int CPG, int KS>
 __global__ void __launch_bounds__(D * H * KS) ff_block_row_kernel(FfParams p) {
+    FF_STAMP(0)
     constexpr int S = D * H * W, R = D * H, NT = R * KS;
     static_assert(NT <= 1024 && R % 64 == 0 && W % 4 == 0, "row mapping: a wave holds rows of ONE slice");
     const int tid = threadIdx.x, r = tid % R, d = r / H, h = r % H;
@@ -249,12 +256,14 @@ __global__ void __launch_bounds__(D * H * KS) ff_block_row_kernel(FfParams p) {
                 }
         }
     }
+    FF_STAMP(1)
 #pragma unroll
     for (int c = 0; c < CPG; ++c)
 #pragma unroll
         for (int ow = 0; ow < W; ++ow) red_[(k * CPG + c) * S + r * W + ow] = acc[c][ow];
     __syncthreads();
     ff_fold<CPG, S, KS, NT>(red_, part_, vals, p.b, c0);
+    FF_STAMP(2)
     if (p.rx) {
         __syncthreads();
 #pragma unroll
@@ -281,11 +290,14 @@ __global__ void __launch_bounds__(D * H * KS) ff_block_row_kernel(FfParams p) {
         for (int c = 0; c < CPG; ++c)
 #pragma unroll
             for (int ow = 0; ow < W; ++ow) red_[(k * CPG + c) * S + r * W + ow] = acc[c][ow];
+        FF_STAMP(3)
         __syncthreads();
         ff_fold<CPG, S, KS, NT>(red_, part_, resv, nullptr, c0);
     }
+    FF_STAMP(4)
     __syncthreads();
     ff_finish<D, H, W, CPG, NT>(p, vals, p.rx ? resv : nullptr, n, c0, dred, mr);
+    FF_STAMP(5)
 }
 
 // ---- the output head of FlowField (model.py:458-465): Conv3d(32, 3, 3) @16x16x16 -> GroupNorm(1, 3) -> ReLU -> tanh ----------------------
@@ -506,3 +518,9 @@ extern "C" int mphip_flowfield_out(const float *x, const float *w, const float *
     hipLaunchKernelGGL(ff_out_norm_kernel, dim3(N * FO_G), dim3(256), 0, s, (const float *)y, (const double *)part, gamma, beta, eps, em);
     return check_launch("flowfield_out");
 }
+
+#ifdef MPHIP_FF_TRACE
+extern "C" int mphip_debug_ff_trace(unsigned long long *host_out /* 512 * 8 */) {
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(mphip::g_ff_trace), sizeof(unsigned long long) * 512 * 8) == hipSuccess ? 0 : -1;
+}
+#endif
