@@ -87,7 +87,7 @@ __device__ __forceinline__ void ff_finish(const FfParams &p, const float *__rest
 
 // Fold the KS per-slice partial results red_[(k*CPG + c)*S + o] into dst[c*S + o] (+ bias[c0 + c]): NT / (CPG*S) threads share an output
 // (contiguous slice ranges, then the ranges in order — a fixed tree: deterministic).  Every thread calls it (barriers inside).
-template <int CPG, int S, int KS, int NT>
+template <int CPG, int S, int KS, int NT, int SP = S>   // SP: floats between the rows of red_
 __device__ __forceinline__ void ff_fold(const float *__restrict__ red_, float *__restrict__ part_, float *__restrict__ dst,
                                         const float *__restrict__ bias, int c0) {
     constexpr int OUT = CPG * S, PARTS = (NT / OUT) < 1 ? 1 : ((NT / OUT) > KS ? KS : (NT / OUT)), PER = KS / PARTS;
@@ -95,8 +95,8 @@ __device__ __forceinline__ void ff_fold(const float *__restrict__ red_, float *_
     const int tid = threadIdx.x;
     for (int t = tid; t < OUT * PARTS; t += NT) {
         const int e = t % OUT, q = t / OUT, cc = e / S, o = e - cc * S;
-        float v = red_[((q * PER) * CPG + cc) * S + o];
-        for (int kk = q * PER + 1; kk < (q + 1) * PER; ++kk) v += red_[(kk * CPG + cc) * S + o];
+        float v = red_[((q * PER) * CPG + cc) * SP + o];
+        for (int kk = q * PER + 1; kk < (q + 1) * PER; ++kk) v += red_[(kk * CPG + cc) * SP + o];
         part_[t] = v;
     }
     __syncthreads();
@@ -116,10 +116,14 @@ template <int D, int H, int W, int CPG, int NT, bool WC = false>
 __global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
     static_assert(!WC || (H == 1 && W == 1), "compact taps: only (kd, 1, 1) exist");
     constexpr int S = D * H * W, KS = NT / CPG;
+    // rows of the per-slice partials are S + 4 floats apart: thread t writes row t, and with a pitch of S = 32 floats every lane of a store
+    // hit the same banks (68 % of this kernel's LDS cycles were bank conflicts, tools/pmc_step_lds.sh); 36 floats spread eight 16-byte stores
+    // over all 32 banks
+    constexpr int SP = S + 4;
     static_assert(S % 4 == 0 && S <= 32, "plane mapping: the input plane lives in registers");
     const int tid = threadIdx.x, c = tid % CPG, k = tid / CPG;
     const int groups = p.Co / CPG, n = blockIdx.x / groups, g = blockIdx.x % groups, c0 = g * CPG;
-    __shared__ float red_[KS * CPG * S];
+    __shared__ __attribute__((aligned(16))) float red_[KS * CPG * SP];
     __shared__ float vals[CPG * S], resv[CPG * S], part_[NT > CPG * S ? NT : CPG * S];
     __shared__ double dred[2 * NT / 64];
     __shared__ float mr[2];
@@ -167,9 +171,9 @@ __global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
                             }
     }
 #pragma unroll
-    for (int o = 0; o < S; ++o) red_[(k * CPG + c) * S + o] = acc[o];
+    for (int o = 0; o < S; ++o) red_[(k * CPG + c) * SP + o] = acc[o];
     __syncthreads();
-    ff_fold<CPG, S, KS, NT>(red_, part_, vals, p.b, c0);
+    ff_fold<CPG, S, KS, NT, SP>(red_, part_, vals, p.b, c0);
     if (p.rx) {   // (uniform) residual 1x1x1 conv of the block input, same slicing
         __syncthreads();
 #pragma unroll
@@ -189,9 +193,9 @@ __global__ void __launch_bounds__(NT) ff_block_plane_kernel(FfParams p) {
             }
         }
 #pragma unroll
-        for (int o = 0; o < S; ++o) red_[(k * CPG + c) * S + o] = acc[o];
+        for (int o = 0; o < S; ++o) red_[(k * CPG + c) * SP + o] = acc[o];
         __syncthreads();
-        ff_fold<CPG, S, KS, NT>(red_, part_, resv, nullptr, c0);
+        ff_fold<CPG, S, KS, NT, SP>(red_, part_, resv, nullptr, c0);
     }
     __syncthreads();
     ff_finish<D, H, W, CPG, NT>(p, vals, p.rx ? resv : nullptr, n, c0, dred, mr);
@@ -315,7 +319,9 @@ __global__ void __launch_bounds__(256) ff_out_conv_kernel(const float *__restric
     __shared__ float xs[XS];
     __shared__ __attribute__((aligned(16))) float wsd[FO_C * 3 * 28];   // weights [ci][c][27 (+1 pad)]: 16-byte LDS reads, no scalar-load round
                                                                        // trip per input channel (one wave per SIMD: nothing would hide it)
-    const int n = blockIdx.x / FO_G, d = blockIdx.x % FO_G, tid = threadIdx.x, h = tid / FO_G, ww = tid % FO_G;
+    // a 32-lane read group holds rows g and g + 8 of the slice: their 18-float-pitch windows are 144 floats = 16 banks apart, so the two
+    // 16-wide tap reads of a group fill the 32 banks exactly (rows g, g + 1 overlapped on two banks: 27 % of the LDS cycles were conflicts)
+    const int n = blockIdx.x / FO_G, d = blockIdx.x % FO_G, tid = threadIdx.x, h = (tid >> 5) + 8 * ((tid >> 4) & 1), ww = tid % FO_G;
     const float *xn = x + (size_t)n * FO_C * FO_S;
     // every global load of the workgroup is issued before the first use: 24 16-byte loads of the slab + 3 of the weights per thread
     // (a loop of dependent load -> LDS-write trips cost one memory round trip each: 57-70 us for this kernel)
@@ -381,7 +387,7 @@ __global__ void __launch_bounds__(256) ff_out_conv_kernel(const float *__restric
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const float val = acc[c] + (b ? b[c] : 0.0f);
-        y[((size_t)n * 3 + c) * FO_S + d * FO_G * FO_G + tid] = val;
+        y[((size_t)n * 3 + c) * FO_S + d * FO_G * FO_G + h * FO_G + ww] = val;
         s += val;
         ss += val * val;
     }
