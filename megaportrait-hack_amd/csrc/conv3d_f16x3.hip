@@ -409,11 +409,26 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
     const int jv = jg * 16 + jpos;  // column (voxel slot) of lane j inside its 32-voxel tile
     // fragment bases (halfs)
     const int a_base = (kg * F16X3_COT + j + mb * 32) * 8;   // + ((part*TG + tap)*2*96 + m*32)*8
+    // column slot -> voxel of the tile.  8-wide tiles with one column tile per wave (the 2x8x8 and 4x8x8 instantiations): a wave owns four rows
+    // of a plane, and the two rows of a 16-lane read group are FOUR rows apart — 4 x 160 B = 32 banks (mod 64) between their 128-byte
+    // windows, which therefore fill the 64 banks exactly.  With neighbouring rows (r03-r04) the windows overlapped on 8 banks: 34 % of the
+    // 2x8x8 level's LDS cycles were bank conflicts (tools/pmc_step_lds.sh).  Any bijection works: slots only name accumulator columns.
+    auto slot_voxel = [&](int t, int &vd, int &vh, int &vw) {
+        if (TW == 8 && NT == 1 && TH == 8) {
+            const int q = jv >> 3;
+            vw = jv & 7;
+            vd = wave / 2;
+            vh = (wave % 2) * 2 + (q & 1) * 4 + (q >> 1);   // rows {A, A+4} (slots 0-15), {A+1, A+5} (slots 16-31), A = 0 or 2
+        } else {
+            const int v = (wave * NT + t) * 32 + jv;
+            vw = v % TW; vh = (v / TW) % TH; vd = v / (TW * TH);
+        }
+    };
     int b_base[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-        const int v = (wave * NT + t) * 32 + jv;
-        const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
+        int vd, vh, vw;
+        slot_voxel(t, vd, vh, vw);
         b_base[t] = (kg * XV + (vd * HH + vh) * HWp + vw) * 8;
     }
 
@@ -679,8 +694,8 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
             bv[reg] = (direct && bias) ? bias[co0 + m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kg + tz] : 0.0f;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const int v = (wave * NT + t) * 32 + jv;
-            const int vw = v % TW, vh = (v / TW) % TH, vd = v / (TW * TH);
+            int vd, vh, vw;
+            slot_voxel(t, vd, vh, vw);
             float *dv = dst + (size_t)en * Co * DHW + (size_t)(ed0 + vd) * HW + (eh0 + vh) * W + ew0 + vw;
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
