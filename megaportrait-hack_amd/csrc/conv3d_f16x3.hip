@@ -817,12 +817,12 @@ __global__ void f16x3_pack_k1_kernel(const float *__restrict__ w, _Float16 *__re
 // (contiguous ranges), then fold their accumulators through LDS in wave order — the small launches (<= one wave per SIMD on the
 // chip) were a serial chain of nchunks dependent global-load round trips (12-48 x ~1.2 us: 28-41 us for 1-2 GFLOP).
 // Either way the loads of chunk c+1 are issued before the MFMAs of chunk c (two register sets).
-template <int KS>
+template <int KS, int NTT = 2>
 __global__ void __launch_bounds__(KS == 1 ? 256 : 64 * KS) __attribute__((amdgpu_waves_per_eu(2)))
 conv3d_k1_f16x3_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                        const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int DHW, unsigned x_bytes,
                        const float *__restrict__ x_range) {
-    constexpr int MT = 3, NT = 2;
+    constexpr int MT = 3, NT = NTT;   // NT: 32-voxel column tiles per wave
     float x_scale = X_SCALE, x_unscale = 1.0f / X_SCALE;
     if (x_range) range_scale_block(x_range, x_scale, x_unscale);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1062,12 +1062,19 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
     const unsigned xb = (unsigned)((size_t)N * Ci * DHW * 4);
     const long waves = (long)N * DHW / 64;
     const int ks = f16x3_k1_ksplit(N, Ci, Co, DHW);
+    // a launch with ONE wave per SIMD (64-voxel wave tiles) runs 32-voxel tiles on twice the waves (192->96 @8x32x32, B=8: 29 -> 25 us; with two
+    // waves per SIMD already — 96->192 — it is slower, 26 -> 31 us: the weight fragments are re-read per wave)
+    static const char *nt_env = getenv("MPHIP_F16X3_K1_NT");   // dev: same-box A/B (1 / 2 forces)
+    const bool nt1 = ks == 1 && (nt_env ? atoi(nt_env) == 1 : waves * (Co / F16X3_COT) <= 1024);
     if (ks == 8)
         hipLaunchKernelGGL(conv3d_k1_f16x3_kernel<8>, dim3((unsigned)waves, Co / F16X3_COT), dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci,
                            Co, DHW, xb, x_range);
     else if (ks == 4)
         hipLaunchKernelGGL(conv3d_k1_f16x3_kernel<4>, dim3((unsigned)waves, Co / F16X3_COT), dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci,
                            Co, DHW, xb, x_range);
+    else if (nt1)   // 32 voxels per wave: twice the waves of a launch that has one or two per SIMD
+        hipLaunchKernelGGL((conv3d_k1_f16x3_kernel<1, 1>), dim3((unsigned)((2 * waves + 3) / 4), Co / F16X3_COT), dim3(256), 0, s, x, slabs, hdr,
+                           bias, dst, N, Ci, Co, DHW, xb, x_range);
     else
         hipLaunchKernelGGL(conv3d_k1_f16x3_kernel<1>, dim3((unsigned)((waves + 3) / 4), Co / F16X3_COT), dim3(256), 0, s, x, slabs, hdr, bias,
                            dst, N, Ci, Co, DHW, xb, x_range);
