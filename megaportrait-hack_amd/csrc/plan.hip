@@ -27,6 +27,8 @@ namespace {
 
 constexpr float GN_EPS = 1e-5f;                 // nn.GroupNorm default (model.py:506,508,460,309)
 constexpr size_t SPLIT_CHAIN_MAX_ELEMS = 1u << 18;   // ops._SPLIT_CHAIN_MAX_ELEMS
+constexpr int SPLIT_CHAIN_MAX_SPLITS = 16;            // ops._SPLIT_CHAIN_MAX_SPLITS: from this many slabs on ...
+constexpr size_t SPLIT_CHAIN_MAX_SLAB_ELEMS = 1u << 20;   // ... and this many slab elements the ordered reduce (whole chip) beats the split-aware GN kernels
 constexpr size_t STATS_SPLIT_MAX_SPAN = 65536;       // ops._STATS_SPLIT_MAX_SPAN
 constexpr size_t GN_FUSED_MAX_SPAN = 12288;          // ops._GN_FUSED_MAX_SPAN
 constexpr size_t ALIGN = 256;
@@ -289,7 +291,8 @@ ConvOut conv3d_split(Ctx &c, T5 &x, ConvW &cw, int gn_groups, const Norm *nm = n
     const int prec = precision_for(c, n, cw.ci, cw.co, d, h, w, cw.k);
     const int splits = mphip_conv3d_splits(n, cw.ci, cw.co, d, h, w, cw.k, prec);
     const size_t elems = (size_t)n * cw.co * d * h * w;
-    if (splits > 1 && elems > SPLIT_CHAIN_MAX_ELEMS) return conv3d(c, x, cw, gn_groups, nm, next);
+    if (splits > 1 && (elems > SPLIT_CHAIN_MAX_ELEMS || (splits >= SPLIT_CHAIN_MAX_SPLITS && (size_t)splits * elems > SPLIT_CHAIN_MAX_SLAB_ELEMS)))
+        return conv3d(c, x, cw, gn_groups, nm, next);
     if (gn_groups && splits == 1 && prec == 1) return conv3d(c, x, cw, gn_groups, nm, next);
     const void *wp = packed(c, cw, prec);
     const float *xr = prec == 1 ? range_for(c, x) : nullptr;

@@ -501,7 +501,8 @@ def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = Non
         prec = 0
     splits = lib.mphip_conv3d_splits(n, ci, pc.co, d, h, w, pc.k, prec)
     shape = (n, pc.co, d, h, w)
-    if splits > 1 and n * pc.co * d * h * w > _SPLIT_CHAIN_MAX_ELEMS:
+    elems = n * pc.co * d * h * w
+    if splits > 1 and (elems > _SPLIT_CHAIN_MAX_ELEMS or (splits >= _SPLIT_CHAIN_MAX_SPLITS and splits * elems > _SPLIT_CHAIN_MAX_SLAB_ELEMS)):
         # mid-sized tensors (G3d's inner levels): the dedicated reduce + vectorised GN kernels are faster than the
         # one-thread-per-element split-aware kernels (measured: -13 % end to end when those were used everywhere)
         if gn_groups:
@@ -528,6 +529,11 @@ def conv3d_split(x: torch.Tensor, pc: PackedConv, precision: Optional[int] = Non
 
 
 _SPLIT_CHAIN_MAX_ELEMS = 1 << 18  # conv outputs up to 1 MB keep their split-K slabs for the GN kernels (FlowField)
+# ... unless there are many of them (a single frame's 2x8x8 level: 24-48 slabs, 9-19 MB): the split-aware statistics kernel is one
+# workgroup per (sample, group) — 32 workgroups at B=1, each reading every slab of its channels (16-23 us) — while the ordered reduce
+# uses the whole chip (r04: B=1 step -60 us)
+_SPLIT_CHAIN_MAX_SPLITS = 16
+_SPLIT_CHAIN_MAX_SLAB_ELEMS = 1 << 20
 _STATS_SPLIT_MAX_SPAN = 65536  # floats per (sample, group) the single-launch split-aware statistics kernel accepts
 
 
