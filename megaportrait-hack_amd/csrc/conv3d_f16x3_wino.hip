@@ -639,6 +639,9 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
 // ---- host side ---------------------------------------------------------------------------------------------------------------
 int f16x3_wino_saturation(unsigned long long *count, int reset) {   // (mphip_f16x3_saturation_count adds it to the direct kernels' counter)
     if (hipMemcpyFromSymbol(count, HIP_SYMBOL(g_f16x3_wino_saturated), sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long pp = 0;   // (the role-split kernel keeps its own counter: separate translation unit)
+    if (f16x3_wino_pp_saturation(&pp, reset) != 0) return -1;
+    *count += pp;
     if (reset) {
         const unsigned long long z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16x3_wino_saturated), &z, sizeof(z)) != hipSuccess) return -1;
@@ -694,6 +697,13 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
     const int cps = (Ci / WN_KC + splits - 1) / splits;
     const unsigned xb = (unsigned)((size_t)N * Ci * D * H * W * 4);
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');
+    const char *pp_env = getenv("MPHIP_WINO_PP");   // dev: same-box A/B against the lockstep schedule (read per call: tools flip it in-process)
+    const bool pp_on = !(pp_env && pp_env[0] == '0');
+    if (pp_on) {   // the role-split schedule (conv3d_f16x3_wino_pp.hip): same arithmetic, same packed weights, same tile
+        f16x3_wino_pp_launch(grid, s, t0, t1, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb, in_affine, in_relu, x_range,
+                             tiles, xcd_on, tile_list, gn_part);
+        return check_launch("conv3d_fwd(f16x3, F(2,3), role-split)");
+    }
     if (t0 && t1)
         hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_kernel, grid, dim3(512), 0, s, t0, t1, 0, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci,
                               Co, D, H, W, cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);

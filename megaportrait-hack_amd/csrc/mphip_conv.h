@@ -48,6 +48,12 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
                       int H, int W, int splits /* f16x3_wino_splits: dst = [splits] slabs when > 1 */, const float *in_affine, int in_relu,
                       const float *x_range, hipStream_t s, const int *tile_list /* demand-driven: {count, tile ids} or NULL */, float *gn_part, hipEvent_t t0, hipEvent_t t1);
 
+// conv3d_f16x3_wino_pp.hip: the same kernel contract on the role-split ("ping-pong") schedule; f16x3_wino_launch picks it
+void f16x3_wino_pp_launch(dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1, const float *x, const _Float16 *slabs, const float *hdr,
+                          const float *bias, float *dst, int N, int Ci, int Co, int D, int H, int W, int cps, unsigned xb,
+                          const float *in_affine, int in_relu, const float *x_range, int tiles, int xcd_on, const int *tile_list,
+                          float *gn_part);
+int f16x3_wino_pp_saturation(unsigned long long *count, int reset);
 
 // conv3d_bwd_f16x3.hip: 3x3x3 backward-weight on the f16 matrix cores (split precision)
 bool bwd_weight_f16x3_supported(int N, int Ci, int Co, int D, int H, int W, int k);
