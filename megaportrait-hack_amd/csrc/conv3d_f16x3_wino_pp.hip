@@ -24,8 +24,8 @@
 // tap)): the pairing is applied by the LDS-DMA's per-lane SOURCE address (k-group block kg of step s comes from tap / k-group
 // (item % 9, item / 9) of the pack) — no second pack.
 //
-// LDS (162 816 B): ring of 3 weight slabs (72 KB) | X, two 8-channel buffers (60 KB) | team A's output-transform exchange
-// (24 KB; team B's is X buffer 1, dead at a tile's end) | fused-GroupNorm table (3 KB).
+// LDS (163 200 B): ring of 3 weight slabs (72 KB) | X, two 8-channel buffers (60 KB) | team A's output-transform exchange
+// (24 KB; team B's is X buffer 1, dead at a tile's end) | fused-GroupNorm table (3 KB) | bias (384 B).
 // Ring hazards (phases numbered globally, A: LOAD(k) = 2k, MFMA(k) = 2k+1; B: one later): slab k is read in phases 2k (A) and
 // 2k+1 (B); a wave issues its pieces of slab k+2 in ITS LOAD(k) — into the slot of slab k-1, last read in phase 2k-1 — waits
 // for them (vmcnt) at the start of ITS next LOAD phase and publishes them with that phase's barrier: A's pieces are visible
@@ -57,7 +57,9 @@ constexpr int PP_AFF_CI = 384;
 constexpr int PP_LDS_X = PP_R * PP_SLAB_B;
 constexpr int PP_LDS_EX = PP_LDS_X + 2 * PP_XBUF_B;
 constexpr int PP_LDS_AFF = PP_LDS_EX + PP_EX_B;
-constexpr int PP_LDS_BYTES = PP_LDS_AFF + PP_AFF_CI * 2 * 4;
+constexpr int PP_LDS_BIAS = PP_LDS_AFF + PP_AFF_CI * 2 * 4;   // the workgroup's 96 bias values (read by the epilogue through LDS: a global
+                                                              // load there would make hipcc wait vmcnt(0) — for the previous round's stores)
+constexpr int PP_LDS_BYTES = PP_LDS_BIAS + PP_COT * 4;
 static_assert(PP_XBUF_B >= PP_EX_B, "team B's exchange lives in X buffer 1");
 static_assert(PP_LDS_BYTES <= 163840 - 128, "LDS");
 
@@ -67,15 +69,27 @@ __device__ unsigned long long g_f16x3_wino_pp_saturated;
 
 #ifdef MPHIP_PP_PROFILE
 // dev instrumentation: wall time (shader cycles) of every phase by step-in-period, summed over waves.  A time stamp is taken at the START of a
-// phase, i.e. right after a barrier (s_memtime, not waited for), and consumed two stamps later: one scalar instruction per phase.
+// phase, i.e. right after a barrier.
 // g_pp_prof[team * 32 + k]: k = 2 sp: LOAD(sp) incl. its barrier, 2 sp + 1: MFMA(sp) incl. its barrier (k = 17 also carries a tile's
 // epilogue and the prologue), 20 waves
+// k = 21..27: the epilogue: 21 = its first segment (slab pre-issue + exchange writes of round 0 + barrier), 22 = round 0 transform + stores + barrier,
+// 23 / 24 and 25 / 26 = rounds 1 and 2, 27 = from the epilogue's last barrier to the next LOAD's stamp
 __device__ unsigned long long g_pp_prof[64];
-#define PPROF_DECL unsigned long long pt0_ = __builtin_readcyclecounter(), pt1_ = pt0_, pa_[18] = {}
-#define PPROF_STAMP(j) { pa_[((j) + 16) % 18] += pt1_ - pt0_; pt0_ = pt1_; pt1_ = __builtin_readcyclecounter(); }
-#define PPROF_FLUSH { PPROF_STAMP(0) PPROF_STAMP(1) if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 18; ++q_) atomicAdd(&g_pp_prof[team * 32 + q_], pa_[q_]); atomicAdd(&g_pp_prof[team * 32 + 20], 1ull); } }
+// (s_memtime as volatile asm WITH its wait: hipcc hoists __builtin_readcyclecounter() across a whole LOAD segment, and an un-waited asm result
+//  lands in an SGPR pair the compiler may already have spilled and reused — for a pointer, as it happened.  Every stamp follows a barrier,
+//  where lgkmcnt is 0 anyway: the wait costs the scalar-memory round trip, ~+10 % on a phase)
+__device__ __forceinline__ unsigned long long pp_memtime() {
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+#define PPROF_DECL unsigned long long pt0_ = pp_memtime(), pt1_ = pt0_, pa_[18] = {}, pe_[7] = {}, pet_ = 0
+#define PPROF_EPI(k) { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = pp_memtime(); if ((k) > 0) pe_[(k) - 1] += n_ - pet_; pet_ = n_; __builtin_amdgcn_sched_barrier(0); }
+#define PPROF_STAMP(j) { __builtin_amdgcn_sched_barrier(0); pa_[((j) + 16) % 18] += pt1_ - pt0_; pt0_ = pt1_; pt1_ = pp_memtime(); __builtin_amdgcn_sched_barrier(0); }
+#define PPROF_FLUSH { PPROF_STAMP(0) PPROF_STAMP(1) if ((threadIdx.x & 63) == 0) { for (int q_ = 0; q_ < 18; ++q_) atomicAdd(&g_pp_prof[team * 32 + q_], pa_[q_]); atomicAdd(&g_pp_prof[team * 32 + 20], 1ull); for (int q_ = 0; q_ < 7; ++q_) atomicAdd(&g_pp_prof[team * 32 + 21 + q_], pe_[q_]); } }
 #else
 #define PPROF_DECL
+#define PPROF_EPI(k)
 #define PPROF_STAMP(j)
 #define PPROF_FLUSH
 #endif
@@ -91,10 +105,16 @@ __device__ unsigned long long g_pp_prof[64];
 #define PP_ABL 0
 #endif
 
-// LDS-DMA of 16 bytes per lane from `base` (wave-uniform) + `off` (per lane) to LDS byte address `lds` + 16 * lane.  Hand-issued
-// for the reason given at lds_dma16 (mphip_f16x3.h); M0 is written in the statement that reads it.
-__device__ __forceinline__ void lds_dma16_s(const void *base, unsigned off, unsigned lds) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
+// Three LDS-DMA pieces of 16 bytes per lane: global `base` (wave-uniform) + `off_i` (per lane) -> LDS byte address `lds_i` + 16 * lane.
+// Hand-issued for the reason given at lds_dma16 (mphip_f16x3.h); M0 is written in the statement that reads it.  The statement opens
+// with `s_nop 4`: `base` may have been reloaded from a spill lane by v_readlane just before, and a VALU-written SGPR needs 5 wait
+// states before a vector-memory instruction reads it — hipcc pads nothing inside an asm string (cdna_hip_programming.md 5.7).
+__device__ __forceinline__ void pp_dma3(const void *base, unsigned off0, unsigned off1, unsigned off2, unsigned lds0, unsigned lds1, unsigned lds2) {
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+                 "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                 "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3"
+                 ::"v"(off0), "v"(off1), "v"(off2), "s"(base), "s"(lds0), "s"(lds1), "s"(lds2) : "memory");
 }
 
 // hi/lo split helpers as single instructions (hipcc has no builtin for either and, left alone, SLP-packs the surrounding fp32 arithmetic
@@ -123,15 +143,16 @@ __device__ __forceinline__ float pp_sub_hi(unsigned h, float t) {
 // unit's loads have landed two phases before its first use (cdna_hip_programming.md 5.7: no use of the destination before that wait,
 // every phase ends in a sched_barrier; the kernel stays below the VGPR limit without spills, so no live range is split or copied).
 typedef unsigned pp_u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f32x4 pp_buf_load_f4(pp_u32x4 rsrc, unsigned voff) {
-    f32x4 r;
-    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
-    return r;
+// (one statement per group of loads, opened by `s_nop 4` for the descriptor — see pp_dma3; early-clobber outputs: a destination must not
+//  share a register with the address of a later load of the same statement)
+__device__ __forceinline__ void pp_buf_load_2x4(pp_u32x4 rsrc, unsigned o0, unsigned o1, f32x4 &r0, f32x4 &r1) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %4, 0 offen\n\tbuffer_load_dwordx4 %1, %3, %4, 0 offen"
+                 : "=&v"(r0), "=&v"(r1) : "v"(o0), "v"(o1), "s"(rsrc) : "memory");
 }
-__device__ __forceinline__ float pp_buf_load_f(pp_u32x4 rsrc, unsigned voff) {
-    float r;
-    asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
-    return r;
+__device__ __forceinline__ void pp_buf_load_4x1(pp_u32x4 rsrc, unsigned o0, unsigned o1, unsigned o2, unsigned o3, float &r0, float &r1, float &r2, float &r3) {
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %4, %8, 0 offen\n\tbuffer_load_dword %1, %5, %8, 0 offen\n\t"
+                 "buffer_load_dword %2, %6, %8, 0 offen\n\tbuffer_load_dword %3, %7, %8, 0 offen"
+                 : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rsrc) : "memory");
 }
 
 struct PpPeriod {   // what a 16-channel period of the K stream addresses (wave-uniform)
@@ -212,62 +233,72 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
     float xl0, xr0, xl1, xr1;   // ... w0-1, w0+8
     float xmaxf_ = 0.0f;        // max |scaled halo value| this thread staged (finite or Inf) ...
     bool xnan_ = false;         // ... and whether it saw a NaN (v_max drops them)
+    unsigned o_row = OOB;       // byte offset of (n, channel 2cp of the half, row, w0) of the unit being loaded, or OOB (padding rows): kept from part 0
     auto halo_load = [&](const PpPeriod &s, auto PARTc) __attribute__((always_inline)) {
         constexpr int part = decltype(PARTc)::value;
         if (PP_ABL & 2) { asm volatile("" : "+v"(xa0), "+v"(xb0), "+v"(xa1), "+v"(xb1), "+v"(xl0), "+v"(xr0), "+v"(xl1), "+v"(xr1)); return; }
-        const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
-        const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
-        const unsigned o = in ? (unsigned)((((long)s.n * Ci + s.chunk * 16 + team * 8 + 2 * cp) * DHW + (long)gd * HW + gh * W + s.w0) * 4) : OOB;
-        const unsigned o1 = in ? o + chan_stride : OOB;
         if constexpr (part == 0) {
-            xa0 = pp_buf_load_f4(rsrc, o);
-            xb0 = pp_buf_load_f4(rsrc, in ? o + 16u : OOB);
+            const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
+            const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+            o_row = in ? (unsigned)((((long)s.n * Ci + s.chunk * 16 + team * 8 + 2 * cp) * DHW + (long)gd * HW + gh * W + s.w0) * 4) : OOB;
+        }
+        const bool in = o_row != OOB;
+        const unsigned o = o_row, o1 = in ? o + chan_stride : OOB;
+        if constexpr (part == 0) {
+            pp_buf_load_2x4(rsrc, o, in ? o + 16u : OOB, xa0, xb0);
         } else if constexpr (part == 1) {
-            xa1 = pp_buf_load_f4(rsrc, o1);
-            xb1 = pp_buf_load_f4(rsrc, in ? o1 + 16u : OOB);
+            pp_buf_load_2x4(rsrc, o1, in ? o1 + 16u : OOB, xa1, xb1);
         } else {
             const bool lft = in && s.w0 > 0, rgt = in && s.w0 + PP_TW < W;
-            xl0 = pp_buf_load_f(rsrc, lft ? o - 4u : OOB);
-            xr0 = pp_buf_load_f(rsrc, rgt ? o + 32u : OOB);
-            xl1 = pp_buf_load_f(rsrc, lft ? o1 - 4u : OOB);
-            xr1 = pp_buf_load_f(rsrc, rgt ? o1 + 32u : OOB);
+            pp_buf_load_4x1(rsrc, lft ? o - 4u : OOB, rgt ? o + 32u : OOB, lft ? o1 - 4u : OOB, rgt ? o1 + 32u : OOB, xl0, xr0, xl1, xr1);
         }
     };
-    // (fused GroupNorm + ReLU) -> operand scale, in place.  The scale S is a power of two: (x m + a) S == x (m S) + a S and max(., 0) S ==
-    // max(. S, 0) bit for bit, so the fused path folds S into the table entries instead of multiplying every value again.
-    auto halo_convert = [&](const PpPeriod &s) __attribute__((always_inline)) {
+    // (fused GroupNorm + ReLU) -> operand scale, in place; part 0: channel 2cp, 1: channel 2cp+1, 2: the four edge voxels — one part per LOAD
+    // phase, each at least two phases after its loads (the counted waits in between have retired them).  The scale S is a power of two:
+    // (x m + a) S == x (m S) + a S and max(., 0) S == max(. S, 0) bit for bit, so the fused path folds S into the table entries.
+    auto halo_convert = [&](const PpPeriod &s, auto PARTc) __attribute__((always_inline)) {
+        constexpr int part = decltype(PARTc)::value;
         if (PP_ABL & 1) { asm volatile("" :: "v"(xa0), "v"(xb0), "v"(xa1), "v"(xb1), "v"(xl0), "v"(xr0), "v"(xl1), "v"(xr1)); return; }
-        if (fuse_in) {   // padding (rows / edge voxels outside the volume) must stay 0: its (scale, shift) pair is zeroed, and
-                         // max(0*x + 0, floor) = 0 for both floors — no select, no branch
-            const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
-            const float mid = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? x_scale : 0.0f;
-            const float lft = s.w0 > 0 ? mid : 0.0f, rgt = s.w0 + PP_TW < W ? mid : 0.0f;
-            const float4 sc = *reinterpret_cast<const float4 *>(aff + (s.chunk * 16 + team * 8 + 2 * cp) * 2);
-            const float m0 = sc.x * mid, a0 = sc.y * mid, m1 = sc.z * mid, a1 = sc.w * mid;
-            const float rf = relu_floor * x_scale;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                xa0[i] = fmaxf(xa0[i] * m0 + a0, rf);
-                xb0[i] = fmaxf(xb0[i] * m0 + a0, rf);
-                xa1[i] = fmaxf(xa1[i] * m1 + a1, rf);
-                xb1[i] = fmaxf(xb1[i] * m1 + a1, rf);
-            }
-            xl0 = fmaxf(xl0 * (sc.x * lft) + sc.y * lft, rf);
-            xr0 = fmaxf(xr0 * (sc.x * rgt) + sc.y * rgt, rf);
-            xl1 = fmaxf(xl1 * (sc.z * lft) + sc.w * lft, rf);
-            xr1 = fmaxf(xr1 * (sc.z * rgt) + sc.w * rgt, rf);
-        } else {
-            xa0 *= x_scale; xb0 *= x_scale; xa1 *= x_scale; xb1 *= x_scale;
-            xl0 *= x_scale; xr0 *= x_scale; xl1 *= x_scale; xr1 *= x_scale;
-        }
         // range diagnostic: one v_max3 (|a|, |b|, m) and one unordered compare per two values
         auto note = [&](float a, float b) {
             xmaxf_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), xmaxf_);
             xnan_ |= __builtin_isunordered(a, b);
         };
+        if (fuse_in) {   // padding (rows / edge voxels outside the volume) must stay 0: its (scale, shift) pair is zeroed, and
+                         // max(0*x + 0, floor) = 0 for both floors — no select, no branch
+            const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
+            const float mid = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? x_scale : 0.0f;
+            const float rf = relu_floor * x_scale;
+            const float *const tb = aff + (s.chunk * 16 + team * 8 + 2 * cp) * 2;   // (scale, shift) of channel 2cp, then of 2cp+1
+            if constexpr (part < 2) {
+                const float2 sc = *reinterpret_cast<const float2 *>(tb + 2 * part);
+                const float m = sc.x * mid, a = sc.y * mid;
+                f32x4 &xa = part == 0 ? xa0 : xa1, &xb = part == 0 ? xb0 : xb1;
 #pragma unroll
-        for (int i = 0; i < 4; i += 2) { note(xa0[i], xa0[i + 1]); note(xb0[i], xb0[i + 1]); note(xa1[i], xa1[i + 1]); note(xb1[i], xb1[i + 1]); }
-        note(xl0, xr0); note(xl1, xr1);
+                for (int i = 0; i < 4; ++i) {
+                    xa[i] = fmaxf(xa[i] * m + a, rf);
+                    xb[i] = fmaxf(xb[i] * m + a, rf);
+                }
+            } else {
+                const float lft = s.w0 > 0 ? mid : 0.0f, rgt = s.w0 + PP_TW < W ? mid : 0.0f;
+                const float4 sc = *reinterpret_cast<const float4 *>(tb);
+                xl0 = fmaxf(xl0 * (sc.x * lft) + sc.y * lft, rf);
+                xr0 = fmaxf(xr0 * (sc.x * rgt) + sc.y * rgt, rf);
+                xl1 = fmaxf(xl1 * (sc.z * lft) + sc.w * lft, rf);
+                xr1 = fmaxf(xr1 * (sc.z * rgt) + sc.w * rgt, rf);
+            }
+        } else if constexpr (part == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xa0[i] *= x_scale; xb0[i] *= x_scale; }
+        } else if constexpr (part == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { xa1[i] *= x_scale; xb1[i] *= x_scale; }
+        } else {
+            xl0 *= x_scale; xr0 *= x_scale; xl1 *= x_scale; xr1 *= x_scale;
+        }
+        if constexpr (part == 0) { note(xa0[0], xa0[1]); note(xa0[2], xa0[3]); note(xb0[0], xb0[1]); note(xb0[2], xb0[3]); }
+        else if constexpr (part == 1) { note(xa1[0], xa1[1]); note(xa1[2], xa1[3]); note(xb1[0], xb1[1]); note(xb1[2], xb1[3]); }
+        else { note(xl0, xr0); note(xl1, xr1); }
     };
     // output pair q of the row: F(2,3) input transform (fp32, after the scale), hi/lo split, 8 half2 stores into the team's buffer.
     // Split of t: hi = rne_f16(t), lo = rne_f16(t - hi) with t - hi as ONE v_fma_mix_f32 (f16 source, exact); the four positions are
@@ -305,6 +336,17 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
     auto load_aff = [&](int n, int first, int stride) {
         for (int i = first; i < Ci * 2; i += stride) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
     };
+    // the same table for another frame, as LDS-DMA (ONE wave, up to three pieces of 1 KiB; lanes beyond the table are masked off): nothing in
+    // the main loop is a compiler-visible load, so hipcc never waits vmcnt(0) in it
+    const unsigned aff_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char *)smem + PP_LDS_AFF;
+    auto dma_aff = [&](int n) __attribute__((always_inline)) {
+        const unsigned char *const src = reinterpret_cast<const unsigned char *>(in_affine + (size_t)n * Ci * 2);
+        const int bytes = Ci * 8;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            if (i * 1024 < bytes && lane * 16 + i * 1024 < bytes)
+                asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"((unsigned)(lane * 16 + i * 1024)), "s"(src), "s"(aff_lds + i * 1024) : "memory");
+    };
 
     // ---- weight stream ------------------------------------------------------------------------------------------------------------
     // piece i of a wave covers LDS bytes [(wave + 8 i) KiB, +1 KiB) of the slab image; a lane's 16 bytes lie in k-group block
@@ -331,9 +373,9 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
         constexpr unsigned V0 = sq == 4 ? 0u : ((2 * sq) % 9) * PP_SLAB_B + ((2 * sq) / 9) * PP_KGBLK_B;   // (tap, k-group) of item 2 sq
         constexpr unsigned slot = sq % PP_R;
         if (PP_ABL & 4) return;
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-            lds_dma16_s(base + V0, sq == 4 ? dsrc4[i] : dsrc[i], lds0 + slot * PP_SLAB_B + (unsigned)(wave + 8 * i) * 1024u);
+        const unsigned dst = lds0 + slot * PP_SLAB_B + (unsigned)wave * 1024u;
+        if constexpr (sq == 4) pp_dma3(base + V0, dsrc4[0], dsrc4[1], dsrc4[2], dst, dst + 8192u, dst + 16384u);
+        else pp_dma3(base + V0, dsrc[0], dsrc[1], dsrc[2], dst, dst + 8192u, dst + 16384u);
     };
 
     // fragment bases (bytes)
@@ -349,6 +391,7 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
     PpPeriod cur = period_at(j_first, c_begin), nxt = cur;
     bool nxt_ok = per_total > 1;
     if (nxt_ok) nxt = period_next(cur);
+    if (tid < PP_COT) reinterpret_cast<float *>(smem + PP_LDS_BIAS)[tid] = (gridDim.z == 1 && bias) ? bias[cot * PP_COT + tid] : 0.0f;
     if (fuse_in) {
         load_aff(cur.n, tid, 512);
         aff_n = cur.n;
@@ -361,7 +404,9 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
     halo_load(cur, std::integral_constant<int, 2>{});
     lds_dma_wait<0>();
     __builtin_amdgcn_sched_barrier(0);
-    halo_convert(cur);
+    halo_convert(cur, std::integral_constant<int, 0>{});
+    halo_convert(cur, std::integral_constant<int, 1>{});
+    halo_convert(cur, std::integral_constant<int, 2>{});
     halo_write(std::integral_constant<int, 0>{});
     halo_write(std::integral_constant<int, 1>{});
     halo_write(std::integral_constant<int, 2>{});
@@ -375,7 +420,8 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
     const bool direct = gridDim.z == 1;
     float *const Ex = reinterpret_cast<float *>(smem + (team == 0 ? PP_LDS_EX : PP_LDS_X + PP_XBUF_B));   // [position][slot 0..5][lane][4]
     int gp = 0;   // period being multiplied
-    int epi_stores = 0;   // global stores of the last epilogue: younger than the weight pieces the next LOAD phase waits for
+    int epi_stores = 0;   // global stores of the last epilogue: younger than the weight pieces the next two LOAD phases wait for
+    bool pre2 = false;    // slab 2 of the tile that starts was issued at the top of the previous tile's epilogue (see there)
 #if PP_PRIO == 2
     if (team == 1) __builtin_amdgcn_s_setprio(1);
 #endif
@@ -401,10 +447,14 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
             auto step = [&](auto SPc) __attribute__((always_inline)) {
                 constexpr int sp = decltype(SPc)::value;
                 // ---------------- LOAD(sp): everything but the MFMAs ----------------
+                PPROF_STAMP(2 * sp)
+#ifdef MPHIP_PP_PROFILE
+                if (sp == 0 && pet_) { pe_[6] += pt1_ - pet_; pet_ = 0; }
+#endif
                 // An LDS-DMA piece needs ~1 us to land under load (MI355X_MICROARCH.md "ldsdma-fill"): this step's pieces (slab sp+2) are issued
                 // FIRST and waited for at the END of the wave's next LOAD phase — two full phases plus a LOAD body later; that phase's barrier
                 // publishes them one phase before their first reader.
-                const bool issue = gp * 9 + sp + 2 < s_total;
+                const bool issue = !(sp == 0 && pre2) && gp * 9 + sp + 2 < s_total;
                 auto dma = [&]() __attribute__((always_inline)) {
                     if (issue) {
                         if constexpr (sp + 2 < 9) dma_slab(std::integral_constant<int, sp + 2>{}, wcur);
@@ -434,53 +484,55 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
                     bl[1] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B + PP_HH * 64);
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                // halo staging: A loads the next period's even half at step 0 and writes it (buffer 0) at steps 5-8; B loads the odd
-                // half at step 4 and writes it (buffer 1) at steps 0-3 of the period it belongs to
-                // A loads the next period's even half over steps 0-2 and writes it (buffer 0) at steps 5-8; B loads the odd half over steps
-                // 4-6 and writes it (buffer 1) at steps 0-3 of the period it belongs to.
-                // `younger`: vector-memory operations of this wave younger than its pieces of slab sp+1 (issued first thing in its previous LOAD
-                // phase): that phase's halo loads, this phase's pieces and halo loads
-                constexpr int hl_[10] = {0, 2, 2, 4, 0, 0, 0, 0, 0, 0};   // [1 + s]: halo loads of a team's s-th step after its prefetch starts
-                constexpr int spa = sp, spb = (sp + 5) % 9;           // that step index for team A (starts at step 0) and team B (at step 4)
+                // Halo staging, one slice per LOAD phase.  In the team's own count ts (A: ts = step; B starts at step 4: ts = step - 4 mod 9):
+                //   ts 0, 1, 2: load part 0 (channel 2cp), part 1 (channel 2cp+1), part 2 (the four edge voxels)
+                //   ts 3, 4   : normalise / scale parts 0, 1 (their loads were retired by the counted waits that ended ts 2 and ts 3)
+                //   ts 5      : part 2, then output pair 0;   ts 6, 7, 8: output pairs 1, 2, 3
+                // A stages the next period's even half into buffer 0 (free during steps 5-8); B the odd half into buffer 1 (free during steps
+                // 0-3 of the period the data belongs to: B's ts 5-8 fall into the NEXT period, where that data is `cur`).
+                // hl_[1 + ts]: halo loads of step ts; HA / HB: those of this and the previous LOAD phase — all younger than the pieces waited for
+                constexpr int hl_[10] = {0, 2, 2, 4, 0, 0, 0, 0, 0, 0};
+                constexpr int spa = sp, spb = (sp + 5) % 9;
                 constexpr int HA = hl_[1 + spa] + hl_[spa], HB = hl_[1 + spb] + hl_[spb];
+                constexpr int ts = team == 0 ? spa : spb;
+                constexpr bool late = team == 1 && sp < 4;                  // (B's ts 5-8)
+                const PpPeriod &stp = late ? cur : nxt;
+                const bool st_on = late ? gp > 0 : nxt_ok;
                 const bool hl_on = nxt_ok && !(PP_ABL & 2);
                 const bool dma_on = issue && !(PP_ABL & 4);
-                if constexpr (sp == 0) {
-                    if (team == 0) {
-                        if (nxt_ok) halo_load(nxt, std::integral_constant<int, 0>{});
-                    } else if (gp > 0) {
-                        halo_convert(cur);
-                        halo_write(std::integral_constant<int, 0>{});
+                if (st_on) {
+                    if constexpr (ts < 3) halo_load(stp, std::integral_constant<int, (ts < 3 ? ts : 0)>{});
+                    else if constexpr (ts < 5) halo_convert(stp, std::integral_constant<int, (ts >= 3 && ts < 5 ? ts - 3 : 0)>{});
+                    else {
+                        if constexpr (ts == 5) halo_convert(stp, std::integral_constant<int, 2>{});
+                        halo_write(std::integral_constant<int, (ts >= 5 ? ts - 5 : 0)>{});
                     }
-                } else if constexpr (sp < 4) {
-                    if (team == 0) {
-                        if (sp < 3 && nxt_ok) halo_load(nxt, std::integral_constant<int, (sp < 3 ? sp : 0)>{});
-                    } else if (gp > 0) halo_write(std::integral_constant<int, sp>{});
-                } else if constexpr (sp == 4) {
-                    if (team == 1) {
-                        if (reload_aff) load_aff(nxt.n, tt, 256);   // (its last reader was B's step 0; the next one is A's step 5)
-                        if (nxt_ok) halo_load(nxt, std::integral_constant<int, 0>{});
-                    }
-                } else {
-                    if (team == 0) {
-                        if (nxt_ok) {
-                            if constexpr (sp == 5) halo_convert(nxt);
-                            halo_write(std::integral_constant<int, sp - 5>{});
-                        }
-                    } else if (sp < 7 && nxt_ok) halo_load(nxt, std::integral_constant<int, (sp < 7 ? sp - 4 : 0)>{});
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // The wait that ends a LOAD phase: this wave's pieces of slab sp+1 (issued first thing in its previous LOAD phase) have landed
                 // — its barrier below publishes them.  Younger, and left in flight: this phase's three pieces, the halo loads of this and
                 // the previous phase (HA / HB: per team, compile-time), and — in a tile's first phase — the epilogue's stores.
-                if (!dma_on) lds_dma_wait<0>();   // (the stream's last two steps: nothing was issued, drain)
-                else if (sp == 0 && epi_stores) {
-                    if (epi_stores == 12) { if (team == 0 && hl_on) lds_dma_wait<3 + HA + 12>(); else lds_dma_wait<3 + 12>(); }
-                    else { if (team == 0 && hl_on) lds_dma_wait<3 + HA + 24>(); else lds_dma_wait<3 + 24>(); }
-                } else if (HA != 0 && team == 0 && hl_on) lds_dma_wait<3 + HA>();
-                else if (HB != 0 && team == 1 && hl_on) lds_dma_wait<3 + HB>();
+                constexpr int HT = team == 0 ? HA : HB;
+                if (sp < 2 && epi_stores) {   // (uniform; vmcnt retires in order: a tile's first two waits must not ask for its predecessor's stores)
+                    const int h = hl_on ? HT : 0;
+                    auto wait_e = [&](auto Ec) __attribute__((always_inline)) {
+                        constexpr int E = decltype(Ec)::value;
+                        if (h == 0) lds_dma_wait<3 + E>(); else if (h == 2) lds_dma_wait<3 + 2 + E>(); else lds_dma_wait<3 + 4 + E>();
+                    };
+                    if (epi_stores == 12) wait_e(std::integral_constant<int, 12>{}); else wait_e(std::integral_constant<int, 24>{});
+                    if (sp == 1) epi_stores = 0;
+                } else if (!dma_on) lds_dma_wait<0>();   // (the stream's last two steps: nothing was issued, drain)
+                else if (HT != 0 && hl_on) lds_dma_wait<3 + HT>();
                 else lds_dma_wait<3>();
-                if (sp == 0) epi_stores = 0;
+                if (sp == 0) pre2 = false;
+                if constexpr (sp == 0 && team == 1) {
+                    // the fused-GroupNorm table of the next period's frame: its last reader was this phase's part-2 conversion, the next one
+                    // is team A's step 3, three barriers on (this wave's next counted wait retires the transfer)
+                    if (reload_aff && p == 0) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        dma_aff(nxt.n);
+                    }
+                }
 #if PP_PRIO == 3
                 __builtin_amdgcn_s_setprio(0);
 #endif
@@ -540,90 +592,118 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
             continue;
         }
 #endif
+        PPROF_EPI(0)
+        // The next tile's slab 2 goes out HERE, ahead of this tile's output stores (its slot — slab 8's — was last read a barrier ago): vmcnt
+        // retires in order, so issued from the next LOAD phase it would sit behind the twelve stores, and the wait for it, two phases
+        // later, would be a wait for a chip-wide store burst.  This way the stores have until the wait for slab 3.
+        if (!(PP_ABL & 4) && gp * 9 + 2 < s_total) {
+            dma_slab(std::integral_constant<int, 2>{}, wchunk(cur.chunk));
+            pre2 = true;
+        }
         const int gn_rows = tiles_total * 2;   // channel-major [Co][tile * 2 + plane pair][2] (the finalize kernel reads rows of it)
         if (gn_part && etile == 0 && tid == 0) gn_part[(size_t)gn_rows * Co * 2] = unscale;   // (behind the partials)
+        // The rounds are instantiated per Winograd position (the wave's `p` is a run-time value, the registers it parks / keeps are not: with
+        // p a variable every unit went through select chains, ~90 VALU instructions per round).  Stores: uniform base (scalar registers) +
+        // one 32-bit per-lane offset for all twelve, so that no 64-bit address is assembled per store.
         const bool odd = (lane & 1) != 0;
-        // (row start of this lane's QUAD of voxels: lanes 2k / 2k+1 store the 4 voxels 4k..4k+3 of a row, for different channels)
-        float *const dsto = (direct ? y : y + (size_t)blockIdx.z * N * Co * DHW) + (size_t)en * Co * DHW + (size_t)(ed0 + 2 * team) * HW + (size_t)(eh0 + (j >> 2)) * W + ew0 + 2 * (j & 2);
+        // (this lane's QUAD of voxels: lanes 2k / 2k+1 store the 4 voxels 4k..4k+3 of a row, for different channels)
+        float *const ybase = (direct ? y : y + (size_t)blockIdx.z * N * Co * DHW) + ((size_t)en * Co + co0) * DHW + (size_t)(ed0 + 2 * team) * HW + (size_t)eh0 * W + ew0;
+        const unsigned yoff = (unsigned)(((8 * p + 4 * kgl + (odd ? 2 : 0)) * DHW + (j >> 2) * W + 2 * (j & 2)) * 4);
+        auto rounds = [&](auto Pc) __attribute__((always_inline)) {
+            constexpr int P = decltype(Pc)::value;
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of both column tiles; wave p keeps unit p
+            for (int m = 0; m < 3; ++m) {
+                // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of both column tiles; wave P keeps unit P
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    if (u != p) {
-                        const int slot = t * 3 + (u - (u > p ? 1 : 0));
-                        const f32x4 v = {acc[m][t][4 * u], acc[m][t][4 * u + 1], acc[m][t][4 * u + 2], acc[m][t][4 * u + 3]};
-                        *reinterpret_cast<f32x4 *>(Ex + ((p * 6 + slot) * 64 + lane) * 4) = v;
+                    for (int u = 0; u < 4; ++u)
+                        if (u != P) {
+                            const int slot = t * 3 + (u - (u > P ? 1 : 0));
+                            const f32x4 v = {acc[m][t][4 * u], acc[m][t][4 * u + 1], acc[m][t][4 * u + 2], acc[m][t][4 * u + 3]};
+                            *reinterpret_cast<f32x4 *>(Ex + ((P * 6 + slot) * 64 + lane) * 4) = v;
+                        }
+                lds_barrier();
+                PPROF_EPI(1 + 2 * m)
+                float ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(smem + PP_LDS_BIAS + (m * 32 + 8 * P + 4 * kgl) * 4);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    f32x4 M[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if (q != P) {
+                            const int slot = t * 3 + (P - (P > q ? 1 : 0));
+                            M[q] = *reinterpret_cast<const f32x4 *>(Ex + ((q * 6 + slot) * 64 + lane) * 4);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) M[q][i] = acc[m][t][4 * q + i];
+                        }
                     }
-            lds_barrier();
-            float ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            float bv[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) bv[i] = (direct && bias) ? bias[co0 + m * 32 + 8 * p + 4 * kgl + i + tz] : 0.0f;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                f32x4 M[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (q != p) {
-                        const int slot = t * 3 + (p - (p > q ? 1 : 0));
-                        M[q] = *reinterpret_cast<const f32x4 *>(Ex + ((q * 6 + slot) * 64 + lane) * 4);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) M[q][i] = acc[m][t][4 * q + i];
-                    }
-                }
-                float y0[4], y1[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float r0 = (M[0][i] + M[1][i]) + M[2][i];
-                    const float r1 = (M[1][i] - M[2][i]) - M[3][i];
-                    ssum[i] += r0 + r1;
-                    qsum[i] = __builtin_fmaf(r0, r0, qsum[i]);
-                    qsum[i] = __builtin_fmaf(r1, r1, qsum[i]);
-                    y0[i] = r0 * unscale + bv[i];
-                    y1[i] = r1 * unscale + bv[i];
-                }
-                // 16-byte stores: a lane holds one output pair (2 voxels) of 4 channels; lanes 2k / 2k+1 hold neighbouring pairs of a row and
-                // trade halves (quad_perm [1,0,3,2]): the even lane ends up with 4 consecutive voxels of channels 0-1, the odd lane with
-                // those of channels 2-3
-#define PP_SWAP(v_) __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), 0xB1, 0xf, 0xf, false))
-                const float g0 = PP_SWAP(odd ? y0[0] : y0[2]), g1 = PP_SWAP(odd ? y1[0] : y1[2]);
-                const float g2 = PP_SWAP(odd ? y0[1] : y0[3]), g3 = PP_SWAP(odd ? y1[1] : y1[3]);
-#undef PP_SWAP
-                const f32x4 va = {odd ? g0 : y0[0], odd ? g1 : y1[0], odd ? y0[2] : g0, odd ? y1[2] : g1};
-                const f32x4 vb = {odd ? g2 : y0[1], odd ? g3 : y1[1], odd ? y0[3] : g2, odd ? y1[3] : g3};
-                float *const dq = dsto + (size_t)(co0 + m * 32 + 8 * p + 4 * kgl + (odd ? 2 : 0) + tz) * DHW + (size_t)t * HW;
-                *reinterpret_cast<f32x4 *>(dq) = va;
-                *reinterpret_cast<f32x4 *>(dq + DHW) = vb;
-            }
-            if (gn_part) {
-                // per-channel (sum, sum of squares) of the RAW transformed accumulators over this wave's 2 x 64 voxels of the channel:
-                // the 32 lanes of a half-wave hold one channel's columns (the finalize kernel applies unscale and the bias in double)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-#define PP_ROW_ADD(v_, ctrl_) v_ += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), ctrl_, 0xf, 0xf, false));
-                    PP_ROW_ADD(ssum[i], 0x128) PP_ROW_ADD(qsum[i], 0x128)   // row_ror:8, :4, :2, :1 -> every lane of a 16-lane row: the row's sum
-                    PP_ROW_ADD(ssum[i], 0x124) PP_ROW_ADD(qsum[i], 0x124)
-                    PP_ROW_ADD(ssum[i], 0x122) PP_ROW_ADD(qsum[i], 0x122)
-                    PP_ROW_ADD(ssum[i], 0x121) PP_ROW_ADD(qsum[i], 0x121)
-#undef PP_ROW_ADD
-                    ssum[i] += __shfl_xor(ssum[i], 16, 64);
-                    qsum[i] += __shfl_xor(qsum[i], 16, 64);
-                }
-                if (j == 0) {
+                    float y0[4], y1[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const int co = co0 + m * 32 + 8 * p + 4 * kgl + i + tz;
-                        *reinterpret_cast<float2 *>(gn_part + ((size_t)co * gn_rows + (size_t)etile * 2 + team) * 2) = make_float2(ssum[i], qsum[i]);
+                        const float r0 = (M[0][i] + M[1][i]) + M[2][i];
+                        const float r1 = (M[1][i] - M[2][i]) - M[3][i];
+                        if (gn_part) {   // (uniform)
+                            ssum[i] += r0 + r1;
+                            qsum[i] = __builtin_fmaf(r0, r0, qsum[i]);
+                            qsum[i] = __builtin_fmaf(r1, r1, qsum[i]);
+                        }
+                        y0[i] = r0 * unscale + bv[i];
+                        y1[i] = r1 * unscale + bv[i];
+                    }
+                    // 16-byte stores: a lane holds one output pair (2 voxels) of 4 channels; lanes 2k / 2k+1 hold neighbouring pairs of a row and
+                    // trade halves (quad_perm [1,0,3,2]): the even lane ends up with 4 consecutive voxels of channels 0-1, the odd lane with
+                    // those of channels 2-3
+#define PP_SWAP(v_) __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), 0xB1, 0xf, 0xf, false))
+                    const float g0 = PP_SWAP(odd ? y0[0] : y0[2]), g1 = PP_SWAP(odd ? y1[0] : y1[2]);
+                    const float g2 = PP_SWAP(odd ? y0[1] : y0[3]), g3 = PP_SWAP(odd ? y1[1] : y1[3]);
+#undef PP_SWAP
+                    const f32x4 va = {odd ? g0 : y0[0], odd ? g1 : y1[0], odd ? y0[2] : g0, odd ? y1[2] : g1};
+                    const f32x4 vb = {odd ? g2 : y0[1], odd ? g3 : y1[1], odd ? y0[3] : g2, odd ? y1[3] : g3};
+                    unsigned char *const dq = reinterpret_cast<unsigned char *>(ybase + (size_t)(m * 32 + tz) * DHW + (size_t)t * HW);   // (uniform)
+#if PP_ABL & 512   /* timing only: the output transform without its global stores */
+                    asm volatile("" ::"v"(va), "v"(vb), "s"(dq));
+#else
+                    *reinterpret_cast<f32x4 *>(dq + yoff) = va;
+                    *reinterpret_cast<f32x4 *>(dq + (size_t)DHW * 4 + yoff) = vb;
+#endif
+                }
+                if (gn_part) {
+                    // per-channel (sum, sum of squares) of the RAW transformed accumulators over this wave's 2 x 64 voxels of the channel:
+                    // the 32 lanes of a half-wave hold one channel's columns (the finalize kernel applies unscale and the bias in double)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+#define PP_ROW_ADD(v_, ctrl_) v_ += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(v_), ctrl_, 0xf, 0xf, false));
+                        PP_ROW_ADD(ssum[i], 0x128) PP_ROW_ADD(qsum[i], 0x128)   // row_ror:8, :4, :2, :1 -> every lane of a 16-lane row: the row's sum
+                        PP_ROW_ADD(ssum[i], 0x124) PP_ROW_ADD(qsum[i], 0x124)
+                        PP_ROW_ADD(ssum[i], 0x122) PP_ROW_ADD(qsum[i], 0x122)
+                        PP_ROW_ADD(ssum[i], 0x121) PP_ROW_ADD(qsum[i], 0x121)
+#undef PP_ROW_ADD
+                        // rows 1 and 3 add the totals of rows 0 and 2 (row_bcast:15, row mask 0b1010): lanes 16-31 / 48-63 hold a half-wave's sum
+                        ssum[i] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(ssum[i]), 0x142, 0xa, 0xf, false));
+                        qsum[i] += __uint_as_float(__builtin_amdgcn_update_dpp(0, __float_as_uint(qsum[i]), 0x142, 0xa, 0xf, false));
+                    }
+                    if (j == 31) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int co = co0 + m * 32 + 8 * P + 4 * kgl + i + tz;
+                            *reinterpret_cast<float2 *>(gn_part + ((size_t)co * gn_rows + (size_t)etile * 2 + team) * 2) = make_float2(ssum[i], qsum[i]);
+                        }
                     }
                 }
+                lds_barrier();   // the region is rewritten by the next round / (team B's) by the next period's halo
+                PPROF_EPI(2 + 2 * m)
             }
-            lds_barrier();   // the region is rewritten by the next round / (team B's) by the next period's halo
+        };
+        switch (p) {   // (wave-uniform)
+        case 0: rounds(std::integral_constant<int, 0>{}); break;
+        case 1: rounds(std::integral_constant<int, 1>{}); break;
+        case 2: rounds(std::integral_constant<int, 2>{}); break;
+        default: rounds(std::integral_constant<int, 3>{}); break;
         }
-        epi_stores = gn_part ? 24 : 12;
+        epi_stores = (PP_ABL & 512) ? (gn_part ? 12 : 0) : gn_part ? 24 : 12;
     }
     if (team == 0) lds_barrier();   // (team B's extra barrier at the start)
 

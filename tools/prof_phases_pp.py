@@ -34,3 +34,6 @@ for team in (0, 1):
     print("   step      " + " ".join(f"{sp:6d}" for sp in range(9)))
     print("   LOAD wall " + " ".join(f"{per[2 * sp]:6.0f}" for sp in range(9)) + f"   sum {sum(per[0::2]):.0f}")
     print("   MFMA wall " + " ".join(f"{per[2 * sp + 1]:6.0f}" for sp in range(9)) + f"   sum {sum(per[1::2]):.0f}")
+    ntile = N * tiles / 256.0
+    ep = [c / waves / ntile * N for c in v[team * 32 + 21: team * 32 + 28]]
+    print("   epilogue per tile: pre-issue+write0 %.0f | xform0 %.0f | write1 %.0f | xform1 %.0f | write2 %.0f | xform2 %.0f | to next LOAD %.0f   sum %.0f" % (*ep, sum(ep)))
