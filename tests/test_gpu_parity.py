@@ -293,6 +293,45 @@ def test_conv3d_f16x3_winograd_domain_is_fp32_class(ops, _libmod, dev, case):
         assert maxabs(dx, want) / want.abs().max().item() < 3e-6
 
 
+ROLE_SPLIT_CASES = [(1, 96, 96, 16, 64, 64), (8, 192, 192, 8, 32, 32), (2, 96, 96, 4, 8, 8), (3, 16, 96, 4, 16, 8), (8, 384, 192, 4, 16, 16),
+                    (1, 256, 96, 8, 24, 40), (5, 96, 96, 4, 16, 16)]
+
+
+@pytest.mark.parametrize("case", ROLE_SPLIT_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_f16x3_winograd_role_split_and_lockstep_schedules_agree(ops, dev, case, monkeypatch):
+    """The F(2,3) kernel has two schedules of the same arithmetic: the default role-split one (conv3d_f16x3_wino_pp.hip: the two waves of a
+    SIMD alternate MFMA and load segments, the K loop walks 8-channel chunks) and the lockstep one it replaced (MPHIP_WINO_PP=0).  They
+    sum in a different order, so they are not bitwise equal; both must be fp32-class against float64 and agree with each other to that
+    class — full launches, split-K launches (2x96x96@4x8x8: 6 splits), a single 16-channel period, multi-frame fused GroupNorm + ReLU
+    inputs (the per-frame table is reloaded by LDS-DMA), and the GroupNorm statistics the epilogue leaves."""
+    N, Ci, Co, D, H, W = case
+    monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")     # (the kernel wherever its tiling applies, also below a full chip)
+    x = R.seeded_tensor((N, Ci, D, H, W), 441, scale=1.7)
+    wt = R.seeded_tensor((Co, Ci, 3, 3, 3), 442, scale=(Ci * 27) ** -0.5)
+    bias = R.seeded_tensor((Co,), 443, scale=0.1)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    truth = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    g, be = R.seeded_tensor((Ci,), 444, scale=0.3) + 1.0, R.seeded_tensor((Ci,), 445, scale=0.2)
+    groups = 32 if Ci % 32 == 0 else 16
+    truth_gn = F.conv3d(F.relu(F.group_norm(x.double(), groups, g.double(), be.double(), 1e-5)), wt.double(), bias.double(), padding=1)
+    xd = x.to(dev)
+    st_in = ops.groupnorm_stats(xd, groups)
+    out = {}
+    for pp in ("1", "0"):
+        monkeypatch.setenv("MPHIP_WINO_PP", pp)
+        y, st = ops.conv3d(xd, pc, precision=1, gn_groups=32)
+        out[pp] = (y, st, ops.conv3d_gn_in(xd, st_in, g.to(dev), be.to(dev), groups, pc))
+    monkeypatch.delenv("MPHIP_WINO_PP")
+    e32 = maxabs(ops.conv3d(xd, pc, precision=0), truth)
+    for pp in ("1", "0"):
+        assert maxabs(out[pp][0], truth) < 2 * e32 + 1e-6, pp
+        assert maxabs(out[pp][2], truth_gn) < 1e-5, pp
+    scale = truth.abs().max().item()
+    assert maxabs(out["1"][0], out["0"][0].cpu().double()) < 4e-6 * max(scale, 1.0)
+    assert maxabs(out["1"][1], out["0"][1].cpu().double()) < 1e-5
+    assert maxabs(out["1"][2], out["0"][2].cpu().double()) < 4e-6 * max(truth_gn.abs().max().item(), 1.0)
+
+
 def test_conv3d_f16x3_winograd_propagates_non_finite(ops, _libmod, dev):
     """test_f16x3_propagates_non_finite at a shape the F(2,3) kernel takes: a NaN / Inf input poisons exactly the output voxels the
     reference's fp32 conv poisons (the transform mixes x[w-1..w+2] into one output pair, but a pair's two outputs use different

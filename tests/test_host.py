@@ -189,7 +189,7 @@ def test_hot_kernels_have_no_scratch():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import register_table
 
-    table = register_table.collect(["conv3d_f16x3_wino.hip", "conv3d_f16x3.hip", "conv3d_bwd_f16x3.hip", "warp.hip"])
+    table = register_table.collect(["conv3d_f16x3_wino.hip", "conv3d_f16x3_wino_pp.hip", "conv3d_f16x3.hip", "conv3d_bwd_f16x3.hip", "warp.hip"])
     kernels = {k["demangled"]: k for t in table.values() for k in t["kernels"]}
     hot = [n for n in kernels if any(s in n for s in ("conv3d_k3_f16x3_wino_kernel", "conv3d_k3_f16x3_kernel", "conv3d_k3_f16x3_third_kernel",
                                                        "conv3d_k1_f16x3_kernel", "conv_bwd_weight_f16x3_kernel", "conv_bwd_weight_k1_f16x3_kernel",
@@ -202,5 +202,49 @@ def test_hot_kernels_have_no_scratch():
             assert scratch <= 256, (n, scratch)
         else:
             assert scratch == 0 and kernels[n].get("vgpr_spill_count", 0) == 0, (n, kernels[n])
-    wino = next(k for n, k in kernels.items() if "conv3d_k3_f16x3_wino_kernel" in n)
-    assert wino["group_segment_fixed_size"] <= 160 * 1024 and wino["vgpr_count"] <= 256
+    for name in ("conv3d_k3_f16x3_wino_kernel", "conv3d_k3_f16x3_wino_pp_kernel"):
+        wino = next(k for n, k in kernels.items() if name in n)
+        assert wino["group_segment_fixed_size"] <= 160 * 1024 and wino["vgpr_count"] <= 256
+
+
+def test_role_split_conv_hand_issued_memory_ops_are_padded_and_unspilled(monkeypatch):
+    """conv3d_f16x3_wino_pp.hip issues its halo loads and LDS-DMA pieces as inline assembly and orders them with its own counted
+    s_waitcnt: hipcc neither pads hazards inside an asm string nor knows that a destination register is still in flight.
+    What the source promises is checked on the disassembly (no GPU needed): (1) every hand-issued vector-memory group opens with
+    `s_nop 4` (its scalar operands may come straight from a v_readlane spill reload: VALU-written SGPR -> VMEM needs 5 wait states);
+    (2) no register of the kernel is spilled and no scratch is used (a spill of an in-flight destination would save garbage);
+    (3) a halo-load destination is written by exactly one load site per team instantiation and never the source of a compiler copy."""
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    monkeypatch.setenv("MPHIP_KEEP_ASM", "1")
+    import register_table
+
+    t = register_table.one(os.path.join(register_table.CSRC, "conv3d_f16x3_wino_pp.hip"))
+    k = next(k for k in t["kernels"] if "wino_pp_kernel" in k["name"])
+    assert k.get("vgpr_spill_count", 0) == 0 and k.get("private_segment_fixed_size", 0) == 0, k
+    asm = t["asm"]
+    body = asm[asm.index("wino_pp_kernel"):]
+    blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, flags=re.S)
+    vmem = [b for b in blocks if "buffer_load" in b or "global_load_lds" in b]
+    assert len(vmem) >= 2 * (3 + 9 + 2), len(vmem)          # per team: three halo-load groups, a DMA group per step, the prologue's
+    for b in vmem:
+        first = [ln.strip() for ln in b.splitlines() if ln.strip()][0]
+        assert first == "s_nop 4", b
+    # the halo loads' destinations: registers named by buffer_load lines inside the tile loop (after the prologue's), per team
+    dests = re.findall(r"buffer_load_dword(?:x4)? (v\[\d+:\d+\]|v\d+),", body)
+    assert len(dests) == 2 * 2 * 8                              # prologue + loop, two teams, eight loads a unit
+    regs = set()
+    for d in dests:
+        m = re.match(r"v\[(\d+):(\d+)\]", d)
+        regs |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(d[1:])}
+    copies = [ln for ln in body.splitlines() if re.match(r"\s+v_(mov_b32|mov_b64|pk_mov_b32|accvgpr_write)", ln) and
+              any(re.search(r", v%d$" % r, ln.strip()) or re.search(r", v\[%d:" % r, ln) for r in regs)]
+    # (the prologue reuses low registers for its own unit; a copy FROM a loop destination register would be a copy of data in flight)
+    loop_dest = set()
+    for d in dests[8:16] + dests[24:32]:
+        m = re.match(r"v\[(\d+):(\d+)\]", d)
+        loop_dest |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(d[1:])}
+    bad = [ln for ln in copies if any(re.search(r", v%d$" % r, ln.strip()) for r in loop_dest)]
+    assert not bad, bad[:5]

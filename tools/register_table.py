@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "megaportrait-hack_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-S", "--cuda-device-only", "-o", "-"]
+EXTRA = {"conv3d_f16x3_wino_pp.hip": ["-fno-slp-vectorize"]}   # (mirrors csrc/build.sh)
 KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size",
         ".group_segment_fixed_size", ".max_flat_workgroup_size")
 
@@ -32,7 +33,7 @@ def demangle(names):
 
 
 def one(path):
-    asm = subprocess.run([HIPCC] + FLAGS + [path], capture_output=True, text=True)
+    asm = subprocess.run([HIPCC] + FLAGS + EXTRA.get(os.path.basename(path), []) + [path], capture_output=True, text=True)
     if asm.returncode != 0:
         raise RuntimeError(f"{path}: {asm.stderr[-2000:]}")
     kernels, cur = [], None
@@ -69,7 +70,7 @@ def one(path):
         kernels.append(k)
     for k, d in zip(kernels, demangle([k["name"] for k in kernels])):
         k["demangled"] = d
-    return {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "kernels": kernels}
+    return {"sha256": hashlib.sha256(open(path, "rb").read()).hexdigest(), "kernels": kernels, "asm": asm.stdout if os.environ.get("MPHIP_KEEP_ASM") else None}
 
 
 def collect(files=None):
