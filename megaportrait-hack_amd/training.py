@@ -209,10 +209,18 @@ class GraphedTrainStep:
     re-packing of the updated weights.  Everything on the path zero-fills with kernels, not hipMemsetAsync: memset
     nodes of a captured graph were not reliably ordered with the kernels around them on ROCm 7.2 (a replayed step
     went wrong in ~40 % of runs — stale f16x3 pack headers — until they were replaced; csrc/mphip_common.h).  Single-process only: a distributed step keeps the eager `train_step`
-    (collectives stay outside the graph)."""
+    (collectives stay outside the graph).
+
+    Ordering of the returned loss: on some boxes of the pool a read of the static loss issued on the launch stream right
+    behind `graph.replay()` returned the PREVIOUS replay's value (3 of ~20 runs in r03/r04; 0 of 140 with tools/repro_graph_loss.py in
+    r05) — stream order was not enough, a device-wide synchronize was: the replay's trailing nodes run on streams of the graph's own and
+    were seen to outlive the launch stream's completion marker.  `__call__` therefore waits for the DEVICE after the replay by default
+    (`sync_after_replay=True`: ~20 us on a step of several ms) and returns a private copy of the loss, so that `.item()`, logging or a
+    later replay cannot observe a half-written or overwritten buffer.  Pass `sync_after_replay=False` to pipeline replays and
+    synchronize yourself before reading."""
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
-                 example_inputs: Dict[str, torch.Tensor], warmup: int = 3):
+                 example_inputs: Dict[str, torch.Tensor], warmup: int = 3, sync_after_replay: bool = True):
         import copy
 
         from . import ops
@@ -222,6 +230,7 @@ class GraphedTrainStep:
                 raise ValueError(f"GraphedTrainStep: {type(optimizer).__name__} must be built with capturable=True to be "
                                  "captured in a hipGraph (its step counters live on the host otherwise); SGD works as is")
         self.model, self.optimizer = model, optimizer
+        self.sync_after_replay = sync_after_replay
         self.static_in = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in example_inputs.items()}
         # the warm-up runs REAL steps (the allocator and the packed-weight caches must see the final shapes): parameters,
         # buffers and optimizer state are snapshotted and restored, so building the graph does not train the model
@@ -270,4 +279,7 @@ class GraphedTrainStep:
                     self.static_in[k].copy_(v)
         self.graph.replay()
         ops.invalidate_packs()  # the replay rewrote the parameters without touching their version counters
+        if self.sync_after_replay:
+            torch.cuda.synchronize()        # (see the class docstring: stream order alone did not cover the replay's trailing nodes)
+            return self.static_loss.detach().clone()
         return self.static_loss

@@ -320,7 +320,7 @@ def _check_param_grads(named_params, ref_grad, tol, flip_ok=False):
         if err >= (tol(n) if callable(tol) else tol):
             # (end-to-end tests: `flip_ok` — an isolated ReLU flip moves a few elements by up to ~1e-2 of the maximum but leaves the
             #  tensor's L2 error tiny; see _fp64_truth_and_movement)
-            if flip_ok and err < 2e-2 and diff.norm().item() <= 1e-3 * max(g.double().norm().item(), 1e-300):
+            if (flip_ok(n) if callable(flip_ok) else flip_ok) and err < 2e-2 and diff.norm().item() <= 1e-3 * max(g.double().norm().item(), 1e-300):
                 continue
             bad.append((err, n, g.abs().max().item()))
     assert not bad, sorted(bad, reverse=True)[:6]
@@ -402,7 +402,39 @@ def test_hot_slice_backward(dev, M):
     for k in inp:
         assert _close_or_flip(gpu_in[k].grad, cpu_in[k].grad, 2e-3 + 2 * mov_in[k]), (k, rel_err(gpu_in[k].grad, cpu_in[k].grad), mov_in[k])
     assert sorted(mov_sd.values())[len(mov_sd) // 2] < 1e-3, "the truth's typical movement must stay below the bar"
-    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, lambda n: 2e-3 + 2 * mov_sd.get(n, 0.0), flip_ok=True)
+    # (the isolated-flip allowance only where the truth ITSELF is seen to move — a tensor no perturbation sample moves by 1e-4 holds the plain bar)
+    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, lambda n: 2e-3 + 2 * mov_sd.get(n, 0.0), flip_ok=lambda n: mov_sd.get(n, 0.0) > 1e-4)
+
+
+QUIET_SEEDS = {(8, 16, 16): 102}   # tools/find_quiet_seed.py: no gradient tensor of the float64 truth moves by more than 2e-5 under six perturbation samples
+
+
+@pytest.mark.parametrize("size", sorted(QUIET_SEEDS), ids=lambda t: "x".join(map(str, t)))
+@pytest.mark.parametrize("winograd", ["1", "0"], ids=["F(2,3) kernels", "direct kernels"])
+def test_hot_slice_backward_strict_on_a_quiet_seed(dev, M, monkeypatch, winograd, size):
+    """The strict end-to-end gate: on an input whose float64 gradients do not move under fp32-rounding-sized perturbations
+    (no ReLU pre-activation close enough to zero to flip: tools/find_quiet_seed.py), EVERY input and parameter gradient of the whole hot
+    slice must be within the plain 2e-3 of the float64 truth — no movement term, no isolated-flip allowance — with the F(2,3) conv
+    kernels and with the direct ones (MPHIP_WINOGRAD=0), so that both conv families are graded end to end."""
+    (D, H, W), seed = size, QUIET_SEEDS[size]
+    monkeypatch.setenv("MPHIP_WINOGRAD", winograd)
+    monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")          # (the F(2,3) kernels wherever their tiling applies at this small size)
+    sd = R.seeded_gbase_hot_state_dict(7)
+    hot = M.GbaseHotSlice()
+    M.load_hot_state_dict(hot, sd)
+    hot = hot.to(dev).train()
+    inp = R.seeded_hot_inputs(1, seed, D=D, H=H, W=W)
+    out_ref, cpu_in, cpu_sd, mov_in, mov_sd = _fp64_truth_and_movement(sd, inp, 92, samples=((1e-6, 1), (2e-6, 2), (2e-6, 3), (5e-6, 4), (5e-6, 5), (1e-5, 6)))
+    quiet = max(list(mov_in.values()) + [m for n, m in mov_sd.items() if not n.endswith(".bias")])
+    assert quiet < 1e-4, ("the seed is not quiet any more (oracle or fixture generator changed?)", quiet)
+    dout = R.seeded_tensor(tuple(out_ref.shape), 92)
+    gpu_in = {k: v.to(dev).requires_grad_(True) for k, v in inp.items()}
+    out = hot.forward_any_size(**gpu_in)
+    assert rel_err(out, out_ref) < 1e-4
+    out.backward(dout.to(dev))
+    for k in inp:
+        assert rel_err(gpu_in[k].grad, cpu_in[k].grad) < 2e-3, (k, rel_err(gpu_in[k].grad, cpu_in[k].grad))
+    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, 2e-3, flip_ok=False)
 
 
 def test_hot_slice_backward_is_bitwise_reproducible(dev, M):
@@ -488,7 +520,7 @@ def test_config3_train_step_full_size(dev, M):
     for k in inp:
         assert _close_or_flip(gpu_in[k].grad, cpu_in[k].grad, 2e-3 + 2 * mov_in[k]), (k, rel_err(gpu_in[k].grad, cpu_in[k].grad), mov_in[k])
     assert sorted(movement.values())[len(movement) // 2] < 1e-4, "the truth's typical movement must stay far below the bar"
-    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, lambda n: 2e-3 + 2 * movement.get(n, 0.0), flip_ok=True)
+    _check_param_grads(hot.named_parameters(), lambda n: cpu_sd[n].grad, lambda n: 2e-3 + 2 * movement.get(n, 0.0), flip_ok=lambda n: movement.get(n, 0.0) > 1e-4)
 
 
 @pytest.mark.parametrize("precision", [1, 0])
@@ -578,9 +610,8 @@ def test_graphed_train_step_matches_eager(dev, M):
     for _ in range(3):
         le = training.train_step(eager, loss_fn, opt_e, {"x": x})
         lg = step(x=x)
-        # (device-wide sync before the static loss tensor is read: on some boxes of the pool the D2H read of a replayed graph's output
-        #  returned the previous replay's value — r03 and r04 builds alike, 3 of ~20 runs; the test is about the parameter walk)
-        torch.cuda.synchronize()
+        # (no synchronize here: GraphedTrainStep.__call__ orders the loss it returns itself — training.py; r03/r04 read the static buffer
+        #  right behind the replay and saw the previous replay's value on some boxes, 3 of ~20 runs; tools/repro_graph_loss.py loops this)
         losses.append((le.item(), lg.item()))
     for le, lg in losses:
         assert abs(le - lg) <= 1e-5 * abs(le), losses
@@ -590,8 +621,14 @@ def test_graphed_train_step_matches_eager(dev, M):
     for _ in range(4):
         lg = step(x=x)                 # replay first, eager kernels of the other model right behind it
         le = training.train_step(eager, loss_fn, opt_e, {"x": x})
-        torch.cuda.synchronize()
         assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item())
+    # the pipelined form: no wait inside __call__, the caller synchronizes before it reads the static buffer
+    step.sync_after_replay = False
+    lg = step(x=x)
+    le = training.train_step(eager, loss_fn, opt_e, {"x": x})
+    torch.cuda.synchronize()
+    assert lg.data_ptr() == step.static_loss.data_ptr() and abs(le.item() - lg.item()) <= 1e-5 * abs(le.item())
+    step.sync_after_replay = True
     with torch.no_grad():
         assert rel_err(graphed(x), eager(x).cpu()) < 1e-5
 
