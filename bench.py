@@ -470,9 +470,11 @@ def fp32_exact(hot, inp, B, steps=10, warmup=2):
             "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
 
 
-def train_leg(dev, B=4, steps=10, warmup=3):
+def train_leg(dev, B=4, steps=10, warmup=3, autocast=False):
     """BASELINE config 3's per-GPU shard on the default line: one training step of the hot slice (forward + backward + SGD,
-    eager launches) at B=4, 96x16x64x64.  Side measurement; `--mode train` is the full-featured version (hipGraph, N ranks)."""
+    eager launches) at B=4, 96x16x64x64.  Side measurement; `--mode train` is the full-featured version (hipGraph, N ranks).
+    autocast: the forward runs inside torch.autocast(float16) like the reference's generator step (train.py:145,188) — the F(2,3) convs
+    (forward and bwd-data) then use one f16 product per multiply (include/mphip.h: mphip_conv3d_set_half_products)."""
     import torch.nn.functional as F
 
     from megaportrait_hack_amd import model as M, training
@@ -487,7 +489,13 @@ def train_leg(dev, B=4, steps=10, warmup=3):
     inp = {k: v.to(dev) for k, v in inp.items()}
     inp["vs"].requires_grad_(True)
     tgt = torch.randn(B, 96, 64, 64, generator=g).to(dev)
-    loss_fn = lambda m, **kw: F.mse_loss(m(**kw), tgt)
+    if autocast:
+        def loss_fn(m, **kw):
+            with torch.autocast("cuda", dtype=torch.float16):
+                out = m(**kw)
+            return F.mse_loss(out.float(), tgt)
+    else:
+        loss_fn = lambda m, **kw: F.mse_loss(m(**kw), tgt)
     opt = torch.optim.SGD(hot.parameters(), lr=1e-5)
     for _ in range(warmup):
         loss = training.train_step(hot, loss_fn, opt, inp)
@@ -515,7 +523,8 @@ def train_leg(dev, B=4, steps=10, warmup=3):
             "launch": "one hipGraph per step (training.GraphedTrainStep)", "eager_ms_per_step": round(dt / steps * 1e3, 3),
             "workload": "GbaseHotSlice training step (forward + backward + SGD), BASELINE config 3's per-GPU shard; final_conv forward and "
                         "backward demand-driven (the final warp's sample boxes)",
-            "dtype": "f16x3 forward/backward convs, fp32 everything else"}
+            "dtype": ("autocast(float16) policy: one f16 product per multiply (fp32 accumulate) in the F(2,3) convs (forward, bwd-data), f16x3 in bwd-weight "
+                      "and the other convs, fp32 everything else") if autocast else "f16x3 forward/backward convs, fp32 everything else"}
 
 
 def train_mode(args, rank, world, dev, dist):
@@ -853,6 +862,7 @@ def main():
             if f16x3:
                 leg("fp32_exact", fp32_exact, hot, inp, B)
             leg("train_step", train_leg, dev)                                    # BASELINE config 3's per-GPU shard
+            leg("train_step_autocast", train_leg, dev, autocast=True)           # ... under the reference's autocast(float16) policy
             leg("reenact_1x64", reenact_leg, dev, repeats=2, find=False)         # BASELINE config 5's per-GPU shard
             leg("end_to_end", end_to_end, dev, B, steps=5, warmup=2)
             leg("end_to_end_autocast_fp16", end_to_end, dev, B, steps=5, warmup=2, fp16=True)

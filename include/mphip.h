@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 10
+#define MPHIP_ABI_VERSION 11
 int mphip_version(void);
 const char *mphip_last_error(void);
 
@@ -449,6 +449,15 @@ size_t mphip_g3d_workspace_bytes(mphip_hot_slice_plan *plan, int B);
 int mphip_g3d_forward(mphip_hot_slice_plan *plan, const float *x, const float *x_range, float *y, int B, void *workspace,
                       size_t workspace_bytes, void *stream);
 void mphip_hot_slice_plan_destroy(mphip_hot_slice_plan *plan);
+
+/* The reference's reduced-precision policy for the convs (train.py:145,188: the generator step runs under torch.cuda.amp.autocast(), its
+ * conv3d calls take f16 operands with fp32 accumulation).  mphip_conv3d_set_half_products(1) makes the CALLING THREAD's subsequent precision-1
+ * 3x3x3 launches that run in the F(2,3) domain (mphip_conv3d_kernel_variant == 5: G3d's levels 0-2, Eapp's 3-D tail, their bwd-data
+ * convs) use ONE f16 product per multiply — operands rounded to f16 (in the transformed domain), fp32 accumulate, a third of the matrix
+ * work; every other kernel keeps its fp32-class arithmetic (autocast permits more precision, never less).  The flag is thread-local, read
+ * when a launch is issued, and returns its previous value; the Python host sets it only while torch.is_autocast_enabled() with float16.
+ * Results then carry f16-operand rounding (~1e-3 relative), NOT the 1e-3 max-abs fp32 contract of the default mode.                  */
+int mphip_conv3d_set_half_products(int enable);
 
 /* Diagnostic (synchronous, not stream-ordered): operand elements of the f16x3 conv kernels whose scaled value was outside
  * the f16 range since the last reset — Inf/NaN inputs, or finite values beyond a wrong caller-supplied range descriptor.

@@ -79,6 +79,7 @@ SIGNATURES = {
     "mphip_warp_field_compose_bwd": (_i, [_p] * 4 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_rt_theta_bwd": (_i, [_p] * 5 + [_i, _i, _p]),
     "mphip_f16x3_saturation_count": (_i, [_p, _i]),
+    "mphip_conv3d_set_half_products": (_i, [_i]),
     "mphip_avgpool2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p]),
     "mphip_upsample_trilinear2_bwd_workspace_bytes": (_sz, [_i] * 4),
     "mphip_upsample_trilinear2_bwd": (_i, [_p, _p, _i, _i, _i, _i, _p, _sz, _p]),
@@ -120,7 +121,7 @@ _lib = None
 # The ABI version the SIGNATURES table above mirrors.  Checked against the library at load time, and against include/mphip.h by
 # tests/test_host.py — NOT read from the header at run time: a relocated / installed package ships libmphip.so without the repository's
 # include/ directory.
-EXPECTED_ABI_VERSION = 10
+EXPECTED_ABI_VERSION = 11
 
 
 def header_abi_version() -> int:

@@ -49,6 +49,7 @@ class Conv3dFn(torch.autograd.Function):
         y = ops.conv3d(x, fwd_pack) if roi is None else ops.conv3d_roi(x, fwd_pack, roi)
         ctx.roi = roi
         ctx.x_range = ops.tensor_range(x)   # the f16x3 operand scale the forward used for x: bwd-weight reuses it
+        ctx.half = ops.autocast_half()      # the forward ran under the autocast policy: its bwd-data conv does too (backward runs on autograd's thread)
         return y
 
     @staticmethod
@@ -64,7 +65,8 @@ class Conv3dFn(torch.autograd.Function):
         # ctx.roi: the forward was demand-driven for a gather — that gather's gradient dy is exactly zero outside the same boxes
         # (mphip_warp_volume_bwd zero-fills, then writes the cells the samples touch), so both products are restricted to them
         if ctx.needs_input_grad[0]:
-            dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale, roi=ctx.roi)
+            with ops.half_products(ctx.half):
+                dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale, roi=ctx.roi)
         if ctx.needs_input_grad[1]:
             dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range, roi=ctx.roi).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
         return dx, dw, db, None, None, None

@@ -14,6 +14,18 @@ void set_error(const char *fmt, ...) {
 }
 }  // namespace mphip
 
+namespace mphip {
+// conv arithmetic policy of the calling thread (mphip_conv3d_set_half_products): a launch reads it when it is issued
+static thread_local int g_half_products = 0;
+bool conv_half_products() { return g_half_products != 0; }
+}  // namespace mphip
+
+extern "C" int mphip_conv3d_set_half_products(int enable) {
+    const int prev = mphip::g_half_products;
+    mphip::g_half_products = enable ? 1 : 0;
+    return prev;
+}
+
 extern "C" int mphip_version(void) { return MPHIP_ABI_VERSION; }
 extern "C" const char *mphip_last_error(void) { return mphip::g_err; }
 

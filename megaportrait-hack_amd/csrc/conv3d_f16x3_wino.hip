@@ -701,7 +701,7 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
     const bool pp_on = !(pp_env && pp_env[0] == '0');
     if (pp_on) {   // the role-split schedule (conv3d_f16x3_wino_pp.hip): same arithmetic, same packed weights, same tile
         f16x3_wino_pp_launch(grid, s, t0, t1, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb, in_affine, in_relu, x_range,
-                             tiles, xcd_on, tile_list, gn_part);
+                             tiles, xcd_on, tile_list, gn_part, conv_half_products());
         return check_launch("conv3d_fwd(f16x3, F(2,3), role-split)");
     }
     if (t0 && t1)

@@ -159,6 +159,9 @@ struct PpPeriod {   // what a 16-channel period of the K stream addresses (wave-
     int n, d0, h0, w0, chunk, tj;
 };
 
+// SINGLE: the reference's autocast(float16) policy for these convs (train.py:145,188) — ONE f16 product per multiply (the hi halves only:
+// operands rounded to f16 in the transformed domain, fp32 accumulation), a third of the MFMAs; everything else unchanged.
+template <bool SINGLE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                                const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
@@ -316,20 +319,23 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
         float l0[4], l1[4];
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) hv[pp] = pp_cvt_pk(t0[pp], t1[pp]);
+        if constexpr (!SINGLE) {
 #pragma unroll
-        for (int pp = 0; pp < 4; ++pp) {
-            l0[pp] = pp_sub_lo(hv[pp], t0[pp]);
-            l1[pp] = pp_sub_hi(hv[pp], t1[pp]);
+            for (int pp = 0; pp < 4; ++pp) {
+                l0[pp] = pp_sub_lo(hv[pp], t0[pp]);
+                l1[pp] = pp_sub_hi(hv[pp], t1[pp]);
+            }
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) lv[pp] = pp_cvt_pk(l0[pp], l1[pp]);
         }
-#pragma unroll
-        for (int pp = 0; pp < 4; ++pp) lv[pp] = pp_cvt_pk(l0[pp], l1[pp]);
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
 #if PP_ABL & 128   /* timing only: the arithmetic without the LDS stores */
-            asm volatile("" ::"v"(hv[pp]), "v"(lv[pp]));
+            asm volatile("" ::"v"(hv[pp]));
+            if constexpr (!SINGLE) asm volatile("" ::"v"(lv[pp]));
 #else
             *reinterpret_cast<unsigned *>(xw + pp * PP_XPOS_B + q * 16) = hv[pp];
-            *reinterpret_cast<unsigned *>(xw + PP_XPART_B + pp * PP_XPOS_B + q * 16) = lv[pp];
+            if constexpr (!SINGLE) *reinterpret_cast<unsigned *>(xw + PP_XPART_B + pp * PP_XPOS_B + q * 16) = lv[pp];
 #endif
         }
     };
@@ -474,14 +480,16 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         ah[m] = *reinterpret_cast<const half8 *>(wsl + m * 512);
-                        al[m] = *reinterpret_cast<const half8 *>(wsl + PP_WPART_B + m * 512);
+                        if constexpr (!SINGLE) al[m] = *reinterpret_cast<const half8 *>(wsl + PP_WPART_B + m * 512);
                     }
                     static_assert(off1 - off0 == 64 || off1 - off0 == 512 || off1 - off0 == PP_XBUF_B - pp_rowoff(8) * 64, "k-group distance");
                     const unsigned char *const xb = smem + (off1 - off0 == 64 ? b_row : off1 - off0 == 512 ? b_plane : b_buf) + off0;
                     bh[0] = *reinterpret_cast<const half8 *>(xb);
                     bh[1] = *reinterpret_cast<const half8 *>(xb + PP_HH * 64);
-                    bl[0] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B);
-                    bl[1] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B + PP_HH * 64);
+                    if constexpr (!SINGLE) {
+                        bl[0] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B);
+                        bl[1] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B + PP_HH * 64);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // Halo staging, one slice per LOAD phase.  In the team's own count ts (A: ts = step; B starts at step 4: ts = step - 4 mod 9):
@@ -547,18 +555,22 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
 #if PP_ABL & 16
                 asm volatile("" ::"v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(al[0]), "v"(al[1]), "v"(al[2]), "v"(bl[0]), "v"(bl[1]), "v"(bh[0]), "v"(bh[1]));
 #else
+                if constexpr (!SINGLE) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+                    for (int m = 0; m < 3; ++m)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
+                }
 #pragma unroll
                 for (int m = 0; m < 3; ++m)
 #pragma unroll
                     for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[t], acc[m][t], 0, 0, 0);
+                if constexpr (!SINGLE) {
 #pragma unroll
-                for (int m = 0; m < 3; ++m)
+                    for (int m = 0; m < 3; ++m)
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
+                        for (int t = 0; t < 2; ++t) acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
+                }
 #endif
 #if PP_PRIO == 1
                 __builtin_amdgcn_s_setprio(0);
@@ -735,13 +747,18 @@ int f16x3_wino_pp_saturation(unsigned long long *count, int reset) {
 void f16x3_wino_pp_launch(dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1, const float *x, const _Float16 *slabs, const float *hdr,
                           const float *bias, float *dst, int N, int Ci, int Co, int D, int H, int W, int cps, unsigned xb,
                           const float *in_affine, int in_relu, const float *x_range, int tiles, int xcd_on, const int *tile_list,
-                          float *gn_part) {
-    if (t0 && t1)
-        hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_pp_kernel, grid, dim3(512), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W,
-                              cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
-    else
-        hipLaunchKernelGGL(conv3d_k3_f16x3_wino_pp_kernel, grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb,
-                           in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
+                          float *gn_part, bool half_products) {
+#define PP_LAUNCH(S_)                                                                                                                    \
+    {                                                                                                                                    \
+        if (t0 && t1)                                                                                                                    \
+            hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_pp_kernel<S_>, grid, dim3(512), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, \
+                                  H, W, cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                        \
+        else                                                                                                                             \
+            hipLaunchKernelGGL(conv3d_k3_f16x3_wino_pp_kernel<S_>, grid, dim3(512), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps,    \
+                               xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                                      \
+    }
+    if (half_products) PP_LAUNCH(true) else PP_LAUNCH(false)
+#undef PP_LAUNCH
 }
 
 }  // namespace mphip

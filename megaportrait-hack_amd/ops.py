@@ -284,6 +284,31 @@ def get_conv_precision() -> int:
     return _default_precision
 
 
+def autocast_half() -> bool:
+    """True inside a torch.autocast(device_type='cuda', dtype=torch.float16) region — the reference's generator step (train.py:145,188)."""
+    try:
+        return bool(torch.is_autocast_enabled("cuda")) and torch.get_autocast_dtype("cuda") == torch.float16
+    except TypeError:   # older torch: no device argument
+        return bool(torch.is_autocast_enabled()) and torch.get_autocast_gpu_dtype() == torch.float16
+
+
+class half_products:
+    """Context manager: the calling thread's F(2,3) conv launches use ONE f16 product per multiply (include/mphip.h:
+    mphip_conv3d_set_half_products) — the arithmetic torch.autocast(float16) gives the reference's conv3d calls.  The flag is
+    thread-local in the library; nesting restores the previous value.  `enable=None`: follow torch's autocast state."""
+
+    def __init__(self, enable: Optional[bool] = None):
+        self.enable = autocast_half() if enable is None else bool(enable)
+
+    def __enter__(self):
+        self.prev = _lib.load().mphip_conv3d_set_half_products(int(self.enable))
+        return self
+
+    def __exit__(self, *exc):
+        _lib.load().mphip_conv3d_set_half_products(self.prev)
+        return False
+
+
 def f16x3_saturation_count(reset: bool = False) -> int:
     """Operand elements of the f16x3 conv kernels whose scaled value was outside the f16 range since the last reset: Inf /
     NaN inputs (or finite values beyond a stale, hand-supplied range descriptor).  They are not clamped — the result

@@ -34,6 +34,23 @@ SD = Dict[str, torch.Tensor]
 
 
 # --------------------------------------------------------------------------- a6
+# Every conv of the restatement goes through CONV3D (default: ATen's conv3d).  Tests of the autocast policy (the reference's generator step
+# runs under torch.cuda.amp.autocast(): conv3d on f16 operands, fp32 accumulate — train.py:145,188) swap in a conv that rounds its
+# operands the way that policy does; the product never imports this module.
+CONV3D = F.conv3d
+
+
+def _conv3d(*args, **kwargs):
+    return CONV3D(*args, **kwargs)
+
+
+def conv3d_f16_operands(x, w, b=None, padding=0):
+    """conv3d with input and weight rounded to float16 and the products accumulated exactly (float64): the arithmetic contract of an
+    autocast(float16) conv3d, without any implementation's accumulation order."""
+    y = F.conv3d(x.detach().half().double(), w.detach().half().double(), None if b is None else b.detach().double(), padding=padding)
+    return y
+
+
 def rotation_matrix(rotation_deg: torch.Tensor) -> torch.Tensor:
     """model.py:811-856 — Euler degrees (alpha,beta,gamma)=(x,y,z) -> R = Rx @ (Ry @ Rz)."""
     r = rotation_deg * (torch.pi / 180.0)
@@ -79,12 +96,12 @@ def adaptive_group_norm(x, sd: SD, prefix: str) -> torch.Tensor:
 
 def resblock3d_adaptive(x, sd: SD, prefix: str) -> torch.Tensor:
     """model.py:385-408 (upsample flag never set on the hot path)."""
-    out = F.conv3d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding=1)
+    out = _conv3d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding=1)
     out = F.relu(adaptive_group_norm(out, sd, prefix + "norm1."))
-    out = F.conv3d(out, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding=1)
+    out = _conv3d(out, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding=1)
     out = adaptive_group_norm(out, sd, prefix + "norm2.")
     if (prefix + "residual_conv.weight") in sd:
-        res = F.conv3d(x, sd[prefix + "residual_conv.weight"], sd[prefix + "residual_conv.bias"])
+        res = _conv3d(x, sd[prefix + "residual_conv.weight"], sd[prefix + "residual_conv.bias"])
     else:
         res = x
     return F.relu(out + res)
@@ -102,7 +119,7 @@ def flowfield(zs_sum: torch.Tensor, sd: SD, prefix: str) -> torch.Tensor:
     for k, up in enumerate(_FLOW_UPS, start=1):
         x = resblock3d_adaptive(x, sd, f"{prefix}resblock{k}.")
         x = F.interpolate(x, scale_factor=up, mode="nearest")  # nn.Upsample default mode
-    x = F.conv3d(x, sd[prefix + "conv3x3x3.weight"], sd[prefix + "conv3x3x3.bias"], padding=1)
+    x = _conv3d(x, sd[prefix + "conv3x3x3.weight"], sd[prefix + "conv3x3x3.bias"], padding=1)
     x = F.group_norm(x, 1, sd[prefix + "gn.weight"], sd[prefix + "gn.bias"], 1e-5)
     return torch.tanh(F.relu(x))
 
@@ -167,12 +184,12 @@ def depth_projection(v: torch.Tensor) -> torch.Tensor:
 def resblock3d(x, sd: SD, prefix: str) -> torch.Tensor:
     """model.py:512-528."""
     if (prefix + "shortcut.weight") in sd:
-        identity = F.conv3d(x, sd[prefix + "shortcut.weight"], sd[prefix + "shortcut.bias"])
+        identity = _conv3d(x, sd[prefix + "shortcut.weight"], sd[prefix + "shortcut.bias"])
     else:
         identity = x
-    out = F.conv3d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding=1)
+    out = _conv3d(x, sd[prefix + "conv1.weight"], sd[prefix + "conv1.bias"], padding=1)
     out = F.relu(F.group_norm(out, 32, sd[prefix + "gn1.weight"], sd[prefix + "gn1.bias"], 1e-5))
-    out = F.conv3d(out, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding=1)
+    out = _conv3d(out, sd[prefix + "conv2.weight"], sd[prefix + "conv2.bias"], padding=1)
     out = F.group_norm(out, 32, sd[prefix + "gn2.weight"], sd[prefix + "gn2.bias"], 1e-5)
     return F.relu(out + identity)
 
@@ -192,7 +209,7 @@ def g3d(x, sd: SD, prefix: str = "G3d.") -> torch.Tensor:
     x = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
     x = resblock3d(x, sd, prefix + "upsampling.4.")
     x = F.interpolate(x, scale_factor=2, mode="trilinear", align_corners=True)
-    return F.conv3d(x, sd[prefix + "final_conv.weight"], sd[prefix + "final_conv.bias"], padding=1)
+    return _conv3d(x, sd[prefix + "final_conv.weight"], sd[prefix + "final_conv.bias"], padding=1)
 
 
 # --------------------------------------------------------------------------- f3 (next row)

@@ -332,6 +332,89 @@ def test_conv3d_f16x3_winograd_role_split_and_lockstep_schedules_agree(ops, dev,
     assert maxabs(out["1"][2], out["0"][2].cpu().double()) < 4e-6 * max(truth_gn.abs().max().item(), 1.0)
 
 
+HALF_CASES = [(1, 96, 96, 16, 64, 64), (8, 192, 192, 8, 32, 32), (2, 96, 192, 8, 32, 32)]
+
+
+@pytest.mark.parametrize("case", HALF_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_half_products_follow_the_autocast_contract(ops, _libmod, dev, case, monkeypatch):
+    """The reference's generator step runs under torch.cuda.amp.autocast() (train.py:145,188): conv3d multiplies f16 operands and
+    accumulates in fp32.  ops.half_products() switches the F(2,3) conv launches to that policy — ONE f16 product per multiply (the
+    transformed operands rounded to f16).  Oracle: oracle.hotpath_ref.conv3d_f16_operands (input and weight rounded to f16, exact
+    accumulation).  Bar, stated against THAT oracle (not the fp32 contract's 1e-3 max-abs): 3e-3 of max|y| — the kernel rounds t = Bx
+    and u = Gg instead of x and g (each f16-rounded once, like the oracle's operands), which moves an output by a few f16 ulps of the
+    operand scale, the distance two correct f16 implementations of one conv (direct vs Winograd, as cuDNN / MIOpen pick them) have; the
+    fp32-class result must be much closer to the float64 truth than either.  Outside the context nothing changes (bitwise), forward
+    and bwd-data."""
+    N, Ci, Co, D, H, W = case
+    monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
+    lib = _libmod.load()
+    assert lib.mphip_conv3d_kernel_variant(N, Ci, Co, D, H, W, 3, 1) == 5
+    x = R.seeded_tensor((N, Ci, D, H, W), 451, scale=1.7)
+    wt = R.seeded_tensor((Co, Ci, 3, 3, 3), 452, scale=(Ci * 27) ** -0.5)
+    bias = R.seeded_tensor((Co,), 453, scale=0.1)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    xd = x.to(dev)
+    truth = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    want = R.conv3d_f16_operands(x, wt, bias, padding=1)
+    full = ops.conv3d(xd, pc, precision=1)
+    with ops.half_products(True):
+        half = ops.conv3d(xd, pc, precision=1)
+    again = ops.conv3d(xd, pc, precision=1)
+    scale = truth.abs().max().item()
+    e_half, e_full, e_oracle = maxabs(half, want) / scale, maxabs(full, truth) / scale, maxabs(want, truth) / scale
+    print(f"relative to max|y|: half products vs f16-operand oracle {e_half:.2e}; f16-operand oracle vs fp64 {e_oracle:.2e}; f16x3 vs fp64 {e_full:.2e}")
+    assert torch.equal(full, again)                      # the flag is scoped
+    assert e_half < 3e-3 and e_full < 1e-5 and not torch.equal(half, full)
+    assert maxabs(half, truth) / scale < 2 * e_oracle + 3e-3
+    # bwd-data is the same kernel on the transposed pack
+    if lib.mphip_conv3d_kernel_variant(N, Co, Ci, D, H, W, 3, 1) == 5:
+        dy = R.seeded_tensor((N, Co, D, H, W), 454, scale=3e-3)
+        wt_t = wt.flip(2, 3, 4).transpose(0, 1).contiguous()
+        _, sc = ops.grad_prep(dy.to(dev), want_bias=False)
+        pct = ops.PackedConv(wt.to(dev), None, transposed=True)
+        with ops.half_products(True):
+            dx = ops.conv3d_bwd_data(dy.to(dev), pct, sc)
+        want_dx = R.conv3d_f16_operands(dy, wt_t, None, padding=1)
+        assert maxabs(dx, want_dx) / want_dx.abs().max().item() < 3e-3
+
+
+def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
+    """model.G3d inside torch.autocast(float16) runs its F(2,3) convs with f16 operands (the reference's policy), everything else — and
+    everything outside the region — as before.  Oracle: the restatement's G3d with conv3d_f16_operands on exactly the layers the library
+    reports the F(2,3) kernel for.  Bar: 1e-2 of max|y| against that oracle through the 15 stacked convs (each GroupNorm renormalises; a
+    wrong layer shows at >= 1e-1), and the region must actually change the result."""
+    from megaportrait_hack_amd import model as M
+
+    monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
+    lib = _libmod.load()
+    g = M.G3d(96)
+    sd = R.seeded_state_dict(R.g3d_shapes(96), 461, prefix="G3d.")
+    g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+    g = g.to(dev).eval()
+    x = R.seeded_tensor((2, 96, 16, 32, 32), 462)
+
+    def conv(xx, w, b=None, padding=0):
+        n, ci, d, h, ww = xx.shape
+        if w.shape[2] == 3 and lib.mphip_conv3d_kernel_variant(n, ci, w.shape[0], d, h, ww, 3, 1) == 5:
+            return R.conv3d_f16_operands(xx, w, b, padding=padding).to(xx.dtype)
+        return F.conv3d(xx, w, b, padding=padding)
+
+    monkeypatch.setattr(R, "CONV3D", conv)
+    want = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
+    monkeypatch.setattr(R, "CONV3D", F.conv3d)
+    truth = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
+    with torch.no_grad():
+        plain = g(x.to(dev))
+        with torch.autocast("cuda", dtype=torch.float16):
+            half = g(x.to(dev))
+        plain2 = g(x.to(dev))
+    scale = truth.abs().max().item()
+    print(f"relative to max|y|: autocast G3d vs policy oracle {maxabs(half, want) / scale:.2e}; policy oracle vs fp64 {maxabs(want, truth) / scale:.2e}; default vs fp64 {maxabs(plain, truth) / scale:.2e}")
+    assert half.dtype == torch.float32 and torch.equal(plain, plain2)
+    assert maxabs(plain, truth) / scale < 1e-4
+    assert maxabs(half, want) / scale < 1e-2 and not torch.equal(half, plain)
+
+
 def test_conv3d_f16x3_winograd_propagates_non_finite(ops, _libmod, dev):
     """test_f16x3_propagates_non_finite at a shape the F(2,3) kernel takes: a NaN / Inf input poisons exactly the output voxels the
     reference's fp32 conv poisons (the transform mixes x[w-1..w+2] into one output pair, but a pair's two outputs use different

@@ -113,6 +113,19 @@ def test_checkpoint_loading_quirks():
         M.load_hot_state_dict(M.GbaseHotSlice(), {k: v for k, v in sd.items() if "final_conv" not in k})
 
 
+def test_half_products_flag_is_thread_local(lib):
+    """mphip_conv3d_set_half_products (the autocast policy switch) returns the previous value and is per thread."""
+    import threading
+
+    assert lib.mphip_conv3d_set_half_products(1) == 0
+    seen = []
+    t = threading.Thread(target=lambda: seen.append(lib.mphip_conv3d_set_half_products(0)))
+    t.start(); t.join()
+    assert seen == [0]                       # another thread starts with the flag off
+    assert lib.mphip_conv3d_set_half_products(0) == 1
+    assert lib.mphip_conv3d_set_half_products(0) == 0
+
+
 def test_no_cpu_fallback():
     from megaportrait_hack_amd import model as M, ops
 
@@ -222,29 +235,32 @@ def test_role_split_conv_hand_issued_memory_ops_are_padded_and_unspilled(monkeyp
     import register_table
 
     t = register_table.one(os.path.join(register_table.CSRC, "conv3d_f16x3_wino_pp.hip"))
-    k = next(k for k in t["kernels"] if "wino_pp_kernel" in k["name"])
-    assert k.get("vgpr_spill_count", 0) == 0 and k.get("private_segment_fixed_size", 0) == 0, k
+    ks = [k for k in t["kernels"] if "wino_pp_kernel" in k["name"]]
+    assert len(ks) == 2                                          # f16x3 and the single-product (autocast) instantiation
     asm = t["asm"]
-    body = asm[asm.index("wino_pp_kernel"):]
-    blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, flags=re.S)
-    vmem = [b for b in blocks if "buffer_load" in b or "global_load_lds" in b]
-    assert len(vmem) >= 2 * (3 + 9 + 2), len(vmem)          # per team: three halo-load groups, a DMA group per step, the prologue's
-    for b in vmem:
-        first = [ln.strip() for ln in b.splitlines() if ln.strip()][0]
-        assert first == "s_nop 4", b
-    # the halo loads' destinations: registers named by buffer_load lines inside the tile loop (after the prologue's), per team
-    dests = re.findall(r"buffer_load_dword(?:x4)? (v\[\d+:\d+\]|v\d+),", body)
-    assert len(dests) == 2 * 2 * 8                              # prologue + loop, two teams, eight loads a unit
-    regs = set()
-    for d in dests:
-        m = re.match(r"v\[(\d+):(\d+)\]", d)
-        regs |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(d[1:])}
-    copies = [ln for ln in body.splitlines() if re.match(r"\s+v_(mov_b32|mov_b64|pk_mov_b32|accvgpr_write)", ln) and
-              any(re.search(r", v%d$" % r, ln.strip()) or re.search(r", v\[%d:" % r, ln) for r in regs)]
-    # (the prologue reuses low registers for its own unit; a copy FROM a loop destination register would be a copy of data in flight)
-    loop_dest = set()
-    for d in dests[8:16] + dests[24:32]:
-        m = re.match(r"v\[(\d+):(\d+)\]", d)
-        loop_dest |= set(range(int(m.group(1)), int(m.group(2)) + 1)) if m else {int(d[1:])}
-    bad = [ln for ln in copies if any(re.search(r", v%d$" % r, ln.strip()) for r in loop_dest)]
-    assert not bad, bad[:5]
+    for k in ks:
+        assert k.get("vgpr_spill_count", 0) == 0 and k.get("private_segment_fixed_size", 0) == 0, k
+        start = asm.index(k["name"] + ":")
+        body = asm[start:asm.index(".Lfunc_end", start)]
+        blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, flags=re.S)
+        vmem = [b for b in blocks if "buffer_load" in b or "global_load_lds" in b]
+        assert len(vmem) >= 2 * (3 + 9 + 2), len(vmem)          # per team: three halo-load groups, a DMA group per step, the prologue's
+        for b in vmem:
+            first = [ln.strip() for ln in b.splitlines() if ln.strip()][0]
+            assert first == "s_nop 4", b
+        # the halo loads' destinations inside the tile loop (hipcc marks a block's loop membership in the label comment; the prologue's loads,
+        # outside every loop, are followed by a full drain before anything reads them)
+        loop_dest, n_loop, in_loop = set(), 0, False
+        for ln in body.splitlines():
+            if re.match(r"\.LBB\d+_\d+:", ln):
+                in_loop = "Loop" in ln
+            m = re.match(r"\s+buffer_load_dword(?:x4)? (v\[(\d+):(\d+)\]|v(\d+)),", ln)
+            if m and in_loop:
+                n_loop += 1
+                loop_dest |= set(range(int(m.group(2)), int(m.group(3)) + 1)) if m.group(2) else {int(m.group(4))}
+        assert n_loop >= 16 and n_loop % 8 == 0, n_loop            # eight loads a unit, two teams (hipcc may unswitch the tile loop)
+        assert 20 <= len(loop_dest) <= 40, sorted(loop_dest)       # one 20-register set per team (the teams may share numbers)
+        # a compiler copy FROM a loop destination register would be a copy of data that may still be in flight
+        bad = [ln for ln in body.splitlines() if re.match(r"\s+v_(mov_b32|mov_b64|pk_mov_b32|accvgpr_write)", ln) and
+               any(re.search(r", v%d$" % r, ln.strip()) for r in loop_dest)]
+        assert not bad, bad[:5]
