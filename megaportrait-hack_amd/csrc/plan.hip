@@ -220,9 +220,9 @@ const void *packed(Ctx &c, ConvW &cw, int prec) {
         cw.pk[prec] = q;
         cw.fresh[prec] = false;
     }
-    if (!cw.fresh[prec]) {
-        RUN(c, mphip_pack_conv_weight(cw.w, cw.pk[prec], cw.co, cw.ci, cw.k, prec, c.s));
-        cw.fresh[prec] = true;
+    if (!cw.fresh[prec] && !c.dry && c.rc == MPHIP_OK) {   // ("fresh" only once the pack was really issued — a forward that failed
+        RUN(c, mphip_pack_conv_weight(cw.w, cw.pk[prec], cw.co, cw.ci, cw.k, prec, c.s));   // earlier must not leave a never-written buffer marked usable)
+        if (c.rc == MPHIP_OK) cw.fresh[prec] = true;
     }
     return cw.pk[prec];
 }
@@ -435,9 +435,9 @@ void resblock_ada(GenLane (&ln)[L], int blk, T5 (&x)[L], int ud, int uh, int uw)
                 cw.pk[1] = q;
                 cw.fresh[1] = false;
             }
-            if (!cw.fresh[1]) {
+            if (!cw.fresh[1] && c.rc == MPHIP_OK) {   // (fresh only when the copy was issued and succeeded, see packed())
                 RUN(c, mphip_flowfield_compact_weight(cw.w, cw.pk[1], cw.ci, cw.co, c.s));
-                cw.fresh[1] = true;
+                if (c.rc == MPHIP_OK) cw.fresh[1] = true;
             }
             return cw.pk[1];
         };
