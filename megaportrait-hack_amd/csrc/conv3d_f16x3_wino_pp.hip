@@ -109,6 +109,8 @@ __device__ __forceinline__ unsigned long long pp_memtime() {
 // Hand-issued for the reason given at lds_dma16 (mphip_f16x3.h); M0 is written in the statement that reads it.  The statement opens
 // with `s_nop 4`: `base` may have been reloaded from a spill lane by v_readlane just before, and a VALU-written SGPR needs 5 wait
 // states before a vector-memory instruction reads it — hipcc pads nothing inside an asm string (cdna_hip_programming.md 5.7).
+// (No "m0" clobber: hipcc refuses it — "reserved register, undefined behaviour".  What it would promise is checked on the disassembly by
+//  tests/test_host.py: outside these statements the kernel contains no instruction that reads or writes M0.)
 __device__ __forceinline__ void pp_dma3(const void *base, unsigned off0, unsigned off1, unsigned off2, unsigned lds0, unsigned lds1, unsigned lds2) {
     asm volatile("s_nop 4\n\t"
                  "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
