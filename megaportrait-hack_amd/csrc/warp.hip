@@ -1285,19 +1285,43 @@ warp_frame_box_kernel(const float *__restrict__ coords, int *__restrict__ fbox, 
     const size_t vol = (size_t)D * H * W;
     const float *cb = coords + (size_t)b * vol * 3;
     int lx = INT_MAX, ly = INT_MAX, lz = INT_MAX, hx = 0, hy = 0, hz = 0;
-    // (eight voxels' loads in flight per thread: with one at a time this one-workgroup-per-frame pass took 15 us of pure latency)
-    for (size_t t0 = threadIdx.x; t0 < vol; t0 += 8 * 1024) {
-        float c[8][3];
+    auto take = [&](float x, float y, float z) {
+        const int x0 = (int)floorf(x), y0 = (int)floorf(y), z0 = (int)floorf(z);
+        lx = min(lx, x0); ly = min(ly, y0); lz = min(lz, z0);
+        hx = max(hx, x0); hy = max(hy, y0); hz = max(hz, z0);
+    };
+    if (vol % 4 == 0 && ((uintptr_t)cb & 15) == 0) {
+        // four voxels = three 16-byte loads of contiguous memory per thread and step, four steps in flight: the frame's 786 KB stream through
+        // ONE workgroup at the CU's load rate (r04's strided dword loads, 24 per step: 55 us per call, the longest single item in front of
+        // the demand-driven final_conv on a one-stream step)
+        const float4 *c4 = reinterpret_cast<const float4 *>(cb);
+        const size_t groups = vol / 4;
+        for (size_t g0 = threadIdx.x; g0 < groups; g0 += 4 * 1024) {
+            float4 q[4][3];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const size_t t = min(t0 + (size_t)u * 1024, vol - 1);  // (a clamped duplicate changes no minimum / maximum)
-            c[u][0] = cb[t * 3]; c[u][1] = cb[t * 3 + 1]; c[u][2] = cb[t * 3 + 2];
+            for (int u = 0; u < 4; ++u) {
+                const size_t g = min(g0 + (size_t)u * 1024, groups - 1);  // (a clamped duplicate changes no minimum / maximum)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) q[u][k] = c4[g * 3 + k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                take(q[u][0].x, q[u][0].y, q[u][0].z);
+                take(q[u][0].w, q[u][1].x, q[u][1].y);
+                take(q[u][1].z, q[u][1].w, q[u][2].x);
+                take(q[u][2].y, q[u][2].z, q[u][2].w);
+            }
         }
+    } else {
+        for (size_t t0 = threadIdx.x; t0 < vol; t0 += 8 * 1024) {
+            float c[8][3];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int x0 = (int)floorf(c[u][0]), y0 = (int)floorf(c[u][1]), z0 = (int)floorf(c[u][2]);
-            lx = min(lx, x0); ly = min(ly, y0); lz = min(lz, z0);
-            hx = max(hx, x0); hy = max(hy, y0); hz = max(hz, z0);
+            for (int u = 0; u < 8; ++u) {
+                const size_t t = min(t0 + (size_t)u * 1024, vol - 1);  // (a clamped duplicate changes no minimum / maximum)
+                c[u][0] = cb[t * 3]; c[u][1] = cb[t * 3 + 1]; c[u][2] = cb[t * 3 + 2];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) take(c[u][0], c[u][1], c[u][2]);
         }
     }
     lx = wave_min(lx); ly = wave_min(ly); lz = wave_min(lz);
