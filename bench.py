@@ -201,7 +201,7 @@ def pmc_record(name, sources):
 
 def pmc_traffic(wino):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes, or (None, stale)."""
-    rec, stale = pmc_record("r04_pmc_conv.json", ["conv3d_f16x3_wino.hip" if wino else "conv3d_f16x3.hip", "mphip_f16x3.h"])
+    rec, stale = pmc_record("r05_pmc_conv.json", ["conv3d_f16x3_wino_pp.hip" if wino else "conv3d_f16x3.hip", "mphip_f16x3.h"])
     if rec is None:
         return None, stale
     try:
@@ -758,8 +758,8 @@ def main():
         wino = bool(f16x3 and _lib.load().mphip_conv3d_kernel_variant(B, 96, 96, 16, 64, 64, 3, 1) == 5)
         issued_per_alg = 2.0 if wino else 3.0   # f16 MFMA FLOPs issued per algorithmic FLOP: 3 products, x 2/3 in the F(2,3) domain
         if f16x3:
-            dom_name = (("conv3d_k3_f16x3_wino_kernel (Conv3d 3x3x3 96->96 @16x64x64 in the 1-D Winograd F(2,3) domain: 2/3 of the direct "
-                         "kernel's MFMAs, " if wino else "conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, ")
+            dom_name = (("conv3d_k3_f16x3_wino_pp_kernel (Conv3d 3x3x3 96->96 @16x64x64 in the 1-D Winograd F(2,3) domain: 2/3 of the direct "
+                         "kernel's MFMAs, role-split schedule, " if wino else "conv3d_k3_f16x3_kernel<4,8,16,8,1> (Conv3d 3x3x3 96->96 @16x64x64, ")
                         + ("2 full launches/step + 1 demand-driven" if demand else "3 launches/step") + ")")
             peak, dtype = PEAK_F16_MFMA_TFLOPS, ("f16x3 (fp32 in/out, operands split into 2 f16 halves, 3 f16 MFMAs per product, fp32 accumulate"
                                                  + ("; 3x3x3 convs that fill the chip run in the F(2,3) Winograd domain along W" if wino else "") + ")")

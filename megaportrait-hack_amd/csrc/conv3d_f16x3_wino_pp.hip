@@ -100,7 +100,7 @@ __device__ __forceinline__ unsigned long long pp_memtime() {
 #define PP_PRIO 0
 #endif
 // Timing-only ablations (dev, wrong results; -DPP_ABL=mask): 1 no halo convert / transform / LDS writes, 2 no halo loads, 4 no weight DMA,
-// 8 no output transform / stores, 16 no MFMAs, 32 no fragment reads
+// 8 no output transform / stores, 16 no MFMAs, 32 no fragment reads, 512 no output stores, 1024 only 12 of a step's 18 MFMAs
 #ifndef PP_ABL
 #define PP_ABL 0
 #endif
@@ -557,7 +557,7 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
 #if PP_ABL & 16
                 asm volatile("" ::"v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(al[0]), "v"(al[1]), "v"(al[2]), "v"(bl[0]), "v"(bl[1]), "v"(bh[0]), "v"(bh[1]));
 #else
-                if constexpr (!SINGLE) {
+                if constexpr (!SINGLE && !(PP_ABL & 1024)) {   /* (1024: timing only — 12 of the 18 MFMAs, what a 2-D F(2x2,3x3) transform would leave, at NO extra cost) */
 #pragma unroll
                     for (int m = 0; m < 3; ++m)
 #pragma unroll

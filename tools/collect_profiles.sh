@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's evidence on a GPU box into gpurun_out/profiles_rNN/ — every JSON it writes carries the commit it was run at and the
 # sha256 of the kernel sources it measured; bench.py quotes counters only when those stamps match the sources of the build.
-# usage (from the build container):  gpurun -- "COMMIT=$(git rev-parse HEAD) ROUND=r04 bash tools/collect_profiles.sh"
+# usage (from the build container):  gpurun -- "COMMIT=$(git rev-parse HEAD) ROUND=r05 bash tools/collect_profiles.sh"
 cd $GRAFT_REPO_ROOT
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 stamp() {   # stamp <json file> <source files...>: adds _commit / _sources (sha256) to a JSON object in place
@@ -39,8 +39,8 @@ rm -rf $out/kt
 # 2. the same line without the profiler, same box
 python bench.py --no-cpu-baseline --extras-budget 30 --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${R}_bench_line_same_box_as_trace.json
 # 3. SQ / HBM counters of the dominant conv (the F(2,3) kernel; separate passes, MI355X_MICROARCH.md)
-bash tools/pmc_conv.sh $out/pmc_conv conv3d_k3_f16x3_wino_kernel > $out/pmc_conv.log 2>&1
-cp $out/pmc_conv/conv_pmc.json $out/${R}_pmc_conv.json && stamp $out/${R}_pmc_conv.json conv3d_f16x3_wino.hip mphip_f16x3.h
+bash tools/pmc_conv.sh $out/pmc_conv conv3d_k3_f16x3_wino_pp_kernel > $out/pmc_conv.log 2>&1
+cp $out/pmc_conv/conv_pmc.json $out/${R}_pmc_conv.json && stamp $out/${R}_pmc_conv.json conv3d_f16x3_wino_pp.hip mphip_f16x3.h
 rm -rf $out/pmc_conv
 # 4. HBM counters of K2 / K3 (B = 8)
 bash tools/pmc_warps.sh $out/pmc_warps 8 > $out/pmc_warps.log 2>&1

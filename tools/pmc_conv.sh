@@ -2,7 +2,7 @@
 # SQ counters of the dominant f16x3 conv (one pass; MI355X_MICROARCH.md PMC slots: 8 SQ counters) + its HBM traffic passes.
 # usage (GPU box): tools/pmc_conv.sh out_dir [kernel name substring, default: the F(2,3) kernel]
 out=$1; mkdir -p $out
-KERNEL=${2:-conv3d_k3_f16x3_wino_kernel}
+KERNEL=${2:-conv3d_k3_f16x3_wino_pp_kernel}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_WAVES -d $out/sq -- python tools/run_one_conv.py 96 96 16 64 64 3 8 4 > $out/sq.log 2>&1
 for ctr in FETCH_SIZE WRITE_SIZE; do
