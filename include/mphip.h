@@ -39,8 +39,12 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 11
+#define MPHIP_ABI_VERSION 12
 int mphip_version(void);
+/* Build flags of the loaded library.  Bit 0: a DEVELOPMENT variant — at least one kernel was compiled with a timing-only ablation
+ * (csrc/mphip_ablate.h) and computes wrong results by design; the product build returns 0 and the Python loader refuses anything else
+ * unless MPHIP_ALLOW_ABLATED=1.                                                                                                     */
+int mphip_build_flags(void);
 const char *mphip_last_error(void);
 
 /* ------------------------------------------------------------------ K0  rigid transform
@@ -464,8 +468,8 @@ int mphip_conv3d_set_half_products(int enable);
  * They are NOT clamped (the output carries Inf/NaN like the reference's fp32 conv would); 0 in normal operation.     */
 int mphip_f16x3_saturation_count(unsigned long long *count, int reset);
 
-/* Which kernel a full launch of mphip_conv3d_fwd takes for this shape: 0 = exact fp32 kernels / the k = 1 GEMM, 1 / 2 = the direct
- * f16x3 kernel on (td,8,8) / (4,8,16) tiles, 5 = the f16x3 kernel in the 1-D Winograd F(2,3) domain (2/3 of the MFMAs;
+/* Which kernel a full launch of mphip_conv3d_fwd takes for this shape: 0 = exact fp32 kernels / the k = 1 GEMM, 1 = the direct
+ * f16x3 kernel on (td,8,8) tiles (2 = its (4,8,16)-tile form, removed in r05: never returned), 5 = the f16x3 kernel in the 1-D Winograd F(2,3) domain (2/3 of the MFMAs;
  * conv3d_f16x3_wino.hip).  For measurements and tests: results do not depend on it beyond fp32 rounding.                     */
 int mphip_conv3d_kernel_variant(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 

@@ -113,6 +113,7 @@ SIGNATURES = {
     "mphip_hot_slice_plan_destroy": (None, [_p]),
     "mphip_debug_mfma_sol": (_i, [_p, _i, _i, _i, _p]),
     "mphip_conv3d_kernel_variant": (_i, [_i] * 8),
+    "mphip_build_flags": (_i, []),
     "mphip_debug_dma_stream": (_i, [_p, _i, _i, _i, _i, _p, _i, _p]),
 }
 
@@ -121,7 +122,7 @@ _lib = None
 # The ABI version the SIGNATURES table above mirrors.  Checked against the library at load time, and against include/mphip.h by
 # tests/test_host.py — NOT read from the header at run time: a relocated / installed package ships libmphip.so without the repository's
 # include/ directory.
-EXPECTED_ABI_VERSION = 11
+EXPECTED_ABI_VERSION = 12
 
 
 def header_abi_version() -> int:
@@ -173,6 +174,9 @@ def load() -> ctypes.CDLL:
     if want != got:   # a stale build next to a newer header (or the reverse): arguments would be passed shifted
         raise RuntimeError(f"{LIB_PATH} was built with MPHIP_ABI_VERSION {got} but include/mphip.h declares {want}; rebuild "
                            "it (`python -c 'import __graft_entry__ as g; g.build()'`)")
+    if lib.mphip_build_flags() & 1 and os.environ.get("MPHIP_ALLOW_ABLATED") != "1":
+        raise RuntimeError(f"{LIB_PATH} is a development variant built with a timing-only ablation (csrc/mphip_ablate.h): its kernels "
+                           "compute wrong results by design.  Set MPHIP_ALLOW_ABLATED=1 to load it for a measurement.")
     _lib = lib
     return lib
 

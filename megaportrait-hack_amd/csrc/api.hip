@@ -27,6 +27,9 @@ extern "C" int mphip_conv3d_set_half_products(int enable) {
 }
 
 extern "C" int mphip_version(void) { return MPHIP_ABI_VERSION; }
+// bit 0: some translation unit of this library was compiled with a timing-only ablation on (mphip_ablate.h): its results are wrong by design
+extern "C" __attribute__((weak)) int mphip_ablated_build_marker;
+extern "C" int mphip_build_flags(void) { return &mphip_ablated_build_marker != nullptr ? 1 : 0; }
 extern "C" const char *mphip_last_error(void) { return mphip::g_err; }
 
 namespace mphip {

@@ -24,6 +24,7 @@
 
 #include <hip/hip_ext.h>
 
+#include "mphip_ablate.h"
 #include "mphip_common.h"
 #include "mphip_conv.h"
 #include "mphip_f16x3.h"
@@ -978,24 +979,17 @@ size_t f16x3_packed_bytes(int Co, int Ci) {   // ... + the transformed-domain sl
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     F16x3Plan p;
     p.td = D % 4 == 0 ? 4 : 2;
-    // variant: 0 = (td,8,8) tile, 256 voxels per workgroup; 1 = (4,8,16) tile, 512 voxels per workgroup (halves the
-    // weight stream per MFMA) — whenever that still gives every CU a workgroup (the persistent grid needs no second one;
-    // measured at B=8: 192->192 @8x32x32 0.371 vs 0.420 ms, 96->192 0.181 vs 0.194 ms; below one workgroup per CU
-    // the smaller tile wins: 192->96 0.203 vs 0.214 ms).
-    const char *force = getenv("MPHIP_F16X3_TILE");   // dev knobs, read per call (tools/sweep_conv_plans.py flips them in-process)
+    // variant: 0 = the direct kernels ((td,8,8) tile, 256 / 128 voxels per workgroup); 4 = the F(2,3) kernel.  (Until r05 a variant 1 —
+    // a (4,8,16) tile, 512 voxels per workgroup, the r02-r03 kernel of the chip-filling launches — was kept as the fallback of
+    // MPHIP_WINOGRAD=0; it was the one hot instantiation with scratch (248-256 B) and every launch it could take is variant 4's: removed.)
+    const char *force = getenv("MPHIP_F16X3_TILE");   // dev knob, read per call: "0" = direct kernels only (tools/sweep_conv_plans.py)
     const int cot = Co / F16X3_COT;
-    const long tiles1 = (p.td == 4 && W % 16 == 0) ? (long)N * (D / 4) * (H / 8) * (W / 16) : 0;
-    p.variant = (tiles1 * cot >= 256) ? 1 : 0;
-    if (force && force[0] == '0') p.variant = 0;
-    if (force && force[0] == '1' && tiles1) p.variant = 1;
-    // demand-driven launches compute a handful of tiles, one per CU: the time is ONE tile's latency, so the smallest tile wins
-    // (a ~5^3 box is 2 tiles either way: 4x8x8 halves the work per tile)
-    // (2x8x8 tiles on 4 waves for these launches: measured the same 0.092 ms as 4x8x8, r03)
-    if (roi && p.td == 4 && !force) p.variant = 0;
+    p.variant = 0;
+    (void)roi;
     // variant 4: the 1-D Winograd F(2,3) kernel (conv3d_f16x3_wino.hip; (4,8,8) tile, 2/3 of the MFMAs) on launches that fill the chip
     // (demand-driven launches follow the full launch's choice, so that the tiles they compute carry the same bits)
     if (!force && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
-    const long tiles = p.variant == 1 ? tiles1 : (long)N * (D / p.td) * (H / 8) * (W / 8);
+    const long tiles = (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup (each split adds a slab write + a reduce pass): the largest
     // whole-chunk split that still fits the chip in ONE round of resident workgroups (one per CU; two for the 4-wave (2,8,8) kernel).
@@ -1025,13 +1019,13 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
 
 int f16x3_tile_waves(const F16x3Plan &p) {   // GroupNorm-partial rows per tile of the kernel variant f16x3_launch picks (= its waves;
                                               // the Winograd kernel leaves one row per plane pair)
-    return p.variant == 4 ? 2 : (p.variant == 1 || p.td == 4) ? 8 : 4;
+    return p.variant == 4 ? 2 : p.td == 4 ? 8 : 4;
 }
 
 void f16x3_tile_dims(const F16x3Plan &p, int dims[3]) {   // output tile (d,h,w) of the kernel variant f16x3_launch picks
-    dims[0] = (p.variant == 1 || p.variant == 4) ? 4 : p.td;
+    dims[0] = p.variant == 4 ? 4 : p.td;
     dims[1] = 8;
-    dims[2] = p.variant == 1 ? 16 : 8;
+    dims[2] = 8;
 }
 
 int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed, const void *header_from, hipStream_t s) {
@@ -1111,7 +1105,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
     // persistent grid: as many workgroups as the chip runs at once (LDS: one per CU for the two big variants, two for
     // the (2,8,8) one), each walking its share of the tiles
     const int tiles_total = (int)p.grid.x;
-    const int per_cu = (p.variant == 1 || p.td == 4) ? 1 : 2;
+    const int per_cu = p.td == 4 ? 1 : 2;
     static const bool thirds_off = getenv("MPHIP_ROI_THIRDS") && getenv("MPHIP_ROI_THIRDS")[0] == '0';   // dev: same-box A/B
     const bool thirds = roi && p.variant == 0 && p.td == 4 && !gn_part && !thirds_off;
     const long others = (long)p.grid.y * (thirds ? 3 : 1) * p.grid.z;
@@ -1135,8 +1129,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
             hipLaunchKernelGGL(kern_, grid, dim3(block_), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, p.chunks_per_split, xb, \
                                in_affine, in_relu, x_scale, tiles_total, xcd_on, roi, roi_frames, gn_part);                      \
     }
-    if (p.variant == 1) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>), 512)
-    else if (p.td == 4 && thirds) F16X3_LAUNCH((conv3d_k3_f16x3_third_kernel<4, 8, 8, 8, 3>), 512)
+    if (p.td == 4 && thirds) F16X3_LAUNCH((conv3d_k3_f16x3_third_kernel<4, 8, 8, 8, 3>), 512)
     else if (p.td == 4) F16X3_LAUNCH((conv3d_k3_f16x3_kernel<4, 8, 8, 8, 3>), 512)
     else F16X3_LAUNCH((conv3d_k3_f16x3_kernel<2, 8, 8, 4, 1>), 256)
 #undef F16X3_LAUNCH

@@ -33,6 +33,7 @@
 
 #include <hip/hip_ext.h>
 
+#include "mphip_ablate.h"
 #include "mphip_conv.h"
 #include "mphip_f16x3.h"
 

@@ -36,6 +36,7 @@
 
 #include <hip/hip_ext.h>
 
+#include "mphip_ablate.h"
 #include "mphip_conv.h"
 #include "mphip_f16x3.h"
 
@@ -99,11 +100,7 @@ __device__ __forceinline__ unsigned long long pp_memtime() {
 #ifndef PP_PRIO
 #define PP_PRIO 0
 #endif
-// Timing-only ablations (dev, wrong results; -DPP_ABL=mask): 1 no halo convert / transform / LDS writes, 2 no halo loads, 4 no weight DMA,
-// 8 no output transform / stores, 16 no MFMAs, 32 no fragment reads, 512 no output stores, 1024 only 12 of a step's 18 MFMAs
-#ifndef PP_ABL
-#define PP_ABL 0
-#endif
+// Timing-only ablations (dev, wrong results; -DPP_ABL=mask): the bits are listed in mphip_ablate.h
 
 // Three LDS-DMA pieces of 16 bytes per lane: global `base` (wave-uniform) + `off_i` (per lane) -> LDS byte address `lds_i` + 16 * lane.
 // Hand-issued for the reason given at lds_dma16 (mphip_f16x3.h); M0 is written in the statement that reads it.  The statement opens

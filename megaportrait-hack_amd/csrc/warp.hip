@@ -3,6 +3,7 @@
 // Reference call sites: model.py:965-973/1016-1022 (K1), model.py:1028-1065 (K2),
 // model.py:1167-1171 (K3).  Built with -ffp-contract=off: every rounding below is placed where
 // ATen's CPU kernels round; the FMAs ATen uses are explicit fmaf().
+#include "mphip_ablate.h"
 #include "mphip_common.h"
 #include "mphip_resample.h"
 

@@ -538,7 +538,7 @@ def test_groupnorm_folded_into_conv(ops, dev):
 
 @pytest.mark.parametrize("shape", [(2, 96, 96, 8, 16, 32), (1, 96, 192, 4, 16, 16), (1, 192, 384, 4, 8, 16), (2, 384, 768, 4, 8, 8),
                                    # unsplit launches: the statistics come from the conv kernel's epilogue (per-tile partials + finalize),
-                                   # one shape per kernel variant: 4x8x8 tiles / 4x8x16 tiles / 2x8x8 tiles on four waves
+                                   # one shape per kernel variant: F(2,3) / 4x8x8 tiles / 2x8x8 tiles on four waves
                                    (2, 96, 96, 16, 64, 32), (4, 96, 192, 8, 32, 64), (4, 96, 96, 2, 64, 128)])
 def test_conv_with_groupnorm_statistics(ops, dev, shape):
     """conv + the following GroupNorm's (mean, rstd) in one call (mphip_conv3d_gn_fwd / mphip_conv3d_gnin_gn_fwd): same

@@ -126,6 +126,29 @@ def test_half_products_flag_is_thread_local(lib):
     assert lib.mphip_conv3d_set_half_products(0) == 0
 
 
+def test_ablated_build_is_marked_and_refused(lib, tmp_path):
+    """csrc/mphip_ablate.h: the product library reports no build flag; a variant with one translation unit compiled under a timing-only
+    ablation carries the marker, and the loader refuses it unless MPHIP_ALLOW_ABLATED=1."""
+    import subprocess
+    import sys
+
+    assert lib.mphip_build_flags() == 0
+    r = subprocess.run(["bash", os.path.join(ROOT, "tools", "build_variant.sh"), "hosttest_abl", "warp", "-DMPHIP_K2_ABL_NOSTORE"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    variant = os.path.join(ROOT, "build_variants", "libmphip_hosttest_abl.so")
+    code = "from megaportrait_hack_amd import _lib; print('flags', _lib.load().mphip_build_flags())"
+    env = dict(os.environ, MPHIP_LIB=variant, PYTHONPATH=ROOT)
+    env.pop("MPHIP_ALLOW_ABLATED", None)
+    try:
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+        assert r.returncode != 0 and "timing-only ablation" in r.stderr, (r.stdout, r.stderr[-1500:])
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(env, MPHIP_ALLOW_ABLATED="1"), timeout=300)
+        assert r.returncode == 0 and "flags 1" in r.stdout, (r.stdout, r.stderr[-1500:])
+    finally:
+        os.remove(variant)
+
+
 def test_no_cpu_fallback():
     from megaportrait_hack_amd import model as M, ops
 
@@ -208,13 +231,9 @@ def test_hot_kernels_have_no_scratch():
                                                        "conv3d_k1_f16x3_kernel", "conv_bwd_weight_f16x3_kernel", "conv_bwd_weight_k1_f16x3_kernel",
                                                        "warp_gather", "warp_coords_kernel", "warp_field_coords_kernel"))]
     assert len(hot) >= 12, sorted(kernels)
-    fallback = "conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>"
+    assert not any("conv3d_k3_f16x3_kernel<4, 8, 16, 8, 1>" in n for n in kernels)   # (the r02-r04 fallback with 248-256 B of scratch: removed in r05)
     for n in hot:
-        scratch = kernels[n].get("private_segment_fixed_size", 0)
-        if fallback in n:
-            assert scratch <= 256, (n, scratch)
-        else:
-            assert scratch == 0 and kernels[n].get("vgpr_spill_count", 0) == 0, (n, kernels[n])
+        assert kernels[n].get("private_segment_fixed_size", 0) == 0 and kernels[n].get("vgpr_spill_count", 0) == 0, (n, kernels[n])
     for name in ("conv3d_k3_f16x3_wino_kernel", "conv3d_k3_f16x3_wino_pp_kernel"):
         wino = next(k for n, k in kernels.items() if name in n)
         assert wino["group_segment_fixed_size"] <= 160 * 1024 and wino["vgpr_count"] <= 256

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MPHIP_ALLOW_ABLATED=1   # these variants are timing-only builds (csrc/mphip_ablate.h)
 # same-box A/B of library variants on the dominant conv + the bench step.  usage: tools/ab_conv.sh out_dir lib1 lib2 ...
 out=$1; shift
 mkdir -p $out

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MPHIP_ALLOW_ABLATED=1   # these variants are timing-only builds (csrc/mphip_ablate.h)
 # same-box A/B of library variants on K2 / K3 alone, per-kernel times from a kernel trace.  usage: tools/k2_ablate.sh lib1 lib2 ...
 export TMPDIR=/tmp
 for lib in "$@"; do

@@ -1,3 +1,4 @@
+export MPHIP_ALLOW_ABLATED=1   # these variants are timing-only builds (csrc/mphip_ablate.h)
 export TMPDIR=/tmp
 for lib in "$@"; do
   rm -rf /tmp/kt; MPHIP_LIB=$PWD/$lib rocprofv3 --kernel-trace -d /tmp/kt -- python tools/bench_warps.py 8 20 --only smooth > /dev/null 2>&1

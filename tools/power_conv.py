@@ -3,6 +3,7 @@ clock does it get?  usage: python tools/power_conv.py [seconds] [B Ci Co D H W] 
 import os, sys, threading, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+os.environ.setdefault("MPHIP_ALLOW_ABLATED", "1")   # dev tool: may be pointed at a timing variant (csrc/mphip_ablate.h)
 import torch
 from megaportrait_hack_amd import ops, _lib
 from mfma_sol import smi_sample

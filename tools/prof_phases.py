@@ -3,6 +3,7 @@
 MPHIP_LIB=/path/lib.so python tools/prof_phases.py"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MPHIP_ALLOW_ABLATED", "1")   # dev tool: may be pointed at a timing variant (csrc/mphip_ablate.h)
 import torch
 from megaportrait_hack_amd import ops, _lib
 lib = _lib.load()

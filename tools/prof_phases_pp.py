@@ -3,6 +3,7 @@ built with -DMPHIP_PP_PROFILE: tools/build_variant.sh ppprof conv3d_f16x3_wino_p
 MPHIP_LIB=$PWD/build_variants/libmphip_ppprof.so python tools/prof_phases_pp.py [B Ci Co D H W]"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MPHIP_ALLOW_ABLATED", "1")   # dev tool: may be pointed at a timing variant (csrc/mphip_ablate.h)
 import torch
 from megaportrait_hack_amd import ops, _lib
 lib = _lib.load()

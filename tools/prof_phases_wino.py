@@ -3,6 +3,7 @@ MPHIP_EXTRA_FLAGS=-DMPHIP_PROFILE_PHASES MPHIP_BUILD_DIR=/tmp/b bash megaportrai
 MPHIP_LIB=$PWD/build_variants/libmphip_prof.so python tools/prof_phases_wino.py [B Ci Co D H W]"""
 import os, sys, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MPHIP_ALLOW_ABLATED", "1")   # dev tool: may be pointed at a timing variant (csrc/mphip_ablate.h)
 import torch
 from megaportrait_hack_amd import ops, _lib
 lib = _lib.load()

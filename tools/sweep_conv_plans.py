@@ -35,7 +35,7 @@ for B in [int(a) for a in sys.argv[1:]] or [8]:
         time_one(x, pc)
         base = time_one(x, pc)
         res = []
-        for tile in ("0", "1"):
+        for tile in ("0",):   # (the 512-voxel tile variant "1" was removed in r05)
             for sp in ("1", "2", "3", "4", "6", "8", "12", "16", "24", "48"):
                 os.environ["MPHIP_F16X3_TILE"] = tile
                 os.environ["MPHIP_F16X3_SPLITS"] = sp

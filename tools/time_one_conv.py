@@ -1,6 +1,7 @@
 """time one conv layer: time_one_conv.py Ci Co D H W k B precision"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MPHIP_ALLOW_ABLATED", "1")   # dev tool: may be pointed at a timing variant (csrc/mphip_ablate.h)
 import torch
 from megaportrait_hack_amd import ops, _lib
 _lib.load()
