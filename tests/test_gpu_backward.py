@@ -97,6 +97,37 @@ def test_conv3d_bwd_data(dev, ops, shape, dy_mag):
         assert rel_err(dx, x.grad) < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 96, 16, 64, 64), (4, 192, 192, 8, 32, 32), (4, 96, 192, 8, 32, 32), (8, 384, 384, 4, 16, 16),
+                                   (8, 384, 192, 4, 16, 16)])
+def test_conv3d_bwd_data_f23_kernel_vs_direct_and_exact_at_g3d_levels(dev, ops, shape, monkeypatch):
+    """a per-layer gate for the F(2,3) kernels in the backward direction, at G3d's own level shapes (where the end-to-end
+    gradient tests need a ReLU-flip allowance, this one does not: one conv, no activation).  bwd-data of a (Ci -> Co) conv is a forward
+    launch (Co -> Ci) on the transposed / flipped pack: it must take the F(2,3) kernel at these shapes, and agree with the exact-fp32
+    MFMA kernel (itself pinned to the CPU at small shapes above) and with the direct f16x3 kernel to fp32 accumulation error.
+    (bwd-weight has no F(2,3) form: its kernel is the same for both settings and is covered by test_conv3d_bwd_weight*.)"""
+    from megaportrait_hack_amd import _lib
+
+    n, ci, co, d, h, w = shape
+    assert _lib.load().mphip_conv3d_kernel_variant(n, co, ci, d, h, w, 3, 1) == 5
+    dy = R.seeded_tensor((n, co, d, h, w), 31, scale=1.3).to(dev)
+    wt = R.seeded_tensor((co, ci, 3, 3, 3), 32, scale=0.05).to(dev)
+    pc = ops.PackedConv(wt, None, transposed=True)
+    _, scale = ops.grad_prep(dy, want_bias=False)
+    exact = ops.conv3d_bwd_data(dy, pc, scale, precision=0)
+    f23 = ops.conv3d_bwd_data(dy, pc, scale, precision=1)
+    monkeypatch.setenv("MPHIP_WINOGRAD", "0")
+    direct = ops.conv3d_bwd_data(dy, pc, scale, precision=1)
+    monkeypatch.delenv("MPHIP_WINOGRAD")
+    monkeypatch.setenv("MPHIP_WINO_PP", "0")
+    lockstep = ops.conv3d_bwd_data(dy, pc, scale, precision=1)
+    top = exact.abs().max().item()
+    assert top > 0.1
+    for name, got in (("F(2,3) role-split", f23), ("F(2,3) lockstep", lockstep), ("direct", direct)):
+        err = (got - exact).abs().max().item() / top
+        assert err < 2e-5, (name, err)
+    assert not torch.equal(f23, direct)          # (different kernels did run)
+
+
 @pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, False)])
 @pytest.mark.parametrize("shape", [(2, 96, 4, 8, 8), (1, 64, 2, 5, 6)])
 def test_groupnorm_bwd(dev, ops, shape, relu, res):

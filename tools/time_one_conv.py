@@ -1,4 +1,4 @@
-"""time one conv layer: time_one_conv.py Ci Co D H W k B precision"""
+"""time one conv layer: [HALF=1] time_one_conv.py Ci Co D H W k B precision"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MPHIP_ALLOW_ABLATED", "1")   # dev tool: may be pointed at a timing variant (csrc/mphip_ablate.h)
@@ -6,6 +6,7 @@ import torch
 from megaportrait_hack_amd import ops, _lib
 _lib.load()
 Ci, Co, D, H, W, k, B, prec = (int(a) for a in sys.argv[1:9])
+if os.environ.get("HALF") == "1": _lib.load().mphip_conv3d_set_half_products(1)   # the autocast policy: one f16 product per multiply
 dev = torch.device("cuda:0")
 x = torch.randn(B, Ci, D, H, W, device=dev)
 pc = ops.PackedConv(torch.randn(Co, Ci, k, k, k, device=dev) * 0.02, torch.randn(Co, device=dev))
