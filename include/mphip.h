@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 12
+#define MPHIP_ABI_VERSION 13
 int mphip_version(void);
 /* Build flags of the loaded library.  Bit 0: a DEVELOPMENT variant — at least one kernel was compiled with a timing-only ablation
  * (csrc/mphip_ablate.h) and computes wrong results by design; the product build returns 0 and the Python loader refuses anything else
@@ -306,6 +306,23 @@ int mphip_pack_conv_weight_bwd_data_like(const float *w, void *wp, int Co, int C
 int mphip_conv3d_bwd_data(const float *dy, const void *wt_packed, float *dx, const float *dy_scale, int N, int Ci,
                           int Co, int D, int H, int W, int k, int precision, void *workspace, size_t workspace_bytes,
                           void *stream);
+/* Batched re-packing (ABI 13): every conv weight of a module in at most five launches instead of two or three per weight — a training
+ * step re-packs all of them after its optimizer update (train.py:283-284 -> the next forward), and ~100 dependent 5-20 us launches are a
+ * millisecond of a 10 ms step.  A job is one mphip_pack_conv_weight / _bwd_data / _bwd_data_like call: `transposed` selects the bwd-data
+ * direction (Co / Ci are then the bwd-data conv's own, as in mphip_pack_conv_weight_bwd_data), `like` (precision 1 only, may be NULL) is
+ * a pack of the SAME weight tensor — another job's `wp` or an existing pack — whose header (max|w|) is reused instead of a second
+ * reduction.  The table resolves the jobs once (pointers and shapes are fixed; the weights' VALUES are read at every run), owns a small
+ * device buffer (hipMalloc / hipFree in create / destroy: not stream-ordered, not capturable) and mphip_pack_table_run only launches
+ * kernels on `stream` (capturable).  Results are bit-identical to the single calls.                                               */
+typedef struct mphip_pack_job {
+    const float *w;      /* OIDHW weight (device)                                                             */
+    void *wp;            /* destination pack, mphip_packed_weight_bytes(Co, Ci, k, precision) bytes (device)  */
+    const void *like;    /* see above                                                                         */
+    int Co, Ci, k, precision, transposed;
+} mphip_pack_job;
+int mphip_pack_table_create(const mphip_pack_job *jobs, int n, void **table);
+int mphip_pack_table_run(void *table, void *stream);
+int mphip_pack_table_destroy(void *table);
 int mphip_conv3d_bwd_weight_supported(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 size_t mphip_conv3d_bwd_weight_workspace_bytes(int N, int Ci, int Co, int D, int H, int W, int k, int precision);
 /* x_range: the range descriptor the forward conv used for x (precision 1; NULL = computed here, one extra read of x) */

@@ -19,6 +19,12 @@ _i = ctypes.c_int
 _sz = ctypes.c_size_t
 _p = ctypes.c_void_p
 
+class PackJob(ctypes.Structure):
+    """mphip_pack_job (include/mphip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("wp", ctypes.c_void_p), ("like", ctypes.c_void_p), ("Co", ctypes.c_int), ("Ci", ctypes.c_int),
+                ("k", ctypes.c_int), ("precision", ctypes.c_int), ("transposed", ctypes.c_int)]
+
+
 # name -> (restype, argtypes); mirrors include/mphip.h one to one.
 SIGNATURES = {
     "mphip_version": (_i, []),
@@ -114,6 +120,9 @@ SIGNATURES = {
     "mphip_debug_mfma_sol": (_i, [_p, _i, _i, _i, _p]),
     "mphip_conv3d_kernel_variant": (_i, [_i] * 8),
     "mphip_build_flags": (_i, []),
+    "mphip_pack_table_create": (_i, [_p, _i, ctypes.POINTER(ctypes.c_void_p)]),
+    "mphip_pack_table_run": (_i, [_p, _p]),
+    "mphip_pack_table_destroy": (_i, [_p]),
     "mphip_debug_dma_stream": (_i, [_p, _i, _i, _i, _i, _p, _i, _p]),
 }
 
@@ -122,7 +131,7 @@ _lib = None
 # The ABI version the SIGNATURES table above mirrors.  Checked against the library at load time, and against include/mphip.h by
 # tests/test_host.py — NOT read from the header at run time: a relocated / installed package ships libmphip.so without the repository's
 # include/ directory.
-EXPECTED_ABI_VERSION = 12
+EXPECTED_ABI_VERSION = 13
 
 
 def header_abi_version() -> int:

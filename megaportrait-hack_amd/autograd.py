@@ -23,9 +23,9 @@ def _bwd_pack(conv) -> ops.PackedConv:
     """PackedConv of the flipped/transposed weight (bwd-data as a forward conv), cached on the module like the
     forward pack and rebuilt when the parameter changes."""
     w = conv.weight
-    key = (w.data_ptr(), w._version, tuple(w.shape), str(w.device), ops.weight_epoch())
+    key = ops._pack_cache_key(conv, "_mphip_bwd_pack")
     hit = conv.__dict__.get("_mphip_bwd_pack")
-    if hit is None or hit[0] != key or ops.repacking():
+    if not ops.pack_is_current(hit, key):
         fwd = conv.__dict__.get("_mphip_pack")  # the forward pack — usable only if it was made from these very weights
         same = fwd is not None and fwd[0][0] == w.data_ptr() and fwd[0][1] == w._version and fwd[0][-1] == ops.weight_epoch()
         hit = (key, ops.PackedConv(w, None, transposed=True, header_from=fwd[1] if same else None))

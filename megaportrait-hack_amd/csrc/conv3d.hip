@@ -10,8 +10,10 @@
 //   B fragment = voxels   B[k=lane>>5][j=lane&31] -> X[ci+k][vox0+j + tap]  (one dword per lane)
 //   C/D: col j = lane&31, row i = (reg&3) + 8*(reg>>2) + 4*(lane>>5).
 #include <stdlib.h>
+#include <string.h>
 
 #include <algorithm>
+#include <vector>
 
 #include "mphip_common.h"
 #include "mphip_conv.h"
@@ -27,16 +29,32 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 // OIDHW [Co,Ci,k,k,k] -> [k^3][CiP][CoP], zero padded.
 // transposed: `w` is the ORIGINAL conv's weight [Ci][Co][taps] and the packed conv is its bwd-data conv:
 // Wt[co][ci][tap] = w[ci][co][taps-1-tap] (flipping all three axes reverses the linear tap index).
-__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int CoP,
-                                   int CiP, int taps, int transposed) {
+__device__ __forceinline__ void pack_weight_body(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int CoP,
+                                                 int CiP, int taps, int transposed, unsigned bid, unsigned nblk) {
     size_t n = (size_t)taps * CiP * CoP;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nblk * blockDim.x) {
         int co = (int)(i % CoP);
         int ci = (int)((i / CoP) % CiP);
         int tap = (int)(i / ((size_t)CoP * CiP));
         const size_t src = transposed ? ((size_t)ci * Co + co) * taps + (taps - 1 - tap) : ((size_t)co * Ci + ci) * taps + tap;
         wp[i] = (co < Co && ci < Ci) ? w[src] : 0.0f;
     }
+}
+__global__ void pack_weight_kernel(const float *__restrict__ w, float *__restrict__ wp, int Co, int Ci, int CoP,
+                                   int CiP, int taps, int transposed) {
+    pack_weight_body(w, wp, Co, Ci, CoP, CiP, taps, transposed, blockIdx.x, gridDim.x);
+}
+// every exact-fp32 pack of a table in one launch (mphip_pack_table_run): a block finds its job among the selected ones
+__global__ void __launch_bounds__(256) pack_many_f32_kernel(const PackJob *__restrict__ jobs, const int *__restrict__ sel,
+                                                            const int *__restrict__ first, int n) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const PackJob j = jobs[sel[lo]];
+    pack_weight_body(j.w, (float *)j.wp, j.Co, j.Ci, (j.Co + 31) / 32 * 32, (j.Ci + 1) / 2 * 2, j.k * j.k * j.k, j.transposed,
+                     blockIdx.x - first[lo], first[lo + 1] - first[lo]);
 }
 
 // Generic gather variant: both operands straight from global/L2 (buffer loads, hardware zero fill
@@ -504,6 +522,106 @@ static int pack_conv_weight(const float *w, void *wp, int Co, int Ci, int k, int
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (float *)wp, Co, Ci,
                        (Co + 31) / 32 * 32, (Ci + 1) / 2 * 2, k * k * k, transposed);
     return check_launch("pack_conv_weight");
+}
+
+// ---- batched re-packing: a table of (weight, pack) jobs resolved once, run in <= 5 launches (zero headers, absmax, f16x3 k=3, f16x3
+// k=1, exact fp32), capturable in a hipGraph.  Same bits as one mphip_pack_conv_weight* call per job.
+namespace {
+struct PackTable {
+    int n = 0;
+    void *dev = nullptr;          // [jobs | int arrays]
+    const PackJob *jobs = nullptr;
+    PackSel sel[4] = {};          // absmax, f16x3 k=3, f16x3 k=1, fp32
+};
+}  // namespace
+
+extern "C" int mphip_pack_table_create(const mphip_pack_job *jobs, int n, void **table_out) {
+    MPHIP_REQUIRE(jobs && table_out && n > 0, "pack_table_create: null pointer / no jobs");
+    std::vector<PackJob> dj((size_t)n);
+    std::vector<int> selv[4], firstv[4];
+    for (int i = 0; i < n; ++i) {
+        const mphip_pack_job &u = jobs[i];
+        MPHIP_REQUIRE(u.w && u.wp, "pack_table_create: job %d: null pointer", i);
+        MPHIP_REQUIRE(u.Co > 0 && u.Ci > 0 && (u.k == 1 || u.k == 3), "pack_table_create: job %d: bad dims", i);
+        MPHIP_REQUIRE(mphip_packed_weight_bytes(u.Co, u.Ci, u.k, u.precision) > 0,
+                      "pack_table_create: job %d: precision %d not available for Co=%d Ci=%d k=%d", i, u.precision, u.Co, u.Ci, u.k);
+        PackJob &j = dj[(size_t)i];
+        j.w = u.w; j.wp = u.wp; j.like = u.precision == 1 ? u.like : nullptr;
+        j.Co = u.Co; j.Ci = u.Ci; j.k = u.k; j.precision = u.precision; j.transposed = u.transposed ? 1 : 0; j.reserved = 0;
+        j.wino_off = (u.precision == 1 && u.k == 3) ? f16x3_pack_wino_offset(u.Co, u.Ci) : 0;
+        auto add = [&](int kind, int blocks) {   // (firstv holds block COUNTS here; the running sums are formed below)
+            selv[kind].push_back(i);
+            firstv[kind].push_back(blocks);
+        };
+        if (u.precision == 1) {
+            if (!j.like) add(0, f16x3_pack_blocks(j, 0));
+            add(u.k == 3 ? 1 : 2, f16x3_pack_blocks(j, u.k == 3 ? 1 : 2));
+        } else {
+            const size_t ne = packed_elems_f32(u.Co, u.Ci, u.k);
+            add(3, (int)std::min<size_t>(4096, (ne + 255) / 256));
+        }
+    }
+    PackTable *t = new PackTable();
+    t->n = n;
+    size_t ints = 0;
+    for (int k = 0; k < 4; ++k) ints += 2 * selv[k].size() + 1;
+    const size_t jobs_bytes = ((size_t)n * sizeof(PackJob) + 15) / 16 * 16;
+    std::vector<char> host(jobs_bytes + ints * sizeof(int));
+    memcpy(host.data(), dj.data(), (size_t)n * sizeof(PackJob));
+    if (hipMalloc(&t->dev, host.size()) != hipSuccess) {
+        delete t;
+        set_error("pack_table_create: hipMalloc of %zu bytes failed", host.size());
+        return MPHIP_ELAUNCH;
+    }
+    t->jobs = (const PackJob *)t->dev;
+    int *hi = (int *)(host.data() + jobs_bytes);
+    const int *di = (const int *)((const char *)t->dev + jobs_bytes);
+    size_t at = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int m = (int)selv[k].size();
+        t->sel[k].n = m;
+        t->sel[k].job = di + at;
+        for (int q = 0; q < m; ++q) hi[at + q] = selv[k][q];
+        at += (size_t)m;
+        t->sel[k].first = di + at;
+        int run = 0;
+        for (int q = 0; q < m; ++q) { hi[at + q] = run; run += firstv[k][q]; }
+        hi[at + m] = run;
+        t->sel[k].blocks = run;
+        at += (size_t)m + 1;
+    }
+    if (hipMemcpy(t->dev, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(t->dev);
+        delete t;
+        set_error("pack_table_create: upload failed");
+        return MPHIP_ELAUNCH;
+    }
+    *table_out = t;
+    return MPHIP_OK;
+}
+
+extern "C" int mphip_pack_table_run(void *table, void *stream) {
+    MPHIP_REQUIRE(table, "pack_table_run: null table");
+    const PackTable *t = (const PackTable *)table;
+    hipStream_t s = (hipStream_t)stream;
+    // (a `like` header is written by the absmax launch of THIS run when its owner is a job of the table, or earlier by the caller:
+    //  either way before the pack launches below, which are the first to read it)
+    if (t->sel[0].n || t->sel[1].n || t->sel[2].n) {
+        const int rc = f16x3_pack_many(t->jobs, t->sel[0], t->sel[1], t->sel[2], s);
+        if (rc != MPHIP_OK) return rc;
+    }
+    if (t->sel[3].n)
+        hipLaunchKernelGGL(pack_many_f32_kernel, dim3((unsigned)t->sel[3].blocks), dim3(256), 0, s, t->jobs, t->sel[3].job, t->sel[3].first,
+                           t->sel[3].n);
+    return check_launch("pack_table_run");
+}
+
+extern "C" int mphip_pack_table_destroy(void *table) {
+    if (!table) return MPHIP_OK;
+    PackTable *t = (PackTable *)table;
+    (void)hipFree(t->dev);
+    delete t;
+    return MPHIP_OK;
 }
 
 constexpr size_t RANGE_BYTES = ((MPHIP_RANGE_FLOATS * sizeof(float) + 255) / 256) * 256;  // descriptor + padding: keeps what follows aligned

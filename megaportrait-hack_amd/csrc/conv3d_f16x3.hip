@@ -71,15 +71,15 @@ __device__ unsigned long long g_f16x3_prof[8];
 
 // ---- weight packing ----------------------------------------------------------------------------
 // header (16 B): [0] inv_scale (float)  [1] scale (float)  [2] max|w| bits (uint)  [3] unused
-__global__ void __launch_bounds__(256) f16x3_absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ hdr) {
+__device__ __forceinline__ void f16x3_absmax_body(const float *__restrict__ w, size_t n, unsigned *__restrict__ hdr, unsigned bid, unsigned nblk) {
     float m = 0.0f;
     const size_t n4 = ((uintptr_t)w & 15) == 0 ? n / 4 : 0;  // 16-byte loads when the tensor is aligned (torch allocations are)
     const float4 *w4 = reinterpret_cast<const float4 *>(w);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n4; i += (size_t)nblk * blockDim.x) {
         const float4 q = w4[i];
         m = fmaxf(fmaxf(m, fmaxf(fabsf(q.x), fabsf(q.y))), fmaxf(fabsf(q.z), fabsf(q.w)));
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+    for (size_t i = n4 * 4 + (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nblk * blockDim.x)
         m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) m = fmaxf(m, __shfl_xor(m, s, 64));
@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(256) f16x3_absmax_kernel(const float *__restri
         if (mine > __hip_atomic_load(hdr + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(hdr + 2, mine);
     }
 }
+__global__ void __launch_bounds__(256) f16x3_absmax_kernel(const float *__restrict__ w, size_t n, unsigned *__restrict__ hdr) {
+    f16x3_absmax_body(w, n, hdr, blockIdx.x, gridDim.x);
+}
 
 // OIDHW [Co,Ci,3,3,3] fp32 -> slabs[(cot*nchunks + chunk)*NG + g][part][tap][kg][co][8] f16 (after the header).
 // A training step re-packs every weight twice (forward and bwd-data direction: 2 x 194 MB read, 2 x 194 MB written for G3d), so
@@ -103,13 +106,13 @@ __global__ void __launch_bounds__(256) f16x3_absmax_kernel(const float *__restri
 constexpr int PK_CO = 32;
 constexpr int PK_LDS_FLOATS = PK_CO * (F16X3_KC * 27 + 1);   // forward: 32 rows of 433; transposed: 16 rows of 865 (fewer floats)
 static_assert(PK_LDS_FLOATS >= F16X3_KC * (PK_CO * 27 + 1), "pack tile");
-__global__ void __launch_bounds__(256)
-f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in, float *__restrict__ hdr_out, int Co,
-                  int Ci, int transposed, _Float16 *__restrict__ wino_out /* the F(2,3) kernel's slabs (conv3d_f16x3_wino.hip) or nullptr */) {
-    __shared__ __attribute__((aligned(16))) float tile[PK_LDS_FLOATS];
+__device__ __forceinline__ void
+f16x3_pack_body(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in, float *__restrict__ hdr_out, int Co,
+                int Ci, int transposed, _Float16 *__restrict__ wino_out /* the F(2,3) kernel's slabs (conv3d_f16x3_wino.hip) or nullptr */,
+                const int block /* of this weight's (Co/32) x (Ci/16) */, float *__restrict__ tile /* LDS, PK_LDS_FLOATS */) {
     const float scale = weight_scale(hdr_in[2]);
     const int nchunks = Ci / F16X3_KC, subs = F16X3_COT / PK_CO;
-    int bid = blockIdx.x;
+    int bid = block;
     const int sub = bid % subs; bid /= subs;
     const int chunk = bid % nchunks;
     const int cot = bid / nchunks;
@@ -192,10 +195,16 @@ f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const
             *reinterpret_cast<half8 *>(wino_out + slab * WSLAB + WSLAB / 2 + inner) = lo;
         }
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (block == 0 && threadIdx.x == 0) {
         hdr_out[0] = 1.0f / scale;
         hdr_out[1] = scale;
     }
+}
+__global__ void __launch_bounds__(256)
+f16x3_pack_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in, float *__restrict__ hdr_out, int Co,
+                  int Ci, int transposed, _Float16 *__restrict__ wino_out) {
+    __shared__ __attribute__((aligned(16))) float tile[PK_LDS_FLOATS];
+    f16x3_pack_body(w, out, hdr_in, hdr_out, Co, Ci, transposed, wino_out, (int)blockIdx.x, tile);
 }
 
 // ---- the conv kernel ---------------------------------------------------------------------------
@@ -786,12 +795,12 @@ conv3d_k3_f16x3_third_kernel(const float *__restrict__ x, const _Float16 *__rest
 // on before managed 27 % of the fp32 MFMA rate (0.25 ms per step for 0.65 % of the FLOPs).
 constexpr int K1_SLAB_HALFS = 2 * 2 * F16X3_COT * 8;   // [part][kg][co][8] = 3072 halfs = 6 KB per (co tile, chunk)
 
-__global__ void f16x3_pack_k1_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in,
-                                     float *__restrict__ hdr_out, int Co, int Ci, int transposed) {
+__device__ __forceinline__ void f16x3_pack_k1_body(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in,
+                                                   float *__restrict__ hdr_out, int Co, int Ci, int transposed, unsigned bid, unsigned nblk) {
     const float scale = weight_scale(hdr_in[2]);
     const int nchunks = Ci / F16X3_KC;
     const size_t n = (size_t)(Co / F16X3_COT) * nchunks * (K1_SLAB_HALFS / 2);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < n; i += (size_t)nblk * blockDim.x) {
         size_t r = i;
         const int e = (int)(r % 8); r /= 8;
         const int co = (int)(r % F16X3_COT); r /= F16X3_COT;
@@ -807,10 +816,14 @@ __global__ void f16x3_pack_k1_kernel(const float *__restrict__ w, _Float16 *__re
         out[slab * K1_SLAB_HALFS + inner] = hi;
         out[slab * K1_SLAB_HALFS + K1_SLAB_HALFS / 2 + inner] = lo;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (bid == 0 && threadIdx.x == 0) {
         hdr_out[0] = 1.0f / scale;
         hdr_out[1] = scale;
     }
+}
+__global__ void __launch_bounds__(256) f16x3_pack_k1_kernel(const float *__restrict__ w, _Float16 *__restrict__ out, const unsigned *hdr_in,
+                                                            float *__restrict__ hdr_out, int Co, int Ci, int transposed) {
+    f16x3_pack_k1_body(w, out, hdr_in, hdr_out, Co, Ci, transposed, blockIdx.x, gridDim.x);
 }
 
 // KS = 1: four waves per workgroup, each with its own 64-voxel tile and the whole channel loop (large launches: the loop is
@@ -1047,6 +1060,66 @@ int f16x3_pack(const float *w, void *out, int Co, int Ci, int k, int transposed,
                            f16x3_wino_packed_bytes(Co, Ci) ? (_Float16 *)((char *)out + f16x3_direct_bytes(Co, Ci)) : (_Float16 *)nullptr);
     }
     return check_launch("pack_conv_weight(f16x3)");
+}
+
+// ---- every weight of a module in one launch per kernel kind (training re-packs all of them every step: r05's step spent 1.08 ms in
+// 105 latency-bound pack launches).  A block finds its job by its index in the launch (binary search over the jobs' first blocks) and runs
+// the body of the single-weight kernel on it: same bits as the single calls.
+__device__ __forceinline__ int pack_find(const int *__restrict__ first, int n, int bid) {
+    int lo = 0, hi = n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (first[mid] <= bid) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+__device__ __forceinline__ const unsigned *pack_hdr_in(const PackJob &j) { return (const unsigned *)(j.like ? j.like : j.wp); }
+__global__ void __launch_bounds__(256) pack_many_zero_hdr_kernel(const PackJob *__restrict__ jobs, const int *__restrict__ sel, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n * 4) reinterpret_cast<unsigned *>(jobs[sel[i >> 2]].wp)[i & 3] = 0u;
+}
+__global__ void __launch_bounds__(256) pack_many_absmax_kernel(const PackJob *__restrict__ jobs, const int *__restrict__ sel,
+                                                               const int *__restrict__ first, int n) {
+    const int q = pack_find(first, n, (int)blockIdx.x);
+    const PackJob j = jobs[sel[q]];
+    f16x3_absmax_body(j.w, (size_t)j.Co * j.Ci * (j.k == 3 ? 27 : 1), (unsigned *)j.wp, blockIdx.x - first[q], first[q + 1] - first[q]);
+}
+__global__ void __launch_bounds__(256) pack_many_k3_kernel(const PackJob *__restrict__ jobs, const int *__restrict__ sel,
+                                                           const int *__restrict__ first, int n) {
+    __shared__ __attribute__((aligned(16))) float tile[PK_LDS_FLOATS];
+    const int q = pack_find(first, n, (int)blockIdx.x);
+    const PackJob j = jobs[sel[q]];
+    char *out = (char *)j.wp;
+    f16x3_pack_body(j.w, (_Float16 *)(out + 16), pack_hdr_in(j), (float *)out, j.Co, j.Ci, j.transposed,
+                    j.wino_off ? (_Float16 *)(out + j.wino_off) : (_Float16 *)nullptr,
+                    (int)blockIdx.x - first[q], tile);
+}
+__global__ void __launch_bounds__(256) pack_many_k1_kernel(const PackJob *__restrict__ jobs, const int *__restrict__ sel,
+                                                           const int *__restrict__ first, int n) {
+    const int q = pack_find(first, n, (int)blockIdx.x);
+    const PackJob j = jobs[sel[q]];
+    char *out = (char *)j.wp;
+    f16x3_pack_k1_body(j.w, (_Float16 *)(out + 16), pack_hdr_in(j), (float *)out, j.Co, j.Ci, j.transposed, blockIdx.x - first[q],
+                       first[q + 1] - first[q]);
+}
+
+size_t f16x3_pack_wino_offset(int Co, int Ci) { return f16x3_wino_packed_bytes(Co, Ci) ? f16x3_direct_bytes(Co, Ci) : 0; }
+
+int f16x3_pack_blocks(const PackJob &j, int kind) {   // blocks of job j in the absmax (0) / k=3 (1) / k=1 (2) launch of f16x3_pack_many
+    const size_t n = (size_t)j.Co * j.Ci * (j.k == 3 ? 27 : 1);
+    if (kind == 0) return (int)std::min<size_t>(2048, (n + 4095) / 4096);
+    if (kind == 1) return (j.Co / PK_CO) * (j.Ci / F16X3_KC);
+    return (int)std::min<size_t>(256, (n + 255) / 256);
+}
+
+int f16x3_pack_many(const PackJob *jobs, PackSel absmax, PackSel k3, PackSel k1, hipStream_t s) {
+    if (absmax.n) {
+        hipLaunchKernelGGL(pack_many_zero_hdr_kernel, dim3((unsigned)((absmax.n * 4 + 255) / 256)), dim3(256), 0, s, jobs, absmax.job, absmax.n);
+        hipLaunchKernelGGL(pack_many_absmax_kernel, dim3((unsigned)absmax.blocks), dim3(256), 0, s, jobs, absmax.job, absmax.first, absmax.n);
+    }
+    if (k3.n) hipLaunchKernelGGL(pack_many_k3_kernel, dim3((unsigned)k3.blocks), dim3(256), 0, s, jobs, k3.job, k3.first, k3.n);
+    if (k1.n) hipLaunchKernelGGL(pack_many_k1_kernel, dim3((unsigned)k1.blocks), dim3(256), 0, s, jobs, k1.job, k1.first, k1.n);
+    return check_launch("pack_conv_weights(f16x3)");
 }
 
 int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci, int Co, int DHW,

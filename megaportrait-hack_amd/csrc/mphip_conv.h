@@ -28,6 +28,24 @@ int f16x3_launch_k1(const float *x, const void *wpacked, const float *bias, floa
                     const float *x_range, hipStream_t s);
 F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi = false);
 int f16x3_pack(const float *w_oidhw, void *out, int Co, int Ci, int k, int transposed, const void *header_from, hipStream_t s);
+// Batched re-packing (mphip_pack_table_*): one launch per kernel kind for every weight of a module.  PackJob is the device-side job
+// (the public mphip_pack_job + what the host resolved); PackSel a launch's selection: indices into the job array and the first block
+// of each selected job (n + 1 entries), both device arrays.
+struct PackJob {
+    const float *w;
+    void *wp;
+    const void *like;      // precision 1: a pack of the same weight whose header (max|w|) is reused, or nullptr
+    size_t wino_off;       // precision 1, k = 3: byte offset of the F(2,3) slabs in wp, 0 = none
+    int Co, Ci, k, precision, transposed, reserved;
+};
+struct PackSel {
+    const int *job;
+    const int *first;
+    int n, blocks;
+};
+int f16x3_pack_blocks(const PackJob &j, int kind /* 0 absmax, 1 k = 3 pack, 2 k = 1 pack */);
+size_t f16x3_pack_wino_offset(int Co, int Ci);
+int f16x3_pack_many(const PackJob *jobs, PackSel absmax, PackSel k3, PackSel k1, hipStream_t s);
 // roi (optional): 8 ints per box {lx,ly,lz,ex,ey,ez,-,-}: only the output tiles a box touches are computed (roi_frames == 0: one box per
 // frame; > 0: the conv's frames... single frame serves that many boxes)
 int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const float *bias, float *dst, int N, int Ci,

@@ -59,10 +59,9 @@ class _PackCache:
     @staticmethod
     def get(conv: nn.Module) -> ops.PackedConv:
         w, b = conv.weight, conv.bias
-        key = (w.data_ptr(), w._version, tuple(w.shape), None if b is None else (b.data_ptr(), b._version), str(w.device),
-               ops.weight_epoch())
+        key = ops._pack_cache_key(conv, "_mphip_pack")   # (data_ptr, _version, shape of the weight; the bias; device; epoch)
         hit = conv.__dict__.get("_mphip_pack")
-        if hit is None or hit[0] != key or ops.repacking():
+        if not ops.pack_is_current(hit, key):
             hit = (key, ops.PackedConv(w, b))
             conv.__dict__["_mphip_pack"] = hit
         return hit[1]

@@ -323,7 +323,7 @@ class PackedConv:
     """One Conv3d / 1x1 Conv2d: OIDHW fp32 weight + bias, packed lazily per precision into the
     kernel layouts described in include/mphip.h."""
 
-    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed", "transposed", "header_from")
+    __slots__ = ("weight", "bias", "co", "ci", "k", "_packed", "transposed", "header_from", "_table_token")
 
     def __init__(self, weight: torch.Tensor, bias: Optional[torch.Tensor], transposed: bool = False,
                  header_from: Optional["PackedConv"] = None):
@@ -343,6 +343,7 @@ class PackedConv:
         self.bias = None if bias is None else _req(bias.detach(), "conv bias")  # a view: the owner re-creates the pack when it changes
         self.co, self.ci, self.k = co, ci, k
         self._packed = {}
+        self._table_token = -1   # ops.PackTable: the repack_always region whose table run wrote these packs
 
     def packed(self, precision: int) -> torch.Tensor:
         wp = self._packed.get(precision)
@@ -369,6 +370,7 @@ class PackedConv:
 
 _conv_hook = None
 _repack_always = False
+_repack_token = 0      # bumped by every repack_always region: a PackTable run inside one marks its packs with it (pack_is_current)
 
 
 class repack_always:
@@ -376,8 +378,9 @@ class repack_always:
     weights into its graph; a cache hit at capture time would freeze stale packs into every replay)."""
 
     def __enter__(self):
-        global _repack_always
+        global _repack_always, _repack_token
         self._old, _repack_always = _repack_always, True
+        _repack_token += 1
 
     def __exit__(self, *exc):
         global _repack_always
@@ -386,6 +389,83 @@ class repack_always:
 
 def repacking() -> bool:
     return _repack_always
+
+
+def pack_is_current(hit, key) -> bool:
+    """The cache test of every per-module pack cache (model._PackCache, autograd._bwd_pack): the cached (key, PackedConv) pair serves
+    `key` — and, inside a repack_always region (a hipGraph capture), only if a PackTable run of THIS region wrote it (the capture must
+    contain the re-packing of every weight it uses; a pack made before it would freeze stale values into every replay)."""
+    if hit is None or hit[0] != key:
+        return False
+    return (not _repack_always) or getattr(hit[1], "_table_token", -1) == _repack_token
+
+
+class PackTable:
+    """Every weight pack a module's training step needs, re-made in at most five launches (mphip_pack_table_*; bit-identical to the
+    lazy per-conv packs).  Build it AFTER one real step has run — `PackTable.from_module(model)` collects the forward packs
+    (model._PackCache) and bwd-data packs (autograd._bwd_pack) that step created, with the precisions it used — then call `run()` at the
+    top of every step, after the optimizer update and before the forward: it re-packs all of them from the current weights and
+    re-validates the module caches, so that the step's convs find their packs current.  Convs the warm-up step did not touch, or shapes
+    that later need another precision, fall back to the lazy path as before.  training.GraphedTrainStep does all of this by itself."""
+
+    def __init__(self, entries):
+        """entries: (conv module, cache attribute, PackedConv) triples; every PackedConv contributes the precisions it holds."""
+        lib = _lib.load()
+        self._entries = list(entries)
+        jobs = []
+        fwd_of = {}   # weight storage -> the forward f16x3 pack buffer of the same weight (its header is shared)
+        for conv, attr, pc in self._entries:
+            if not pc.transposed and 1 in pc._packed:
+                fwd_of[pc.weight.data_ptr()] = pc._packed[1]
+        for conv, attr, pc in self._entries:
+            for prec, wp in sorted(pc._packed.items()):
+                like = fwd_of.get(pc.weight.data_ptr()) if (pc.transposed and prec == 1) else None
+                jobs.append(_lib.PackJob(pc.weight.data_ptr(), wp.data_ptr(), None if like is None else like.data_ptr(), pc.co, pc.ci, pc.k,
+                                         prec, int(pc.transposed)))
+        if not jobs:
+            raise RuntimeError("PackTable: nothing to pack (run one step of the module first)")
+        self.n_jobs = len(jobs)
+        arr = (_lib.PackJob * len(jobs))(*jobs)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.mphip_pack_table_create(ctypes.cast(arr, ctypes.c_void_p), len(jobs), ctypes.byref(handle)), "mphip_pack_table_create")
+        self._handle = handle
+
+    @classmethod
+    def from_module(cls, module: "torch.nn.Module") -> "PackTable":
+        entries = []
+        for m in module.modules():
+            for attr in ("_mphip_pack", "_mphip_bwd_pack"):
+                hit = m.__dict__.get(attr)
+                if hit is not None and isinstance(hit[1], PackedConv) and hit[1]._packed:
+                    entries.append((m, attr, hit[1]))
+        return cls(entries)
+
+    def run(self) -> None:
+        _lib.check(_lib.load().mphip_pack_table_run(self._handle, _stream()), "mphip_pack_table_run")
+        for conv, attr, pc in self._entries:
+            pc._table_token = _repack_token
+            pc.weight = conv.weight.detach()
+            pc.bias = None if (pc.transposed or conv.bias is None) else conv.bias.detach()
+            conv.__dict__[attr] = (_pack_cache_key(conv, attr), pc)
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None):
+            _lib.load().mphip_pack_table_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _pack_cache_key(conv, attr):
+    """The cache keys of model._PackCache.get / autograd._bwd_pack (kept here so that PackTable.run can re-validate both)."""
+    w, b = conv.weight, conv.bias
+    if attr == "_mphip_pack":
+        return (w.data_ptr(), w._version, tuple(w.shape), None if b is None else (b.data_ptr(), b._version), str(w.device), weight_epoch())
+    return (w.data_ptr(), w._version, tuple(w.shape), str(w.device), weight_epoch())
 
 
 _weight_epoch = 0

@@ -10,6 +10,7 @@ layers are tiny).
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Dict, Iterable, List, Optional
 
 import torch
@@ -206,7 +207,7 @@ class GraphedTrainStep:
 
     Inputs are copied into static buffers; `__call__` replays the graph and returns the (static) loss tensor.
     The packed-weight caches are bypassed while capturing (ops.repack_always) so the graph contains the per-step
-    re-packing of the updated weights.  Everything on the path zero-fills with kernels, not hipMemsetAsync: memset
+    re-packing of the updated weights — as one batched table run at the top of the step (ops.PackTable, `batched_packs`).  Everything on the path zero-fills with kernels, not hipMemsetAsync: memset
     nodes of a captured graph were not reliably ordered with the kernels around them on ROCm 7.2 (a replayed step
     went wrong in ~40 % of runs — stale f16x3 pack headers — until they were replaced; csrc/mphip_common.h).  Single-process only: a distributed step keeps the eager `train_step`
     (collectives stay outside the graph).
@@ -220,7 +221,7 @@ class GraphedTrainStep:
     synchronize yourself before reading."""
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
-                 example_inputs: Dict[str, torch.Tensor], warmup: int = 3, sync_after_replay: bool = True):
+                 example_inputs: Dict[str, torch.Tensor], warmup: int = 3, sync_after_replay: bool = True, batched_packs: Optional[bool] = None):
         import copy
 
         from . import ops
@@ -265,7 +266,15 @@ class GraphedTrainStep:
         for v in self.static_in.values():
             v.grad = None
         ops.begin_capture()   # range descriptors measured on the warm-up batch are not frozen into the graph (ops._range_for)
+        # batched_packs: the re-packing of every weight the warm-up steps packed (forward and bwd-data direction, the precisions they
+        # used) is captured as ONE table run at the top of the step (<= 5 launches, same bits) instead of two or three launches per
+        # weight at its first use: r05's step spent 1.08 of 10.9 ms in 105 latency-bound pack launches
+        if batched_packs is None:
+            batched_packs = os.environ.get("MPHIP_BATCHED_PACKS", "1") != "0"   # (dev: same-box A/B)
+        self.pack_table = ops.PackTable.from_module(model) if batched_packs else None
         with ops.repack_always(), torch.cuda.graph(self.graph):
+            if self.pack_table is not None:
+                self.pack_table.run()
             self.static_loss = loss_fn(model, **self.static_in)
             self.static_loss.backward()
             optimizer.step()

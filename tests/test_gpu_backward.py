@@ -615,6 +615,79 @@ def test_compute_rt_warp_is_differentiable(dev, M):
         assert not M.compute_rt_warp(rot.to(dev), tr.to(dev)).requires_grad
 
 
+def test_pack_table_rewrites_every_pack_bitwise(dev, M, ops):
+    """ops.PackTable (mphip_pack_table_*): every weight pack a step of a module needs — forward and bwd-data direction, f16x3 k=3 (with
+    its F(2,3) slabs), f16x3 k=1 and exact-fp32 packs — re-made in <= 5 launches is BIT-identical to the lazy per-conv packs of the same
+    weights, and leaves the module caches valid for exactly those weights."""
+    from megaportrait_hack_amd import model as Mm
+
+    torch.manual_seed(5)
+    blocks = torch.nn.ModuleList([M.ResBlock3D(96, 192), M.ResBlock3D(192, 192), M.ResBlock3D_Adaptive(64, 32)]).to(dev)
+    x0 = torch.randn(2, 96, 4, 16, 16, device=dev, requires_grad=True)
+    x1 = torch.randn(2, 64, 4, 2, 2, device=dev, requires_grad=True)       # FlowField-sized: exact-fp32 packs
+
+    def step():
+        for p in blocks.parameters():
+            p.grad = None
+        y = blocks[1](blocks[0](x0)).square().mean() + blocks[2](x1).square().mean()
+        y.backward()
+        return y.detach().clone(), [p.grad.clone() for p in blocks.parameters()]
+
+    step()                                         # creates every pack lazily
+    table = ops.PackTable.from_module(blocks)
+    precs = {(pc.k, prec) for _, _, pc in table._entries for prec in pc._packed}
+    assert {(3, 1), (1, 1), (3, 0)} <= precs and table.n_jobs >= 12, (precs, table.n_jobs)
+    with torch.no_grad():
+        for p in blocks.parameters():
+            p.mul_(1.3).add_(0.003)                # new values AND new _version: every cache entry is stale now
+    table.run()
+    for conv, attr, pc in table._entries:          # (1) the bytes: a fresh lazy pack of the same weights
+        assert conv.__dict__[attr][1] is pc
+        fresh = ops.PackedConv(conv.weight, None, transposed=pc.transposed)
+        for prec, wp in pc._packed.items():
+            want = fresh.packed(prec)
+            skip = 4 if prec == 1 else 0            # f16x3 header: [0] 1/scale [1] scale are compared; [2] max|w| lives in the forward pack when shared
+            assert torch.equal(wp[skip:], want[skip:]), (attr, prec)
+            if prec == 1:
+                assert torch.equal(wp[:2], want[:2])
+    # (2) the caches: the step runs on the table's packs (no PackedConv is re-created) and equals a step on lazily made packs
+    loss_t, grads_t = step()
+    for conv, attr, pc in table._entries:
+        assert conv.__dict__[attr][1] is pc
+    ops.invalidate_packs()
+    loss_l, grads_l = step()
+    assert torch.equal(loss_t, loss_l)
+    for a, b in zip(grads_t, grads_l):
+        assert torch.equal(a, b)
+    table.close()
+
+
+@pytest.mark.parametrize("batched", [True, False], ids=["one table run", "lazy packs"])
+def test_graphed_train_step_packs_both_ways_agree(dev, M, batched):
+    """training.GraphedTrainStep with the re-packing captured as one ops.PackTable run (default) or as the lazy per-conv packs (r01-r04):
+    the same losses and the same weights after three replays, bit for bit."""
+    from megaportrait_hack_amd import training
+
+    def build():
+        torch.manual_seed(11)
+        g = M.G3d(96).to(dev)
+        opt = torch.optim.SGD(g.parameters(), lr=1e-3, momentum=0.9)
+        return g, opt
+
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 77).to(dev)
+    loss_fn = lambda m, x: m(x).square().mean()
+    g, opt = build()
+    stepper = training.GraphedTrainStep(g, loss_fn, opt, {"x": x}, batched_packs=batched)
+    assert (stepper.pack_table is not None) == batched
+    losses = [stepper(x=x).item() for _ in range(3)]
+    ref_g, ref_opt = build()
+    ref = training.GraphedTrainStep(ref_g, loss_fn, ref_opt, {"x": x}, batched_packs=False)
+    ref_losses = [ref(x=x).item() for _ in range(3)]
+    assert losses == ref_losses
+    for a, b in zip(g.parameters(), ref_g.parameters()):
+        assert torch.equal(a, b)
+
+
 def test_graphed_train_step_matches_eager(dev, M):
     """training.GraphedTrainStep (forward + backward + SGD replayed as one hipGraph, weights re-packed inside the
     graph) walks the parameters exactly like the eager step."""
