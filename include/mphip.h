@@ -41,6 +41,13 @@ extern "C" {
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
 #define MPHIP_ABI_VERSION 13
 int mphip_version(void);
+/* hipGraph hygiene (ABI 13).  On ROCm 7.x a MEMSET node of a captured hipGraph is not reliably ordered with its neighbouring kernel nodes
+ * (observed twice: stale f16x3 pack headers, r03; a training step's loss that kept its previous value, r04-r05 — ATen's multi-block
+ * reduction zeroes its semaphores with hipMemsetAsync).  Rewrites `graph` (a hipGraph_t) in place: every 1-D MEMSET node becomes a kernel
+ * node with the same bytes, predecessors and successors; *replaced (may be NULL) receives the count.  Call between capture and
+ * instantiation.  Not stream-ordered; no effect on graphs without memset nodes.                                                        */
+int mphip_graph_memsets_to_kernels(void *graph, int *replaced);
+
 /* Build flags of the loaded library.  Bit 0: a DEVELOPMENT variant — at least one kernel was compiled with a timing-only ablation
  * (csrc/mphip_ablate.h) and computes wrong results by design; the product build returns 0 and the Python loader refuses anything else
  * unless MPHIP_ALLOW_ABLATED=1.                                                                                                     */
@@ -474,7 +481,8 @@ void mphip_hot_slice_plan_destroy(mphip_hot_slice_plan *plan);
 /* The reference's reduced-precision policy for the convs (train.py:145,188: the generator step runs under torch.cuda.amp.autocast(), its
  * conv3d calls take f16 operands with fp32 accumulation).  mphip_conv3d_set_half_products(1) makes the CALLING THREAD's subsequent precision-1
  * 3x3x3 launches that run in the F(2,3) domain (mphip_conv3d_kernel_variant == 5: G3d's levels 0-2, Eapp's 3-D tail, their bwd-data
- * convs) use ONE f16 product per multiply — operands rounded to f16 (in the transformed domain), fp32 accumulate, a third of the matrix
+ * convs) and the 3x3x3 f16x3 backward-weight launches (mphip_conv3d_bwd_weight, precision 1; since ABI 13) use ONE f16 product per
+ * multiply — operands rounded to f16 (in the transformed domain for the F(2,3) kernels), fp32 accumulate, a third of the matrix
  * work; every other kernel keeps its fp32-class arithmetic (autocast permits more precision, never less).  The flag is thread-local, read
  * when a launch is issued, and returns its previous value; the Python host sets it only while torch.is_autocast_enabled() with float16.
  * Results then carry f16-operand rounding (~1e-3 relative), NOT the 1e-3 max-abs fp32 contract of the default mode.                  */

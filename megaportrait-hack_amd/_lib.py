@@ -120,6 +120,7 @@ SIGNATURES = {
     "mphip_debug_mfma_sol": (_i, [_p, _i, _i, _i, _p]),
     "mphip_conv3d_kernel_variant": (_i, [_i] * 8),
     "mphip_build_flags": (_i, []),
+    "mphip_graph_memsets_to_kernels": (_i, [_p, ctypes.POINTER(ctypes.c_int)]),
     "mphip_pack_table_create": (_i, [_p, _i, ctypes.POINTER(ctypes.c_void_p)]),
     "mphip_pack_table_run": (_i, [_p, _p]),
     "mphip_pack_table_destroy": (_i, [_p]),

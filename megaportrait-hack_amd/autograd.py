@@ -49,7 +49,8 @@ class Conv3dFn(torch.autograd.Function):
         y = ops.conv3d(x, fwd_pack) if roi is None else ops.conv3d_roi(x, fwd_pack, roi)
         ctx.roi = roi
         ctx.x_range = ops.tensor_range(x)   # the f16x3 operand scale the forward used for x: bwd-weight reuses it
-        ctx.half = ops.autocast_half()      # the forward ran under the autocast policy: its bwd-data conv does too (backward runs on autograd's thread)
+        ctx.half = ops.half_products_active()   # the forward ran under the autocast policy (model._autocast_policy set the library's flag; torch's
+                                                # own autocast state is off inside custom_fwd): its backward convs do too, on autograd's thread
         return y
 
     @staticmethod
@@ -68,7 +69,8 @@ class Conv3dFn(torch.autograd.Function):
             with ops.half_products(ctx.half):
                 dx = ops.conv3d_bwd_data(dy, _bwd_pack(conv), scale, roi=ctx.roi)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range, roi=ctx.roi).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
+            with ops.half_products(ctx.half):   # (the 3x3x3 f16x3 bwd-weight kernel follows the policy too: one product per multiply)
+                dw = ops.conv3d_bwd_weight(x, dy, k, scale, x_range=ctx.x_range, roi=ctx.roi).view(conv.weight.shape)  # (a 1x1 Conv2d's weight is 4-D)
         return dx, dw, db, None, None, None
 
 

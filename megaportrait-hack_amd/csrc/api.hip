@@ -1,5 +1,8 @@
 // Library-level entry points: version and the thread-local error string.
+#include <string.h>
+
 #include <algorithm>
+#include <vector>
 
 #include "mphip_common.h"
 
@@ -38,6 +41,71 @@ __global__ void __launch_bounds__(256) zero_fill_kernel(float4 *__restrict__ p, 
         p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 }  // namespace mphip
+
+// ---- hipGraph hygiene: MEMSET nodes -> kernel nodes ------------------------------------------------------------------------------
+// On ROCm 7.x a MEMSET node of a captured graph is not reliably ordered with the kernel nodes around it, even in a strictly linear
+// chain (r03: stale f16x3 pack headers in ~40 % of replays until the library's own hipMemsetAsync calls became kernels; r05: the
+// "flaky graphed loss" of r04 — ATen's multi-block reduction zeroes its semaphores with hipMemsetAsync, the last block to finish writes
+// the result, and with a semaphore that still holds the previous replay's count NO block is the last: the loss tensor keeps its old
+// value while the step itself is right; tools/dbg_replay_stale_loss.py, tools/dbg_graph_topology.py: 262 nodes, 261 edges, ONE memset).
+// A captured graph may contain memsets the library never issued (any torch op in the user's loss).  This entry rewrites a hipGraph_t
+// in place: every 1-D MEMSET node becomes a kernel node (same bytes, same predecessors and successors).  Call it between capture and
+// instantiation (torch.cuda.CUDAGraph(keep_graph=True) -> raw_cuda_graph() -> this -> instantiate()).
+namespace mphip {
+__global__ void __launch_bounds__(256) graph_memset_kernel(unsigned char *__restrict__ dst, unsigned value, unsigned elem, size_t count) {
+    // count elements of `elem` bytes (1, 2 or 4), each set to the low bytes of `value` (hipMemsetParams semantics)
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+        if (elem == 4) reinterpret_cast<unsigned *>(dst)[i] = value;
+        else if (elem == 2) reinterpret_cast<unsigned short *>(dst)[i] = (unsigned short)value;
+        else dst[i] = (unsigned char)value;
+    }
+}
+}  // namespace mphip
+
+extern "C" int mphip_graph_memsets_to_kernels(void *graph_, int *replaced_out) {
+    MPHIP_REQUIRE(graph_, "graph_memsets_to_kernels: null graph");
+    hipGraph_t graph = (hipGraph_t)graph_;
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: hipGraphGetNodes failed"); return MPHIP_ELAUNCH; }
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: hipGraphGetNodes failed"); return MPHIP_ELAUNCH; }
+    int replaced = 0;
+    // (kernel parameters are copied by hipGraphAddKernelNode; these live only across the call)
+    for (hipGraphNode_t node : nodes) {
+        hipGraphNodeType type;
+        if (hipGraphNodeGetType(node, &type) != hipSuccess || type != hipGraphNodeTypeMemset) continue;
+        hipMemsetParams mp;
+        if (hipGraphMemsetNodeGetParams(node, &mp) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: hipGraphMemsetNodeGetParams failed"); return MPHIP_ELAUNCH; }
+        if (mp.height > 1 || (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4)) continue;   // (2-D memsets: left alone)
+        size_t np = 0, ns = 0;
+        (void)hipGraphNodeGetDependencies(node, nullptr, &np);
+        (void)hipGraphNodeGetDependentNodes(node, nullptr, &ns);
+        std::vector<hipGraphNode_t> preds(np), succs(ns);
+        if (np && hipGraphNodeGetDependencies(node, preds.data(), &np) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: dependencies"); return MPHIP_ELAUNCH; }
+        if (ns && hipGraphNodeGetDependentNodes(node, succs.data(), &ns) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: dependents"); return MPHIP_ELAUNCH; }
+        unsigned char *dst = (unsigned char *)mp.dst;
+        unsigned value = mp.value, elem = mp.elementSize;
+        size_t count = mp.width;
+        void *args[4] = {&dst, &value, &elem, &count};
+        hipKernelNodeParams kp;
+        memset(&kp, 0, sizeof(kp));
+        kp.func = (void *)mphip::graph_memset_kernel;
+        kp.blockDim = dim3(256);
+        kp.gridDim = dim3((unsigned)std::min<size_t>(1024, (count + 255) / 256 ? (count + 255) / 256 : 1));
+        kp.kernelParams = args;
+        hipGraphNode_t knode;
+        if (hipGraphAddKernelNode(&knode, graph, preds.data(), np, &kp) != hipSuccess) {
+            mphip::set_error("graph_memsets_to_kernels: hipGraphAddKernelNode failed (%s)", hipGetErrorString(hipGetLastError()));
+            return MPHIP_ELAUNCH;
+        }
+        for (hipGraphNode_t sct : succs)
+            if (hipGraphAddDependencies(graph, &knode, &sct, 1) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: hipGraphAddDependencies failed"); return MPHIP_ELAUNCH; }
+        if (hipGraphDestroyNode(node) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: hipGraphDestroyNode failed"); return MPHIP_ELAUNCH; }
+        ++replaced;
+    }
+    if (replaced_out) *replaced_out = replaced;
+    return MPHIP_OK;
+}
 
 namespace mphip {
 __global__ void __launch_bounds__(256) absmax_range_kernel(const float *__restrict__ x, size_t n, float *__restrict__ range) {

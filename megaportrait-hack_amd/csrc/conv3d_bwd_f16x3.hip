@@ -64,6 +64,9 @@ __device__ __forceinline__ void halo_row_frags(const _Float16 *row, half8 f[3]) 
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BL, ACC, 0, 0, 0);         \
     ACC = __builtin_amdgcn_mfma_f32_32x32x16_f16(AH, BH, ACC, 0, 0, 0);
 
+// SINGLE: the autocast(float16) policy (mphip_conv3d_set_half_products) — one product per multiply on the hi halves (= the
+// operands rounded to f16, what ATen's autocast feeds its conv backward), fp32 accumulation: a third of the MFMAs, no lo planes staged.
+template <bool SINGLE>
 __global__ void __launch_bounds__(512)
 conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gscale,
                              const float *__restrict__ x_range,
@@ -144,7 +147,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
                     lo[e] = l;
                 }
                 *reinterpret_cast<half8 *>(As + co * BF_AP + rr * 8) = hi;
-                *reinterpret_cast<half8 *>(As + BF_A_PART + co * BF_AP + rr * 8) = lo;
+                if constexpr (!SINGLE) *reinterpret_cast<half8 *>(As + BF_A_PART + co * BF_AP + rr * 8) = lo;
             }
         }
         {   // ---- X halo: 32 ci x 4 planes x 10 rows of 10 voxels (zero outside the volume), <= 3 rows per thread
@@ -186,7 +189,7 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
 #pragma unroll
                     for (int e = 0; e < 5; ++e) {
                         *reinterpret_cast<half2v *>(dst + 2 * e) = hp[e];
-                        *reinterpret_cast<half2v *>(dst + BF_X_PART + 2 * e) = lp[e];
+                        if constexpr (!SINGLE) *reinterpret_cast<half2v *>(dst + BF_X_PART + 2 * e) = lp[e];
                     }
                 }
             }
@@ -200,24 +203,34 @@ conv_bwd_weight_f16x3_kernel(const float *__restrict__ x, const float *__restric
             half8 bh[3], bl[3];
             const _Float16 *xrow = Xs + j * BF_XCI + ((dl + kd) * 10 + hrow + kh) * BF_XROW;
             halo_row_frags(xrow, bh);
-            halo_row_frags(xrow + BF_X_PART, bl);
+            if constexpr (!SINGLE) halo_row_frags(xrow + BF_X_PART, bl);
             const _Float16 *arow = As + j * BF_AP + ks * 16 + kb * 8;
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 const half8 ah = *reinterpret_cast<const half8 *>(arow + m * 32 * BF_AP);
-                const half8 al = *reinterpret_cast<const half8 *>(arow + m * 32 * BF_AP + BF_A_PART);
+                if constexpr (SINGLE) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) { BF_MFMA3(acc[t][m], ah, al, bh[t], bl[t]) }
+                    for (int t = 0; t < 3; ++t) acc[t][m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[t], acc[t][m], 0, 0, 0);
+                } else {
+                    const half8 al = *reinterpret_cast<const half8 *>(arow + m * 32 * BF_AP + BF_A_PART);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) { BF_MFMA3(acc[t][m], ah, al, bh[t], bl[t]) }
+                }
             }
             if (heavy) {
                 half8 ch[3], cl[3];
                 const _Float16 *xrow2 = Xs + j * BF_XCI + ((dl + 2) * 10 + hrow + 2) * BF_XROW;
                 halo_row_frags(xrow2, ch);
-                halo_row_frags(xrow2 + BF_X_PART, cl);
                 const half8 ah = *reinterpret_cast<const half8 *>(arow + wave * 32 * BF_AP);
-                const half8 al = *reinterpret_cast<const half8 *>(arow + wave * 32 * BF_AP + BF_A_PART);
+                if constexpr (SINGLE) {
 #pragma unroll
-                for (int t = 0; t < 3; ++t) { BF_MFMA3(acc2[t], ah, al, ch[t], cl[t]) }
+                    for (int t = 0; t < 3; ++t) acc2[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, ch[t], acc2[t], 0, 0, 0);
+                } else {
+                    halo_row_frags(xrow2 + BF_X_PART, cl);
+                    const half8 al = *reinterpret_cast<const half8 *>(arow + wave * 32 * BF_AP + BF_A_PART);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) { BF_MFMA3(acc2[t], ah, al, ch[t], cl[t]) }
+                }
             }
         }
 #endif
@@ -500,8 +513,12 @@ int bwd_weight_f16x3_launch(const float *x, const float *x_range, const float *d
     }
     bwf_plan(N, Ci, Co, D, H, W, splits, tps);
     dim3 grid(((Ci + 31) / 32) * ((Co + 95) / 96), 1, splits);
-    hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel, grid, dim3(512), 0, s, x, dy, dy_scale, x_range, (float *)workspace, N, Ci, Co, D, H, W,
-                       tps, dy_boxes);
+    if (conv_half_products())   // the calling thread's autocast policy
+        hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel<true>, grid, dim3(512), 0, s, x, dy, dy_scale, x_range, (float *)workspace, N, Ci, Co, D,
+                           H, W, tps, dy_boxes);
+    else
+        hipLaunchKernelGGL(conv_bwd_weight_f16x3_kernel<false>, grid, dim3(512), 0, s, x, dy, dy_scale, x_range, (float *)workspace, N, Ci, Co, D,
+                           H, W, tps, dy_boxes);
     const size_t ncc = (size_t)Co * Ci;
     hipLaunchKernelGGL(slab_reduce_f16x3_kernel, dim3(cdiv(ncc, 64)), dim3(256), 0, s, (const float *)workspace, dw, ncc, splits);
     return check_launch("conv3d_bwd_weight(f16x3)");

@@ -644,10 +644,11 @@ class GraphedHotSlice:
                     fn(**self.static_in)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True)
             ops.begin_capture()   # range descriptors measured on the warm-up batch are not frozen into the graph
             with torch.cuda.graph(self.graph):
                 self.static_out = fn(**self.static_in)
+            self.memset_nodes_replaced = ops.finish_graph_capture(self.graph)   # (memset nodes -> kernel nodes, then instantiate)
 
     def __call__(self, **inputs):
         for k, v in inputs.items():

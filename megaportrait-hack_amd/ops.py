@@ -292,8 +292,30 @@ def autocast_half() -> bool:
         return bool(torch.is_autocast_enabled()) and torch.get_autocast_gpu_dtype() == torch.float16
 
 
+def finish_graph_capture(graph: "torch.cuda.CUDAGraph") -> int:
+    """For a torch.cuda.CUDAGraph(keep_graph=True) right after its capture: rewrites every MEMSET node as a kernel node
+    (mphip_graph_memsets_to_kernels — on ROCm 7.x memset nodes are not reliably ordered with their neighbours, see
+    training.GraphedTrainStep) and instantiates the graph.  Returns the number of nodes replaced.  MPHIP_GRAPH_MEMSET_FIX=0 (dev A/B)
+    leaves the memsets alone."""
+    n = ctypes.c_int(0)
+    if _os.environ.get("MPHIP_GRAPH_MEMSET_FIX", "1") != "0":
+        _lib.check(_lib.load().mphip_graph_memsets_to_kernels(graph.raw_cuda_graph(), ctypes.byref(n)), "mphip_graph_memsets_to_kernels")
+    graph.instantiate()
+    return n.value
+
+
+def half_products_active() -> bool:
+    """The calling thread's conv arithmetic policy as the library sees it (set by `half_products` / model._autocast_policy).  This — not
+    torch's autocast state — is what an autograd Function must record in its forward: custom_fwd(cast_inputs=...) runs the forward with
+    autocast disabled, so torch.is_autocast_enabled() is False there even inside the region."""
+    lib = _lib.load()
+    prev = lib.mphip_conv3d_set_half_products(0)
+    lib.mphip_conv3d_set_half_products(prev)
+    return bool(prev)
+
+
 class half_products:
-    """Context manager: the calling thread's F(2,3) conv launches use ONE f16 product per multiply (include/mphip.h:
+    """Context manager: the calling thread's F(2,3) conv launches and 3x3x3 f16x3 bwd-weight launches use ONE f16 product per multiply (include/mphip.h:
     mphip_conv3d_set_half_products) — the arithmetic torch.autocast(float16) gives the reference's conv3d calls.  The flag is
     thread-local in the library; nesting restores the previous value.  `enable=None`: follow torch's autocast state."""
 

@@ -212,13 +212,17 @@ class GraphedTrainStep:
     went wrong in ~40 % of runs — stale f16x3 pack headers — until they were replaced; csrc/mphip_common.h).  Single-process only: a distributed step keeps the eager `train_step`
     (collectives stay outside the graph).
 
-    Ordering of the returned loss: on some boxes of the pool a read of the static loss issued on the launch stream right
-    behind `graph.replay()` returned the PREVIOUS replay's value (3 of ~20 runs in r03/r04; 0 of 140 with tools/repro_graph_loss.py in
-    r05) — stream order was not enough, a device-wide synchronize was: the replay's trailing nodes run on streams of the graph's own and
-    were seen to outlive the launch stream's completion marker.  `__call__` therefore waits for the DEVICE after the replay by default
-    (`sync_after_replay=True`: ~20 us on a step of several ms) and returns a private copy of the loss, so that `.item()`, logging or a
-    later replay cannot observe a half-written or overwritten buffer.  Pass `sync_after_replay=False` to pipeline replays and
-    synchronize yourself before reading."""
+    The stale loss of r03-r04, root-caused in r05: the step was always right, the LOSS TENSOR was not
+    rewritten.  `F.mse_loss` / `.mean()` over more than ~64 k elements is ATen's multi-block reduction: it zeroes a semaphore array with
+    hipMemsetAsync (a MEMSET node in the captured graph) and the last block to finish writes the result.  On ROCm 7.x a memset node is
+    not reliably ordered with the kernel nodes around it — even in this strictly linear chain (262 nodes, 261 edges, one memset:
+    tools/dbg_graph_topology.py) — so the reduction sometimes starts on the previous replay's count, no block is "the last one" and the
+    output keeps its old value (5-9 stale losses in 12 replays with the batched re-pack at the top of the graph, ~3 in 20 before it;
+    a loss reduced in two single-block stages was never stale; tools/dbg_replay_stale_loss.py).  Not reproducible with torch kernels
+    alone (tools/repro_graph_memset.py).  Fix: after capture every MEMSET node of the graph is rewritten as a kernel node
+    (mphip_graph_memsets_to_kernels, the same cure as for the library's own memsets above); `memset_nodes_replaced` counts them.
+    Independently `__call__` waits for the device after the replay by default and returns a private copy of the loss
+    (`sync_after_replay=True`: ~20 us on a step of several ms); pass False to pipeline replays and synchronize yourself before reading."""
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
                  example_inputs: Dict[str, torch.Tensor], warmup: int = 3, sync_after_replay: bool = True, batched_packs: Optional[bool] = None):
@@ -261,7 +265,9 @@ class GraphedTrainStep:
                         if isinstance(v, torch.Tensor):
                             v.zero_()
         ops.invalidate_packs()
-        self.graph = torch.cuda.CUDAGraph()
+        # keep_graph: the captured hipGraph_t stays reachable (raw_cuda_graph()) and is instantiated by hand below, after its MEMSET
+        # nodes were rewritten as kernel nodes (see the class docstring; MPHIP_GRAPH_MEMSET_FIX=0: dev A/B, leaves them)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
         optimizer.zero_grad(set_to_none=True)
         for v in self.static_in.values():
             v.grad = None
@@ -278,6 +284,7 @@ class GraphedTrainStep:
             self.static_loss = loss_fn(model, **self.static_in)
             self.static_loss.backward()
             optimizer.step()
+        self.memset_nodes_replaced = ops.finish_graph_capture(self.graph)
 
     def __call__(self, **inputs) -> torch.Tensor:
         from . import ops

@@ -79,6 +79,33 @@ def test_conv3d_bwd_weight(dev, ops, shape, dy_mag):
     assert rel_err(dw, wt.grad) < 2e-5     # f16x3 (falls back to the fp32 kernel where unsupported)
 
 
+@pytest.mark.parametrize("shape", [(2, 96, 96, 4, 16, 16), (1, 96, 192, 2, 8, 8), (2, 40, 72, 3, 12, 16), (1, 192, 96, 8, 32, 32)])
+def test_conv3d_bwd_weight_half_products_follow_the_autocast_contract(dev, ops, shape):
+    """The autocast(float16) policy in the backward-weight direction (ops.half_products -> conv_bwd_weight_f16x3_kernel<true>): one f16
+    product per multiply, fp32 accumulation — what ATen's autocast gives the reference's conv backward (train.py:188).  Reference: the
+    same product with both operands rounded to f16 (x at its power-of-two operand scale, dy at grad_prep's: scaling by a power of two
+    commutes with the rounding inside the f16 range), accumulated in float64.  Bar: 3e-3 of max|dW| — f16-operand rounding, not more;
+    and the result must differ from the default three-product mode (the policy did switch kernels)."""
+    n, ci, co, d, h, w = shape
+    x = R.seeded_tensor((n, ci, d, h, w), 41, scale=1.5)
+    dy = R.seeded_tensor((n, co, d, h, w), 42)
+    xd, dyd = x.to(dev), dy.to(dev)
+    _, scale = ops.grad_prep(dyd, want_bias=False)
+    full = ops.conv3d_bwd_weight(xd, dyd, 3, scale, precision=1)
+    with ops.half_products(True):
+        half = ops.conv3d_bwd_weight(xd, dyd, 3, scale, precision=1)
+    again = ops.conv3d_bwd_weight(xd, dyd, 3, scale, precision=1)
+    assert torch.equal(full, again)                      # the flag is restored
+    x16, dy16 = x.half().double(), dy.half().double()   # (O(1) values: the kernels' power-of-two operand scales do not change the rounding)
+    wt = torch.zeros(co, ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv3d(x16, wt, None, padding=1).backward(dy16)
+    top = wt.grad.abs().max().item()
+    err = (half.cpu().double() - wt.grad).abs().max().item() / top
+    assert err < 3e-3, err
+    assert (full.cpu().double() - wt.grad).abs().max().item() / top < 3e-3    # (fp32-class result vs the f16-operand reference: same bar, looser side)
+    assert not torch.equal(half, full)
+
+
 @pytest.mark.parametrize("shape", [(2, 96, 96, 4, 16, 16, 3), (1, 192, 96, 2, 8, 8, 3), (1, 96, 192, 4, 8, 8, 1),
                                    (1, 40, 24, 3, 5, 7, 3)])
 @pytest.mark.parametrize("dy_mag", [1.0, 3e-8, 5e4])
@@ -780,6 +807,65 @@ def test_graph_replay_follows_the_input_range(dev, M):
         assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item()), (scale, le.item(), lg.item())
 
 
+def test_graphed_loss_is_fresh_when_the_loss_is_a_multi_block_reduction(dev, M):
+    """The r03-r04 "flaky graphed step", root-caused in r05: F.mse_loss over 196 608 elements is ATen's multi-block reduction, whose
+    semaphores are zeroed by hipMemsetAsync — a MEMSET node in the captured graph, which ROCm 7.x does not reliably order with the kernel
+    nodes around it: the reduction then finds the previous replay's count, no block is the last one and the loss tensor keeps its old
+    value (5-9 of 12 replays with the graph below before the fix; the parameters were always right).  GraphedTrainStep rewrites memset
+    nodes as kernel nodes (mphip_graph_memsets_to_kernels): every replay's loss must equal the eager step's — read WITHOUT trusting any
+    earlier value (alternating input scales make consecutive losses differ)."""
+    from megaportrait_hack_amd import training
+
+    sd = R.seeded_state_dict(R.g3d_shapes(96), 91, prefix="G3d.")
+
+    def mk():
+        g = M.G3d(96)
+        g.load_state_dict({k[len("G3d."):]: v for k, v in sd.items()})
+        return g.to(dev).train()
+
+    gt, ge = mk(), mk()
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 92).to(dev)
+    tgt = R.seeded_tensor((1, 96, 8, 16, 16), 93).to(dev)
+    loss_fn = lambda m, x: F.mse_loss(m(x), tgt)
+    opt_g, opt_e = torch.optim.SGD(gt.parameters(), lr=1e-3), torch.optim.SGD(ge.parameters(), lr=1e-3)
+    step = training.GraphedTrainStep(gt, loss_fn, opt_g, {"x": x}, warmup=2)
+    assert step.memset_nodes_replaced >= 1          # (the reduction's semaphore memset was in the capture)
+    seen = []
+    for i in range(12):
+        scale = (100.0, 1.0, 1.0, 100.0)[i % 4]
+        lg = step(x=x * scale)
+        le = training.train_step(ge, loss_fn, opt_e, {"x": x * scale})
+        assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item()), (i, scale, le.item(), lg.item(), seen)
+        seen.append(lg.item())
+    assert len(set(seen)) == len(seen)              # (every replay produced a new value: a stale read could not have passed by luck)
+    for a, b in zip(gt.parameters(), ge.parameters()):
+        assert torch.equal(a, b)
+
+
+def test_graph_memsets_to_kernels_on_a_plain_torch_graph(dev):
+    """mphip_graph_memsets_to_kernels through ops.finish_graph_capture on a graph the library has no kernel in: the one MEMSET node
+    (ATen's reduction semaphores) becomes a kernel node and the graph still computes the same values."""
+    from megaportrait_hack_amd import ops
+
+    x = torch.zeros(1 << 20, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            (x * 2.0).mean()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        out = (x * 2.0).mean()
+    assert ops.finish_graph_capture(g) == 1
+    for v in (3.0, 5.0, 0.5, 7.0):
+        x.fill_(v)
+        g.replay()
+        torch.cuda.synchronize()
+        assert abs(out.item() - 2.0 * v) < 1e-6 * v
+
+
 def test_autocast_inputs_are_computed_in_fp32(dev, M):
     """train.py:188 calls the generator under autocast: half-precision inputs / an enabled autocast region must not
     change what the HIP path computes (fp32), forward or backward."""
@@ -802,6 +888,35 @@ def test_autocast_inputs_are_computed_in_fp32(dev, M):
     assert x16.grad is not None and x16.grad.dtype == torch.float16
     with torch.no_grad(), torch.autocast(device_type="cuda", dtype=torch.float16):
         assert torch.equal(blk(x16), blk(x32))
+
+
+def test_g3d_backward_under_autocast_runs_the_half_product_kernels(dev, M):
+    """The autocast policy reaches the BACKWARD convs: Conv3dFn.forward runs with torch's autocast state off (custom_fwd casts its inputs),
+    so what it records is the library's thread-local flag set by G3d.forward's policy wrapper (ops.half_products_active) — r05 first read
+    torch's state there and the backward silently kept its three-product kernels.  Under autocast every conv weight gradient must
+    differ from the default mode's (other kernels ran) and stay a small perturbation of it: L2 error <= 0.1 of the norm — 15 convs deep,
+    every forward and backward product carries ~1e-3 of f16-operand rounding and GroupNorm re-normalises it; the first layer's weight
+    gradient, at the end of the backward chain, measured 4.6e-2.  (The per-kernel precision bars are the 3e-3 tests of each kernel.)"""
+    torch.manual_seed(3)
+    g = M.G3d(96).to(dev)
+    x = R.seeded_tensor((2, 96, 16, 32, 32), 91).to(dev)
+
+    def grads(autocast):
+        g.zero_grad(set_to_none=True)
+        with torch.autocast(device_type="cuda", dtype=torch.float16, enabled=autocast):
+            y = g(x)
+        y.square().mean().backward()
+        return {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None and p.dim() == 5 and p.shape[2] == 3}
+
+    full, half = grads(False), grads(True)
+    assert len(full) >= 14
+    for n in full:
+        assert not torch.equal(full[n], half[n]), n
+        rel = (half[n] - full[n]).norm().item() / max(full[n].norm().item(), 1e-30)
+        assert rel < 0.1, (n, rel)
+    again = grads(False)
+    for n in full:
+        assert torch.equal(full[n], again[n]), n      # (the flag does not leak out of the region)
 
 
 def test_distributed_data_parallel_wraps_the_hot_slice(dev, M):
