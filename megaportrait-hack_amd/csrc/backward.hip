@@ -262,6 +262,42 @@ gn_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ y, co
     if (dres) dres[i] = du;
 }
 
+// S % 4 == 0 (every tensor of the hot path): four consecutive elements of one (n,c) plane per thread — 16-byte loads / stores, one plane
+// lookup per thread instead of a 64-bit division per element; the same expression per element as gn_bwd_apply_kernel (same bits).
+// grid = (ceil(S / 1024), N * C)
+__global__ void __launch_bounds__(256)
+gn_bwd_apply4_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                     const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ w2,
+                     const float *__restrict__ ab, float *__restrict__ dx, float *__restrict__ dres, int C, int cpg, int S, int relu) {
+    const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    const int e = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    if (e >= S) return;
+    const int grp = n * (C / cpg) + c / cpg;
+    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+    const float ge = w2 ? gamma[c] * w2[c] : gamma[c];
+    const float a = ab[grp * 2], b = ab[grp * 2 + 1];
+    const size_t i = (size_t)plane * S + e;
+    const float4 g = *reinterpret_cast<const float4 *>(dy + i);
+    const float4 xv = *reinterpret_cast<const float4 *>(x + i);
+    float du[4] = {g.x, g.y, g.z, g.w};
+    if (relu) {
+        const float4 yv = *reinterpret_cast<const float4 *>(y + i);
+        du[0] = act_grad(du[0], yv.x, relu);
+        du[1] = act_grad(du[1], yv.y, relu);
+        du[2] = act_grad(du[2], yv.z, relu);
+        du[3] = act_grad(du[3], yv.w, relu);
+    }
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xh = (xs[k] - mean) * rstd;
+        o[k] = rstd * (ge * du[k] - a - xh * b);
+    }
+    *reinterpret_cast<float4 *>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres) *reinterpret_cast<float4 *>(dres + i) = make_float4(du[0], du[1], du[2], du[3]);
+}
+
 // AvgPool3d(2,2) backward: dx[2d+a][2h+b][2w+c] = dout[d][h][w] / 8
 __global__ void __launch_bounds__(256)
 avgpool2_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, size_t total) {
@@ -746,8 +782,13 @@ extern "C" int mphip_groupnorm_bwd_apply(const float *x, const float *y, const f
     MPHIP_REQUIRE(x && dy && stats && gamma && ab && dx && (!act || y), "groupnorm_bwd_apply: null pointer");
     MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd_apply: bad dims");
     const size_t total = (size_t)N * C * S;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, gamma,
-                       w2, ab, dx, dres, C, C / G, S, relu, total);
+    const bool aligned = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)(y ? y : x) | (uintptr_t)(dres ? dres : dx)) & 15) == 0;
+    if (S % 4 == 0 && S >= 512 && aligned && (size_t)N * C <= 65535)   // (tiny planes: the flat kernel fills its workgroups better)
+        hipLaunchKernelGGL(gn_bwd_apply4_kernel, dim3((unsigned)cdiv(S, 1024), (unsigned)(N * C)), dim3(256), 0, (hipStream_t)stream, x, y, dy,
+                           stats, gamma, w2, ab, dx, dres, C, C / G, S, relu);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, gamma,
+                           w2, ab, dx, dres, C, C / G, S, relu, total);
     return check_launch("groupnorm_bwd_apply");
 }
 

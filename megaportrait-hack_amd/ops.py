@@ -463,6 +463,12 @@ class PackTable:
         return cls(entries)
 
     def run(self) -> None:
+        for conv, attr, pc in self._entries:   # the table holds raw pointers: a parameter that moved (module.to(), a replaced Parameter) makes it stale
+            if conv.weight.data_ptr() != pc.weight.data_ptr():
+                raise RuntimeError("PackTable.run: a conv weight moved since the table was built (module.to() / a replaced Parameter); "
+                                   "build a new table with PackTable.from_module")
+        if not self._handle:
+            raise RuntimeError("PackTable.run: the table was closed")
         _lib.check(_lib.load().mphip_pack_table_run(self._handle, _stream()), "mphip_pack_table_run")
         for conv, attr, pc in self._entries:
             pc._table_token = _repack_token

@@ -686,7 +686,14 @@ def test_pack_table_rewrites_every_pack_bitwise(dev, M, ops):
     assert torch.equal(loss_t, loss_l)
     for a, b in zip(grads_t, grads_l):
         assert torch.equal(a, b)
+    # (3) a parameter that moved makes the table's raw pointers stale: refused, not silently packed from the old storage
+    conv0 = table._entries[0][0]
+    conv0.weight = torch.nn.Parameter(conv0.weight.detach().clone())
+    with pytest.raises(RuntimeError, match="moved since the table was built"):
+        table.run()
     table.close()
+    with pytest.raises(RuntimeError):
+        table.run()
 
 
 @pytest.mark.parametrize("batched", [True, False], ids=["one table run", "lazy packs"])
