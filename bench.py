@@ -474,7 +474,7 @@ def train_leg(dev, B=4, steps=10, warmup=3, autocast=False):
     """BASELINE config 3's per-GPU shard on the default line: one training step of the hot slice (forward + backward + SGD,
     eager launches) at B=4, 96x16x64x64.  Side measurement; `--mode train` is the full-featured version (hipGraph, N ranks).
     autocast: the forward runs inside torch.autocast(float16) like the reference's generator step (train.py:145,188) — the F(2,3) convs
-    (forward and bwd-data) then use one f16 product per multiply (include/mphip.h: mphip_conv3d_set_half_products)."""
+    (forward and bwd-data) and the 3x3x3 bwd-weight kernel then use one f16 product per multiply (include/mphip.h: mphip_conv3d_set_half_products)."""
     import torch.nn.functional as F
 
     from megaportrait_hack_amd import model as M, training
@@ -523,8 +523,8 @@ def train_leg(dev, B=4, steps=10, warmup=3, autocast=False):
             "launch": "one hipGraph per step (training.GraphedTrainStep)", "eager_ms_per_step": round(dt / steps * 1e3, 3),
             "workload": "GbaseHotSlice training step (forward + backward + SGD), BASELINE config 3's per-GPU shard; final_conv forward and "
                         "backward demand-driven (the final warp's sample boxes)",
-            "dtype": ("autocast(float16) policy: one f16 product per multiply (fp32 accumulate) in the F(2,3) convs (forward, bwd-data), f16x3 in bwd-weight "
-                      "and the other convs, fp32 everything else") if autocast else "f16x3 forward/backward convs, fp32 everything else"}
+            "dtype": ("autocast(float16) policy: one f16 product per multiply (fp32 accumulate) in the F(2,3) convs (forward, bwd-data) and the 3x3x3 "
+                      "bwd-weight kernel, f16x3 in the other convs, fp32 everything else") if autocast else "f16x3 forward/backward convs, fp32 everything else"}
 
 
 def train_mode(args, rank, world, dev, dist):
