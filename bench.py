@@ -366,7 +366,7 @@ def roofline_hbm(hot, inp, B):
     ("faithful") fields of this batch and for a smooth field that travels through the whole volume ("smooth": the
     stress case — the reference's fields only ever sample the 4^3 low corner).
     achieved = ALGORITHMIC bytes (K2 53.5 MB, K3 29.9 MB per frame) / time; `traffic` = counter bytes per launch from the
-    committed rocprofv3 --pmc passes (profiles/r02_pmc_warps.json, B=8), `counter_GBps` = traffic / this run's time."""
+    committed rocprofv3 --pmc passes (profiles/r05_pmc_warps.json, B=8), `counter_GBps` = traffic / this run's time."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_warps as BW
 
@@ -374,7 +374,7 @@ def roofline_hbm(hot, inp, B):
         w_s2c = hot.warp_generator_s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
     table = {"faithful": w_s2c, "smooth": BW.fields(B)["smooth"]}
     res = BW.measure(B, iters=20, quiet=True, field_override=table)
-    rec_, stale = pmc_record("r04_pmc_warps.json", ["warp.hip"])   # (counters are quoted only when stamped with this build's warp.hip)
+    rec_, stale = pmc_record("r05_pmc_warps.json", ["warp.hip"])   # (counters are quoted only when stamped with this build's warp.hip)
     pmc = rec_.get("kernels", {}) if rec_ else {}
     out = {}
     for key, rec in res.items():
