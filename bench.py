@@ -470,6 +470,31 @@ def fp32_exact(hot, inp, B, steps=10, warmup=2):
             "dtype": "f32 (v_mfma_f32_32x32x2_f32 everywhere)"}
 
 
+def eapp_tail_leg(dev, B=8, steps=10, warmup=3):
+    """Scope row f1: Eapp's 3-D tail (model.py:217-226, 271-290) — six ResBlock3D_Adaptive(96, 96) = twelve full-resolution
+    96->96 3x3x3 convs per frame on the appearance volume, the heaviest source-side piece of the generator — alone, random-init weights,
+    input resident in HBM.  Side measurement."""
+    from megaportrait_hack_amd import model as M
+
+    torch.manual_seed(0)
+    tail = M.Eapp3DTail().to(dev).eval()
+    x = torch.randn(B, 1536, 64, 64, device=dev)
+    with torch.no_grad():
+        for _ in range(warmup):
+            tail(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tail(x)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    flops = 12 * 2.0 * B * 65536 * 96 * 96 * 27
+    return {"value": round(B * steps / dt, 2), "unit": "frames/s", "ms_per_step": round(dt / steps * 1e3, 3), "batch": B, "steps": steps,
+            "algorithmic_tflops": round(flops * steps / dt / 1e12, 1),
+            "workload": "model.Eapp3DTail.forward on [B,1536,64,64] (= [B,96,16,64,64]): 6 x ResBlock3D_Adaptive(96,96), f16x3 F(2,3) convs, "
+                        "GroupNorm statistics from the conv epilogues"}
+
+
 def train_leg(dev, B=4, steps=10, warmup=3, autocast=False):
     """BASELINE config 3's per-GPU shard on the default line: one training step of the hot slice (forward + backward + SGD,
     eager launches) at B=4, 96x16x64x64.  Side measurement; `--mode train` is the full-featured version (hipGraph, N ranks).
@@ -861,6 +886,7 @@ def main():
             leg("roofline_hbm", roofline_hbm, hot, inp, B)
             if f16x3:
                 leg("fp32_exact", fp32_exact, hot, inp, B)
+            leg("eapp_3d_tail", eapp_tail_leg, dev, B)                           # scope row f1: the source side's 3-D tail
             leg("train_step", train_leg, dev)                                    # BASELINE config 3's per-GPU shard
             leg("train_step_autocast", train_leg, dev, autocast=True)           # ... under the reference's autocast(float16) policy
             leg("reenact_1x64", reenact_leg, dev, repeats=2, find=False)         # BASELINE config 5's per-GPU shard
