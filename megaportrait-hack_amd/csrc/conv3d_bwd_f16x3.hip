@@ -270,6 +270,11 @@ __global__ void __launch_bounds__(512)
 conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__restrict__ dy, const float *__restrict__ gscale,
                                 const float *__restrict__ x_range,
                                 float *__restrict__ slabs, int N, int Ci, int Co, int DHW, int tiles_per_split) {
+    // r05: the waves split the OUTPUT, not K.  Wave w owns the 32 x 32 tile (m, t) = (w / 3, w % 3) of the 96 x 96 block and walks all
+    // eight K-steps of a staged tile itself; the ninth tile (2, 2) is split by K-step over the eight waves and is the only one that needs
+    // a cross-wave sum.  (Until r04 every wave kept all nine accumulators for ONE K-step and the eight partial blocks were folded through
+    // LDS in eight serial read-add-write rounds: ~10 us of a launch whose workgroups see two tiles each — 60 us for 38 MB of operands.)
+    // 32 accumulator registers instead of 144 leave room to keep the next tile's global loads in flight under the MFMAs.
     __shared__ __attribute__((aligned(16))) _Float16 smem[4 * BF_A_PART];
     _Float16 *const As = smem;                  // dY [part][96][BF_AP]
     _Float16 *const Bs = smem + 2 * BF_A_PART;  // X  [part][96][BF_AP]
@@ -284,37 +289,41 @@ conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__rest
     const float dscale = gscale[0];
     float BF_X_SCALE, bf_x_unscale;  // the saved activation's own operand scale (its range descriptor)
     range_scale_block(x_range, BF_X_SCALE, bf_x_unscale);
-    f32x16 acc[3][3];
+    const int om = wave / 3, ot = wave % 3;   // this wave's own output tile: co rows om*32.., ci columns ot*32..
+    f32x16 acc, acc2;                         // own tile; this wave's K-step share of tile (2,2)
 #pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][t][r] = 0.0f;
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; acc2[r] = 0.0f; }
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    float4 va[2][3][2], vb[2][3][2];   // the staged tile's raw rows ([0: dY, 1: X][3 rows per thread][8 voxels]) and the next tile's, in flight
+    auto prefetch = [&](int tile, float4 (&va)[2][3][2]) __attribute__((always_inline)) {
         const int n = tile / tiles_per_sample, v0 = (tile % tiles_per_sample) * 128;
-        __syncthreads();
 #pragma unroll
-        for (int which = 0; which < 2; ++which) {  // 0: dY -> As, 1: X -> Bs; 96 channels x 16 rows of 8 voxels, 3 rows per thread
+        for (int which = 0; which < 2; ++which) {
             const float *src = which ? x : dy;
             const int C = which ? Ci : Co, c0 = which ? ci0 : co0;
-            const float scale = which ? BF_X_SCALE : dscale;
-            _Float16 *dst = which ? Bs : As;
-            float4 va[3][2];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int q = tid + i * 512, ch = q >> 4, grp = q & 15;
                 const bool ok = c0 + ch < C;
                 const float *p = src + (ok ? ((size_t)n * C + c0 + ch) * DHW + v0 + grp * 8 : 0);
-                va[i][0] = *reinterpret_cast<const float4 *>(p);
-                va[i][1] = *reinterpret_cast<const float4 *>(p + 4);
-                if (!ok) va[i][0] = va[i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
+                va[which][i][0] = *reinterpret_cast<const float4 *>(p);
+                va[which][i][1] = *reinterpret_cast<const float4 *>(p + 4);
+                if (!ok) va[which][i][0] = va[which][i][1] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
+    };
+    if (t_begin < t_end) prefetch(t_begin, va);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        __syncthreads();   // the previous tile's fragments are read
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {  // 0: dY -> As, 1: X -> Bs; 96 channels x 16 rows of 8 voxels, 3 rows per thread
+            const float scale = which ? BF_X_SCALE : dscale;
+            _Float16 *dst = which ? Bs : As;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const int q = tid + i * 512, ch = q >> 4, grp = q & 15;
-                const float v[8] = {va[i][0].x, va[i][0].y, va[i][0].z, va[i][0].w, va[i][1].x, va[i][1].y, va[i][1].z, va[i][1].w};
+                const float4 a = va[which][i][0], b = va[which][i][1];
+                const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
                 half8 hi, lo;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -328,39 +337,51 @@ conv_bwd_weight_k1_f16x3_kernel(const float *__restrict__ x, const float *__rest
             }
         }
         __syncthreads();
-        const int koff = wave * 16 + kb * 8;  // this wave's K-step of the tile
-        half8 bh[3], bl[3];
+        const bool more = tile + 1 < t_end;
+        if (more) prefetch(tile + 1, vb);   // in flight under the MFMAs below
+        const _Float16 *arow = As + (om * 32 + j) * BF_AP + kb * 8, *brow = Bs + (ot * 32 + j) * BF_AP + kb * 8;
 #pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            bh[t] = *reinterpret_cast<const half8 *>(Bs + (t * 32 + j) * BF_AP + koff);
-            bl[t] = *reinterpret_cast<const half8 *>(Bs + BF_A_PART + (t * 32 + j) * BF_AP + koff);
+        for (int ks = 0; ks < 8; ++ks) {   // the own tile: all eight K-steps of the staged tile, in order
+            const half8 ah = *reinterpret_cast<const half8 *>(arow + ks * 16);
+            const half8 al = *reinterpret_cast<const half8 *>(arow + ks * 16 + BF_A_PART);
+            const half8 bh = *reinterpret_cast<const half8 *>(brow + ks * 16);
+            const half8 bl = *reinterpret_cast<const half8 *>(brow + ks * 16 + BF_A_PART);
+            BF_MFMA3(acc, ah, al, bh, bl)
         }
+        {   // tile (2,2): K-step `wave`
+            const int koff = wave * 16 + kb * 8;
+            const half8 ah = *reinterpret_cast<const half8 *>(As + (64 + j) * BF_AP + koff);
+            const half8 al = *reinterpret_cast<const half8 *>(As + (64 + j) * BF_AP + koff + BF_A_PART);
+            const half8 bh = *reinterpret_cast<const half8 *>(Bs + (64 + j) * BF_AP + koff);
+            const half8 bl = *reinterpret_cast<const half8 *>(Bs + (64 + j) * BF_AP + koff + BF_A_PART);
+            BF_MFMA3(acc2, ah, al, bh, bl)
+        }
+        if (more) {
 #pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            const half8 ah = *reinterpret_cast<const half8 *>(As + (m * 32 + j) * BF_AP + koff);
-            const half8 al = *reinterpret_cast<const half8 *>(As + BF_A_PART + (m * 32 + j) * BF_AP + koff);
+            for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) { BF_MFMA3(acc[m][t], ah, al, bh[t], bl[t]) }
+                for (int b = 0; b < 3; ++b) { va[a][b][0] = vb[a][b][0]; va[a][b][1] = vb[a][b][1]; }
         }
     }
-    // combine the eight waves' partial sums in LDS — eight plain read-add-write rounds (LDS float atomics retire about
-    // one lane per cycle on gfx950: 74 k of them per workgroup cost more than the whole GEMM) — then one slab write
+    // the block's 96 x 96 sums in LDS: eight tiles straight from their owners, tile (2,2) as the ordered sum of the waves' shares
     __syncthreads();
-    float *sum = reinterpret_cast<float *>(smem);  // [96][96]
-    for (int w = 0; w < 8; ++w) {
-        if (wave == w) {
+    float *sum = reinterpret_cast<float *>(smem);       // [96][96]
+    float *part = sum + 96 * 96;                         // [8 waves][16 regs][64 lanes]
+    static_assert((96 * 96 + 8 * 16 * 64) * 4 <= 4 * BF_A_PART * 2, "LDS: combine region");
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int t = 0; t < 3; ++t)
-#pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        float *q = sum + (m * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kb) * 96 + t * 32 + j;
-                        *q = w == 0 ? acc[m][t][reg] : *q + acc[m][t][reg];
-                    }
-        }
-        __syncthreads();
+    for (int reg = 0; reg < 16; ++reg) {
+        sum[(om * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * kb) * 96 + ot * 32 + j] = acc[reg];
+        part[(wave * 16 + reg) * 64 + lane] = acc2[reg];
     }
+    __syncthreads();
+    for (int i = tid; i < 16 * 64; i += 512) {   // (reg, lane) of tile (2,2): waves 0..7 in order
+        const int reg = i >> 6, ln = i & 63;
+        float a = part[i];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) a += part[w * 1024 + i];
+        sum[(64 + (reg & 3) + 8 * (reg >> 2) + 4 * (ln >> 5)) * 96 + 64 + (ln & 31)] = a;
+    }
+    __syncthreads();
     const float unscale = gscale[1] * bf_x_unscale;
     float *slab = slabs + (size_t)blockIdx.z * Co * Ci;
     for (int i = tid; i < 96 * 96; i += 512) {
