@@ -344,6 +344,12 @@ int mphip_groupnorm_bwd_reduce(const float *x, const float *y, const float *dy, 
 int mphip_groupnorm_bwd_apply(const float *x, const float *y, const float *dy, const float *stats,
                               const float *gamma, const float *w2, const float *ab, float *dx, float *dres, int N,
                               int C, int S, int G, int act, void *stream);
+/* reduce + apply in two launches instead of three (ABI 13): the fold of the partial sums is re-derived by every apply workgroup for its
+ * own (frame, group) — same operation order, same bits as mphip_groupnorm_bwd_reduce + mphip_groupnorm_bwd_apply.  dres, w2 / beta / dw2 /
+ * db2 may be NULL (no residual branch; no second affine).                                                                          */
+int mphip_groupnorm_bwd(const float *x, const float *y, const float *dy, const float *stats, const float *gamma, const float *beta,
+                        const float *w2, float *dx, float *dres, float *dgamma, float *dbeta, float *dw2, float *db2, int N, int C, int S,
+                        int G, int act, void *workspace, size_t workspace_bytes, void *stream);
 int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream);
 size_t mphip_upsample_trilinear2_bwd_workspace_bytes(int NC, int D, int H, int W);
 /* workspace: three separable bandwidth passes (D, H, W); NULL: one gather pass that needs no scratch (slower on large tensors) */

@@ -76,6 +76,7 @@ SIGNATURES = {
     "mphip_groupnorm_bwd_workspace_bytes": (_sz, [_i, _i, _i]),
     "mphip_groupnorm_bwd_reduce": (_i, [_p] * 12 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_groupnorm_bwd_apply": (_i, [_p] * 9 + [_i] * 5 + [_p]),
+    "mphip_groupnorm_bwd": (_i, [_p] * 13 + [_i] * 5 + [_p, _sz, _p]),
     "mphip_upsample_nearest_bwd": (_i, [_p, _p] + [_i] * 7 + [_p]),
     "mphip_small_gemm": (_i, [_p] * 5 + [_i] * 3 + [ctypes.c_long] * 4 + [_p]),
     "mphip_warp_coords": (_i, [_p] * 5 + [_i] * 7 + [_p]),

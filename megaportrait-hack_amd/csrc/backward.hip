@@ -298,6 +298,115 @@ gn_bwd_apply4_kernel(const float *__restrict__ x, const float *__restrict__ y, c
     if (dres) *reinterpret_cast<float4 *>(dres + i) = make_float4(du[0], du[1], du[2], du[3]);
 }
 
+// ---- the fold folded into the apply (r05): mphip_groupnorm_bwd = reduce + ONE apply launch.  What gn_bwd_fold_kernel computed in a
+// launch of its own (32 launches of ~5 us in a training step of the slice) is a few dozen numbers per consumer: every apply workgroup
+// re-derives the (A, B) of its own (n, group) from the reduce pass's partial sums — cpg x chunks <= ~24 pairs, with the fold kernel's own
+// operation order (float-rounded per-(n,c) sums of double accumulations, then a double sum over the group's channels): same bits — and
+// one designated thread per channel writes dgamma / dbeta (/ dw2 / db2).
+__device__ __forceinline__ void gn_fold_s12(const float *__restrict__ partial, int p, int chunks, float &s1, float &s2) {
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < chunks; ++k) {
+        a += (double)partial[((size_t)p * chunks + k) * 2];
+        b += (double)partial[((size_t)p * chunks + k) * 2 + 1];
+    }
+    s1 = (float)a;
+    s2 = (float)b;
+}
+__device__ __forceinline__ void gn_fold_ab(const float *__restrict__ partial, const float *__restrict__ gamma, const float *__restrict__ w2,
+                                           int n, int g, int C, int cpg, int S, int chunks, float &A, float &B) {
+    const double inv = 1.0 / ((double)cpg * (double)S);
+    double a = 0.0, b = 0.0;
+    for (int k = 0; k < cpg; ++k) {
+        const int c = g * cpg + k;
+        float s1, s2;
+        gn_fold_s12(partial, n * C + c, chunks, s1, s2);
+        const double ge = (double)gamma[c] * (w2 ? (double)w2[c] : 1.0);
+        a += ge * (double)s1;
+        b += ge * (double)s2;
+    }
+    A = (float)(a * inv);
+    B = (float)(b * inv);
+}
+__device__ __forceinline__ void gn_fold_channel(const float *__restrict__ partial, const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                const float *__restrict__ w2, int c, int N, int C, int chunks, float *__restrict__ dgamma,
+                                                float *__restrict__ dbeta, float *__restrict__ dw2, float *__restrict__ db2) {
+    double a = 0.0, b = 0.0;
+    for (int n = 0; n < N; ++n) {
+        float s1, s2;
+        gn_fold_s12(partial, n * C + c, chunks, s1, s2);
+        a += (double)s1;
+        b += (double)s2;
+    }
+    const double w = w2 ? (double)w2[c] : 1.0;
+    dbeta[c] = (float)(w * a);
+    dgamma[c] = (float)(w * b);
+    if (w2) {
+        dw2[c] = (float)((double)gamma[c] * b + (double)beta[c] * a);
+        db2[c] = (float)a;
+    }
+}
+
+// vector form (S % 4 == 0, S >= 512): grid = (ceil(S / 1024), N * C); (n, group) is workgroup-uniform
+__global__ void __launch_bounds__(256)
+gn_bwd_apply4_fold_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                          const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+                          const float *__restrict__ w2, const float *__restrict__ partial, float *__restrict__ dx, float *__restrict__ dres,
+                          float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dw2, float *__restrict__ db2, int N, int C,
+                          int cpg, int S, int relu, int chunks) {
+    const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    if (blockIdx.x == 0 && n == 0 && threadIdx.x == 0) gn_fold_channel(partial, gamma, beta, w2, c, N, C, chunks, dgamma, dbeta, dw2, db2);
+    const int e = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    if (e >= S) return;
+    const int grp = n * (C / cpg) + c / cpg;
+    float a, b;
+    gn_fold_ab(partial, gamma, w2, n, c / cpg, C, cpg, S, chunks, a, b);
+    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+    const float ge = w2 ? gamma[c] * w2[c] : gamma[c];
+    const size_t i = (size_t)plane * S + e;
+    const float4 g = *reinterpret_cast<const float4 *>(dy + i);
+    const float4 xv = *reinterpret_cast<const float4 *>(x + i);
+    float du[4] = {g.x, g.y, g.z, g.w};
+    if (relu) {
+        const float4 yv = *reinterpret_cast<const float4 *>(y + i);
+        du[0] = act_grad(du[0], yv.x, relu);
+        du[1] = act_grad(du[1], yv.y, relu);
+        du[2] = act_grad(du[2], yv.z, relu);
+        du[3] = act_grad(du[3], yv.w, relu);
+    }
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xh = (xs[k] - mean) * rstd;
+        o[k] = rstd * (ge * du[k] - a - xh * b);
+    }
+    *reinterpret_cast<float4 *>(dx + i) = make_float4(o[0], o[1], o[2], o[3]);
+    if (dres) *reinterpret_cast<float4 *>(dres + i) = make_float4(du[0], du[1], du[2], du[3]);
+}
+
+// flat form (any S): one thread per element; the first C threads of the grid also write their channel's parameter gradients
+__global__ void __launch_bounds__(256)
+gn_bwd_apply_fold_kernel(const float *__restrict__ x, const float *__restrict__ y, const float *__restrict__ dy,
+                         const float *__restrict__ stats, const float *__restrict__ gamma, const float *__restrict__ beta,
+                         const float *__restrict__ w2, const float *__restrict__ partial, float *__restrict__ dx, float *__restrict__ dres,
+                         float *__restrict__ dgamma, float *__restrict__ dbeta, float *__restrict__ dw2, float *__restrict__ db2, int N, int C,
+                         int cpg, int S, int relu, int chunks, size_t total) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (size_t)C) gn_fold_channel(partial, gamma, beta, w2, (int)i, N, C, chunks, dgamma, dbeta, dw2, db2);
+    if (i >= total) return;
+    const size_t plane = i / S;
+    const int c = (int)(plane % C), n = (int)(plane / C);
+    const int grp = n * (C / cpg) + c / cpg;
+    float a, b;
+    gn_fold_ab(partial, gamma, w2, n, c / cpg, C, cpg, S, chunks, a, b);
+    const float mean = stats[grp * 2], rstd = stats[grp * 2 + 1];
+    const float du = relu ? act_grad(dy[i], y[i], relu) : dy[i];
+    const float xh = (x[i] - mean) * rstd;
+    const float ge = w2 ? gamma[c] * w2[c] : gamma[c];
+    dx[i] = rstd * (ge * du - a - xh * b);
+    if (dres) dres[i] = du;
+}
+
 // AvgPool3d(2,2) backward: dx[2d+a][2h+b][2w+c] = dout[d][h][w] / 8
 __global__ void __launch_bounds__(256)
 avgpool2_bwd_kernel(const float *__restrict__ dout, float *__restrict__ dx, int D, int H, int W, size_t total) {
@@ -790,6 +899,34 @@ extern "C" int mphip_groupnorm_bwd_apply(const float *x, const float *y, const f
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x, y, dy, stats, gamma,
                            w2, ab, dx, dres, C, C / G, S, relu, total);
     return check_launch("groupnorm_bwd_apply");
+}
+
+extern "C" int mphip_groupnorm_bwd(const float *x, const float *y, const float *dy, const float *stats, const float *gamma,
+                                   const float *beta, const float *w2, float *dx, float *dres, float *dgamma, float *dbeta, float *dw2,
+                                   float *db2, int N, int C, int S, int G, int act, void *workspace, size_t workspace_bytes, void *stream) {
+    const int relu = act;
+    MPHIP_REQUIRE(x && dy && stats && gamma && dx && dgamma && dbeta && (!act || y), "groupnorm_bwd: null pointer");
+    MPHIP_REQUIRE(!w2 || (beta && dw2 && db2), "groupnorm_bwd: the second affine needs beta, dw2 and db2");
+    MPHIP_REQUIRE(act >= 0 && act <= 2, "groupnorm_bwd: act must be 0 (none), 1 (ReLU) or 2 (tanh(ReLU))");
+    MPHIP_REQUIRE(N > 0 && C > 0 && S > 0 && G > 0 && C % G == 0, "groupnorm_bwd: bad dims");
+    const size_t need = mphip_groupnorm_bwd_workspace_bytes(N, C, S);
+    if (!workspace || workspace_bytes < need) {
+        set_error("groupnorm_bwd: workspace %zu bytes < required %zu", workspace_bytes, need);
+        return MPHIP_EWORKSPACE;
+    }
+    const int chunks = cdiv(S, GNB_CHUNK);
+    float *partial = (float *)workspace;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(N * C * chunks), dim3(256), 0, s, x, y, dy, stats, partial, C, C / G, S, relu, chunks);
+    const size_t total = (size_t)N * C * S;
+    const bool aligned = (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)dx | (uintptr_t)(y ? y : x) | (uintptr_t)(dres ? dres : dx)) & 15) == 0;
+    if (S % 4 == 0 && S >= 512 && aligned && (size_t)N * C <= 65535)
+        hipLaunchKernelGGL(gn_bwd_apply4_fold_kernel, dim3((unsigned)cdiv(S, 1024), (unsigned)(N * C)), dim3(256), 0, s, x, y, dy, stats, gamma,
+                           beta, w2, (const float *)partial, dx, dres, dgamma, dbeta, dw2, db2, N, C, C / G, S, relu, chunks);
+    else
+        hipLaunchKernelGGL(gn_bwd_apply_fold_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, x, y, dy, stats, gamma, beta, w2,
+                           (const float *)partial, dx, dres, dgamma, dbeta, dw2, db2, N, C, C / G, S, relu, chunks, total);
+    return check_launch("groupnorm_bwd");
 }
 
 extern "C" int mphip_avgpool2_bwd(const float *dout, float *dx, int NC, int D, int H, int W, void *stream) {

@@ -1012,14 +1012,19 @@ def groupnorm_bwd(x, y, dy, stats, gamma, groups: int, relu, want_res: bool, bet
     dbeta = torch.empty(c, dtype=torch.float32, device=dev)
     dw2 = torch.empty(c, dtype=torch.float32, device=dev) if w2 is not None else None
     db2 = torch.empty(c, dtype=torch.float32, device=dev) if w2 is not None else None
-    ab = torch.empty((n * groups, 2), dtype=torch.float32, device=dev)
-    _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2),
-                                              _ptr(dgamma), _ptr(dbeta), _ptr(dw2), _ptr(db2), _ptr(ab), n, c, s, groups, act,
-                                              _ptr(ws), ws_bytes, _stream()), "mphip_groupnorm_bwd_reduce")
     dx = torch.empty_like(x)
     dres = torch.empty_like(x) if want_res else None
-    _lib.check(lib.mphip_groupnorm_bwd_apply(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(w2), _ptr(ab), _ptr(dx),
-                                             _ptr(dres), n, c, s, groups, act, _stream()), "mphip_groupnorm_bwd_apply")
+    if _os.environ.get("MPHIP_GN_BWD_FUSED", "1") != "0":   # reduce + apply (the fold is re-derived inside the apply): two launches, same bits
+        _lib.check(lib.mphip_groupnorm_bwd(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2), _ptr(dx), _ptr(dres),
+                                           _ptr(dgamma), _ptr(dbeta), _ptr(dw2), _ptr(db2), n, c, s, groups, act, _ptr(ws), ws_bytes, _stream()),
+                   "mphip_groupnorm_bwd")
+    else:                                                    # (dev A/B and the bitwise reference of the fused entry: reduce + fold, then apply)
+        ab = torch.empty((n * groups, 2), dtype=torch.float32, device=dev)
+        _lib.check(lib.mphip_groupnorm_bwd_reduce(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(beta), _ptr(w2),
+                                                  _ptr(dgamma), _ptr(dbeta), _ptr(dw2), _ptr(db2), _ptr(ab), n, c, s, groups, act,
+                                                  _ptr(ws), ws_bytes, _stream()), "mphip_groupnorm_bwd_reduce")
+        _lib.check(lib.mphip_groupnorm_bwd_apply(_ptr(x), _ptr(y), _ptr(dy), _ptr(stats), _ptr(gamma), _ptr(w2), _ptr(ab), _ptr(dx),
+                                                 _ptr(dres), n, c, s, groups, act, _stream()), "mphip_groupnorm_bwd_apply")
     if w2 is not None:
         return dx, dgamma, dbeta, dres, dw2, db2
     return dx, dgamma, dbeta, dres

@@ -155,6 +155,30 @@ def test_conv3d_bwd_data_f23_kernel_vs_direct_and_exact_at_g3d_levels(dev, ops, 
     assert not torch.equal(f23, direct)          # (different kernels did run)
 
 
+@pytest.mark.parametrize("w2", [False, True], ids=["GroupNorm", "AdaptiveGroupNorm"])
+@pytest.mark.parametrize("shape", [(2, 96, 16, 32, 32), (4, 192, 8, 16, 16), (4, 768, 2, 8, 8), (3, 64, 4, 1, 1), (1, 64, 2, 5, 6)])
+def test_groupnorm_bwd_two_launches_equal_three(dev, ops, shape, w2, monkeypatch):
+    """mphip_groupnorm_bwd (reduce + an apply that re-derives the fold for its own (frame, group)) against the three-launch path
+    (reduce, fold, apply): every output — dx, dres, dgamma, dbeta, dw2, db2 — bit for bit, on planes of one and several reduce chunks,
+    the vector and the flat apply form, with and without AdaptiveGroupNorm's second affine."""
+    n, c = shape[0], shape[1]
+    x = R.seeded_tensor(shape, 131, scale=2.0, shift=0.3).to(dev)
+    dy = R.seeded_tensor(shape, 135).to(dev)
+    gamma = R.seeded_tensor((c,), 133, shift=1.0).to(dev)
+    beta = R.seeded_tensor((c,), 134).to(dev)
+    a2 = R.seeded_tensor((c,), 136, shift=1.0).to(dev) if w2 else None
+    b2 = R.seeded_tensor((c,), 137).to(dev) if w2 else None
+    st = ops.groupnorm_stats(x, 32, 1e-5)
+    y = ops.groupnorm_apply(x, st, gamma, beta, 32, w2=a2, b2=b2, relu=True)
+    outs = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MPHIP_GN_BWD_FUSED", mode)
+        outs[mode] = ops.groupnorm_bwd(x, y, dy, st, gamma, 32, True, True, beta=beta if w2 else None, w2=a2)
+    assert len(outs["1"]) == (6 if w2 else 4)
+    for i, (a, b) in enumerate(zip(outs["1"], outs["0"])):
+        assert torch.equal(a, b), (i, (a - b).abs().max().item())
+
+
 @pytest.mark.parametrize("relu,res", [(True, True), (True, False), (False, False)])
 @pytest.mark.parametrize("shape", [(2, 96, 4, 8, 8), (1, 64, 2, 5, 6)])
 def test_groupnorm_bwd(dev, ops, shape, relu, res):
