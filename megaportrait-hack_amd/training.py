@@ -179,13 +179,18 @@ class OverlappedGradReducer:
 
 
 def train_step(model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
-               inputs: Dict[str, torch.Tensor], group=None, reducer: Optional[OverlappedGradReducer] = None) -> torch.Tensor:
+               inputs: Dict[str, torch.Tensor], group=None, reducer: Optional[OverlappedGradReducer] = None,
+               pack_table=None) -> torch.Tensor:
     """zero_grad -> forward -> loss -> backward -> (gradient all-reduce when distributed) -> optimizer.step().
     `loss_fn(model, **inputs)` returns the scalar loss of this rank's shard.  With `reducer` the all-reduces run
     bucket by bucket underneath backward on pre-allocated flat gradient buffers; without, after backward
-    (allreduce_gradients)."""
+    (allreduce_gradients).  `pack_table` (ops.PackTable.from_module(model), built after one step has run): every conv weight
+    the step uses is re-packed in <= 5 launches at its top instead of two or three launches per weight at first use — the
+    distributed (eager) step's counterpart of what GraphedTrainStep captures; same bits."""
     import torch.distributed as dist
 
+    if pack_table is not None:
+        pack_table.run()
     if reducer is not None:
         reducer.prepare()
         loss = loss_fn(model, **inputs)

@@ -720,6 +720,31 @@ def test_pack_table_rewrites_every_pack_bitwise(dev, M, ops):
         table.run()
 
 
+def test_eager_train_step_with_a_pack_table_is_bitwise_the_lazy_one(dev, M, ops):
+    """training.train_step(pack_table=...): the eager (distributed) step with all re-packing batched at its top — same losses, same
+    parameters as the step that packs lazily, over three optimizer updates."""
+    from megaportrait_hack_amd import training
+
+    def build():
+        torch.manual_seed(13)
+        g = M.G3d(96).to(dev)
+        return g, torch.optim.SGD(g.parameters(), lr=1e-3, momentum=0.9)
+
+    x = R.seeded_tensor((1, 96, 8, 16, 16), 78).to(dev)
+    loss_fn = lambda m, x: m(x).square().mean()
+    (ga, oa), (gb, ob) = build(), build()
+    la = [training.train_step(ga, loss_fn, oa, {"x": x}).item()]
+    lb = [training.train_step(gb, loss_fn, ob, {"x": x}).item()]
+    table = ops.PackTable.from_module(ga)
+    for _ in range(3):
+        la.append(training.train_step(ga, loss_fn, oa, {"x": x}, pack_table=table).item())
+        lb.append(training.train_step(gb, loss_fn, ob, {"x": x}).item())
+    assert la == lb
+    for a, b in zip(ga.parameters(), gb.parameters()):
+        assert torch.equal(a, b)
+    table.close()
+
+
 @pytest.mark.parametrize("batched", [True, False], ids=["one table run", "lazy packs"])
 def test_graphed_train_step_packs_both_ways_agree(dev, M, batched):
     """training.GraphedTrainStep with the re-packing captured as one ops.PackTable run (default) or as the lazy per-conv packs (r01-r04):
