@@ -149,6 +149,28 @@ def test_ablated_build_is_marked_and_refused(lib, tmp_path):
         os.remove(variant)
 
 
+def test_pack_cache_rule_inside_and_outside_a_capture():
+    """ops.pack_is_current (the cache test of model._PackCache / autograd._bwd_pack): outside a repack_always region a matching key is
+    enough; inside one (a hipGraph capture) only a pack that a PackTable run of THAT region wrote counts — a pack made before the
+    capture, or by a table run of an earlier capture, must be re-made inside it."""
+    from megaportrait_hack_amd import ops
+
+    class Pack:
+        _table_token = -1
+
+    pc, key = Pack(), ("ptr", 3)
+    assert not ops.pack_is_current(None, key)
+    assert not ops.pack_is_current((("ptr", 2), pc), key)          # stale key
+    assert ops.pack_is_current((key, pc), key)
+    with ops.repack_always():
+        assert ops.repacking() and not ops.pack_is_current((key, pc), key)
+        pc._table_token = ops._repack_token                        # what PackTable.run() does
+        assert ops.pack_is_current((key, pc), key)
+    assert not ops.repacking() and ops.pack_is_current((key, pc), key)
+    with ops.repack_always():                                      # a later capture: the earlier table run does not count
+        assert not ops.pack_is_current((key, pc), key)
+
+
 def test_no_cpu_fallback():
     from megaportrait_hack_amd import model as M, ops
 
