@@ -39,7 +39,7 @@ extern "C" {
 
 /* ABI version of this header.  Bumped whenever an exported signature or a packed layout changes; mphip_version() returns the
  * value the LIBRARY was built with — compare the two after dlopen (the ctypes binding does, and refuses a mismatch). */
-#define MPHIP_ABI_VERSION 13
+#define MPHIP_ABI_VERSION 14
 int mphip_version(void);
 /* hipGraph hygiene (ABI 13).  On ROCm 7.x a MEMSET node of a captured hipGraph is not reliably ordered with its neighbouring kernel nodes
  * (observed twice: stale f16x3 pack headers, r03; a training step's loss that kept its previous value, r04-r05 — ATen's multi-block
@@ -47,6 +47,9 @@ int mphip_version(void);
  * node with the same bytes, predecessors and successors; *replaced (may be NULL) receives the count.  Call between capture and
  * instantiation.  Not stream-ordered; no effect on graphs without memset nodes.                                                        */
 int mphip_graph_memsets_to_kernels(void *graph, int *replaced);
+/* (ABI 14) MEMSET nodes `graph` still holds, child graphs included — the ones the rewrite above leaves alone (2-D memsets, element sizes
+ * other than 1/2/4 bytes, nodes inside child graphs).  Non-zero after a rewrite = the hazard is still there: the caller should warn.   */
+int mphip_graph_memset_nodes_left(void *graph, int *left);
 
 /* Build flags of the loaded library.  Bit 0: a DEVELOPMENT variant — at least one kernel was compiled with a timing-only ablation
  * (csrc/mphip_ablate.h) and computes wrong results by design; the product build returns 0 and the Python loader refuses anything else

@@ -122,6 +122,7 @@ SIGNATURES = {
     "mphip_conv3d_kernel_variant": (_i, [_i] * 8),
     "mphip_build_flags": (_i, []),
     "mphip_graph_memsets_to_kernels": (_i, [_p, ctypes.POINTER(ctypes.c_int)]),
+    "mphip_graph_memset_nodes_left": (_i, [_p, ctypes.POINTER(ctypes.c_int)]),
     "mphip_pack_table_create": (_i, [_p, _i, ctypes.POINTER(ctypes.c_void_p)]),
     "mphip_pack_table_run": (_i, [_p, _p]),
     "mphip_pack_table_destroy": (_i, [_p]),
@@ -133,7 +134,7 @@ _lib = None
 # The ABI version the SIGNATURES table above mirrors.  Checked against the library at load time, and against include/mphip.h by
 # tests/test_host.py — NOT read from the header at run time: a relocated / installed package ships libmphip.so without the repository's
 # include/ directory.
-EXPECTED_ABI_VERSION = 13
+EXPECTED_ABI_VERSION = 14
 
 
 def header_abi_version() -> int:

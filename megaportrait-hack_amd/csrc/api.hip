@@ -78,8 +78,10 @@ extern "C" int mphip_graph_memsets_to_kernels(void *graph_, int *replaced_out) {
         if (hipGraphMemsetNodeGetParams(node, &mp) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: hipGraphMemsetNodeGetParams failed"); return MPHIP_ELAUNCH; }
         if (mp.height > 1 || (mp.elementSize != 1 && mp.elementSize != 2 && mp.elementSize != 4)) continue;   // (2-D memsets: left alone)
         size_t np = 0, ns = 0;
-        (void)hipGraphNodeGetDependencies(node, nullptr, &np);
-        (void)hipGraphNodeGetDependentNodes(node, nullptr, &ns);
+        if (hipGraphNodeGetDependencies(node, nullptr, &np) != hipSuccess || hipGraphNodeGetDependentNodes(node, nullptr, &ns) != hipSuccess) {
+            mphip::set_error("graph_memsets_to_kernels: dependency counts");
+            return MPHIP_ELAUNCH;
+        }
         std::vector<hipGraphNode_t> preds(np), succs(ns);
         if (np && hipGraphNodeGetDependencies(node, preds.data(), &np) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: dependencies"); return MPHIP_ELAUNCH; }
         if (ns && hipGraphNodeGetDependentNodes(node, succs.data(), &ns) != hipSuccess) { mphip::set_error("graph_memsets_to_kernels: dependents"); return MPHIP_ELAUNCH; }
@@ -105,6 +107,34 @@ extern "C" int mphip_graph_memsets_to_kernels(void *graph_, int *replaced_out) {
     }
     if (replaced_out) *replaced_out = replaced;
     return MPHIP_OK;
+}
+
+// Counts the MEMSET nodes `graph` (and its child graphs) still holds: what mphip_graph_memsets_to_kernels left alone.
+static int count_memset_nodes(hipGraph_t graph, int depth, int *count) {
+    size_t n = 0;
+    if (hipGraphGetNodes(graph, nullptr, &n) != hipSuccess) return MPHIP_ELAUNCH;
+    std::vector<hipGraphNode_t> nodes(n);
+    if (n && hipGraphGetNodes(graph, nodes.data(), &n) != hipSuccess) return MPHIP_ELAUNCH;
+    for (hipGraphNode_t node : nodes) {
+        hipGraphNodeType type;
+        if (hipGraphNodeGetType(node, &type) != hipSuccess) return MPHIP_ELAUNCH;
+        if (type == hipGraphNodeTypeMemset) ++*count;
+        if (type == hipGraphNodeTypeGraph && depth < 8) {
+            hipGraph_t child;
+            if (hipGraphChildGraphNodeGetGraph(node, &child) != hipSuccess) return MPHIP_ELAUNCH;
+            const int rc = count_memset_nodes(child, depth + 1, count);
+            if (rc != MPHIP_OK) return rc;
+        }
+    }
+    return MPHIP_OK;
+}
+
+extern "C" int mphip_graph_memset_nodes_left(void *graph_, int *left) {
+    MPHIP_REQUIRE(graph_ && left, "graph_memset_nodes_left: null graph or null result");
+    *left = 0;
+    const int rc = count_memset_nodes((hipGraph_t)graph_, 0, left);
+    if (rc != MPHIP_OK) mphip::set_error("graph_memset_nodes_left: graph query failed (%s)", hipGetErrorString(hipGetLastError()));
+    return rc;
 }
 
 namespace mphip {

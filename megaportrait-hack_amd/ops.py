@@ -299,7 +299,15 @@ def finish_graph_capture(graph: "torch.cuda.CUDAGraph") -> int:
     leaves the memsets alone."""
     n = ctypes.c_int(0)
     if _os.environ.get("MPHIP_GRAPH_MEMSET_FIX", "1") != "0":
-        _lib.check(_lib.load().mphip_graph_memsets_to_kernels(graph.raw_cuda_graph(), ctypes.byref(n)), "mphip_graph_memsets_to_kernels")
+        lib, left = _lib.load(), ctypes.c_int(0)
+        _lib.check(lib.mphip_graph_memsets_to_kernels(graph.raw_cuda_graph(), ctypes.byref(n)), "mphip_graph_memsets_to_kernels")
+        _lib.check(lib.mphip_graph_memset_nodes_left(graph.raw_cuda_graph(), ctypes.byref(left)), "mphip_graph_memset_nodes_left")
+        if left.value:
+            import warnings
+
+            warnings.warn(f"finish_graph_capture: {left.value} MEMSET node(s) could not be rewritten as kernel nodes (2-D memsets, odd element "
+                          "sizes or child graphs); on ROCm 7.x they are not reliably ordered with their neighbours — results they guard "
+                          "(multi-block reductions) may be stale after a replay", RuntimeWarning, stacklevel=2)
     graph.instantiate()
     return n.value
 
@@ -427,13 +435,16 @@ class PackTable:
     lazy per-conv packs).  Build it AFTER one real step has run — `PackTable.from_module(model)` collects the forward packs
     (model._PackCache) and bwd-data packs (autograd._bwd_pack) that step created, with the precisions it used — then call `run()` at the
     top of every step, after the optimizer update and before the forward: it re-packs all of them from the current weights and
-    re-validates the module caches, so that the step's convs find their packs current.  Convs the warm-up step did not touch, or shapes
-    that later need another precision, fall back to the lazy path as before.  training.GraphedTrainStep does all of this by itself."""
+    re-validates the module caches, so that the step's convs find their packs current.  Convs the warm-up step did not touch fall back
+    to the lazy path as before; a precision a covered conv acquires later (a shape outside the fast kernel's tiling -> precision 0) is
+    dropped by every run and re-packed lazily from the current weights.  training.GraphedTrainStep does all of this by itself."""
 
     def __init__(self, entries):
         """entries: (conv module, cache attribute, PackedConv) triples; every PackedConv contributes the precisions it holds."""
         lib = _lib.load()
         self._entries = list(entries)
+        # the precisions each PackedConv held when the table was built = what a run re-packs; anything added later is NOT covered
+        self._covered = [frozenset(pc._packed) for _, _, pc in self._entries]
         jobs = []
         fwd_of = {}   # weight storage -> the forward f16x3 pack buffer of the same weight (its header is shared)
         for conv, attr, pc in self._entries:
@@ -470,7 +481,11 @@ class PackTable:
         if not self._handle:
             raise RuntimeError("PackTable.run: the table was closed")
         _lib.check(_lib.load().mphip_pack_table_run(self._handle, _stream()), "mphip_pack_table_run")
-        for conv, attr, pc in self._entries:
+        for (conv, attr, pc), covered in zip(self._entries, self._covered):
+            # a precision packed lazily AFTER the table was built (a ragged last batch falling back to precision 0,
+            # set_conv_precision) is not among the table's jobs: drop it so that packed() re-makes it from the current weights
+            for prec in [q for q in pc._packed if q not in covered]:
+                del pc._packed[prec]
             pc._table_token = _repack_token
             pc.weight = conv.weight.detach()
             pc.bias = None if (pc.transposed or conv.bias is None) else conv.bias.detach()

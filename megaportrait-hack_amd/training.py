@@ -226,11 +226,14 @@ class GraphedTrainStep:
     a loss reduced in two single-block stages was never stale; tools/dbg_replay_stale_loss.py).  Not reproducible with torch kernels
     alone (tools/repro_graph_memset.py).  Fix: after capture every MEMSET node of the graph is rewritten as a kernel node
     (mphip_graph_memsets_to_kernels, the same cure as for the library's own memsets above); `memset_nodes_replaced` counts them.
-    Independently `__call__` waits for the device after the replay by default and returns a private copy of the loss
-    (`sync_after_replay=True`: ~20 us on a step of several ms); pass False to pipeline replays and synchronize yourself before reading."""
+    `__call__` returns a private, stream-ordered copy of the loss (one small copy kernel on the replay's stream, no host wait), so replays
+    pipeline like eager steps and losses kept across steps do not alias.  `sync_after_replay=True` adds a device-wide wait after every
+    replay — r05's belt-and-braces default from before the root cause was known; it is the default only when the memset rewrite is
+    switched off (MPHIP_GRAPH_MEMSET_FIX=0)."""
 
     def __init__(self, model: torch.nn.Module, loss_fn: Callable[..., torch.Tensor], optimizer: torch.optim.Optimizer,
-                 example_inputs: Dict[str, torch.Tensor], warmup: int = 3, sync_after_replay: bool = True, batched_packs: Optional[bool] = None):
+                 example_inputs: Dict[str, torch.Tensor], warmup: int = 3, sync_after_replay: Optional[bool] = None,
+                 batched_packs: Optional[bool] = None):
         import copy
 
         from . import ops
@@ -240,7 +243,9 @@ class GraphedTrainStep:
                 raise ValueError(f"GraphedTrainStep: {type(optimizer).__name__} must be built with capturable=True to be "
                                  "captured in a hipGraph (its step counters live on the host otherwise); SGD works as is")
         self.model, self.optimizer = model, optimizer
-        self.sync_after_replay = sync_after_replay
+        if sync_after_replay is None:
+            sync_after_replay = os.environ.get("MPHIP_GRAPH_MEMSET_FIX", "1") == "0"
+        self.sync_after_replay = bool(sync_after_replay)
         self.static_in = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in example_inputs.items()}
         # the warm-up runs REAL steps (the allocator and the packed-weight caches must see the final shapes): parameters,
         # buffers and optimizer state are snapshotted and restored, so building the graph does not train the model
@@ -301,6 +306,5 @@ class GraphedTrainStep:
         self.graph.replay()
         ops.invalidate_packs()  # the replay rewrote the parameters without touching their version counters
         if self.sync_after_replay:
-            torch.cuda.synchronize()        # (see the class docstring: stream order alone did not cover the replay's trailing nodes)
-            return self.static_loss.detach().clone()
-        return self.static_loss
+            torch.cuda.synchronize()
+        return self.static_loss.detach().clone()   # stream-ordered after the replay; never the static tensor itself

@@ -51,6 +51,48 @@ def conv3d_f16_operands(x, w, b=None, padding=0):
     return y
 
 
+def pow2_operand_scale(max_abs: float, top: int) -> float:
+    """The power-of-two operand scale s of the split-f16 kernels: max|x| * s < 2^top (csrc/mphip_common.h scale_from_bits: top = 14 for
+    activations / gradients; csrc/mphip_f16x3.h weight_scale: top = 15 for weights).  All-zero or non-finite tensors: 1."""
+    if not (0.0 < max_abs < 3.0e38):
+        return 1.0
+    _, e = math.frexp(max_abs)          # max_abs = f * 2^e, f in [0.5, 1)
+    return 2.0 ** (top - e)
+
+
+def round_f16_at_scale(x: torch.Tensor, top: int = 14) -> torch.Tensor:
+    """x rounded to float16 AT its power-of-two operand scale, returned unscaled in float64: the operand a one-product (autocast) launch
+    of a direct-domain kernel multiplies (bwd-weight: x and dy).  Scaling by a power of two commutes with the rounding inside f16's
+    normal range, so this equals x.half() except for values the unscaled cast would flush into f16 subnormals."""
+    s = pow2_operand_scale(x.detach().abs().max().item(), top)
+    return (x.detach().float() * s).half().double() / s
+
+
+def conv3d_wino_f16_contract(x, w, b=None, padding=1):
+    """The arithmetic contract of the F(2,3) conv kernels under the autocast policy (mphip_conv3d_set_half_products), stated without any
+    implementation's accumulation order: k = 3, padding = 1, W even.  Along W the 3-tap filter runs in the Winograd F(2,3) domain; what
+    is rounded to float16 is the TRANSFORMED operand pair, exactly as the kernels do it —
+      input  (csrc/conv3d_f16x3_wino_pp.hip halo_write): t = Bt d on the scaled fp32 input (d0-d2, d1+d2, d2-d1, d1-d3, one fp32
+             operation each), then rne_f16(t);
+      filter (csrc/conv3d_f16x3.hip f16x3_pack_body): u = G g in double (g0, (g0+g1+g2)/2, (g0-g1+g2)/2, g2), scaled, rounded
+             double -> float -> f16;
+    the products are accumulated exactly (float64), the output transform At = [[1,1,1,0],[0,1,-1,-1]] and the unscale are exact, then the
+    bias.  A kernel that follows this contract differs from it only by its fp32 accumulation (~1e-6 of max|y|)."""
+    assert padding == 1 and w.shape[2:] == (3, 3, 3) and x.shape[-1] % 2 == 0
+    x, w = x.detach().float(), w.detach().float()
+    W = x.shape[-1]
+    sx = pow2_operand_scale(x.abs().max().item(), 14)
+    sw = pow2_operand_scale(w.abs().max().item(), 15)
+    xp = F.pad(x * sx, (1, 1))                                        # W halo; D / H are padded by the conv below
+    d = [xp[..., i:i + W:2] for i in range(4)]                         # d_i of output pair j = x[2j - 1 + i]
+    t = [d[0] - d[2], d[1] + d[2], d[2] - d[1], d[1] - d[3]]          # fp32, one rounding each
+    g = w.double()
+    u = [g[..., 0], 0.5 * (g[..., 0] + g[..., 1] + g[..., 2]), 0.5 * (g[..., 0] - g[..., 1] + g[..., 2]), g[..., 2]]
+    m = [F.conv3d(tp.half().double(), (up * sw).float().half().double().unsqueeze(-1), None, padding=(1, 1, 0)) for tp, up in zip(t, u)]
+    y = torch.stack([m[0] + m[1] + m[2], m[1] - m[2] - m[3]], dim=-1).flatten(-2) / (sx * sw)
+    return y if b is None else y + b.detach().double().view(1, -1, 1, 1, 1)
+
+
 def rotation_matrix(rotation_deg: torch.Tensor) -> torch.Tensor:
     """model.py:811-856 — Euler degrees (alpha,beta,gamma)=(x,y,z) -> R = Rx @ (Ry @ Rz)."""
     r = rotation_deg * (torch.pi / 180.0)

@@ -83,9 +83,10 @@ def test_conv3d_bwd_weight(dev, ops, shape, dy_mag):
 def test_conv3d_bwd_weight_half_products_follow_the_autocast_contract(dev, ops, shape):
     """The autocast(float16) policy in the backward-weight direction (ops.half_products -> conv_bwd_weight_f16x3_kernel<true>): one f16
     product per multiply, fp32 accumulation — what ATen's autocast gives the reference's conv backward (train.py:188).  Reference: the
-    same product with both operands rounded to f16 (x at its power-of-two operand scale, dy at grad_prep's: scaling by a power of two
-    commutes with the rounding inside the f16 range), accumulated in float64.  Bar: 3e-3 of max|dW| — f16-operand rounding, not more;
-    and the result must differ from the default three-product mode (the policy did switch kernels)."""
+    same product with both operands rounded to f16 AT their power-of-two operand scales (oracle.hotpath_ref.round_f16_at_scale: exactly
+    what the kernel multiplies — this kernel works in the direct domain, no transform), accumulated in float64.  THE GATE:
+    1e-4 of max|dW| — only the kernel's fp32 accumulation is left.  The default three-product result against the same reference at 3e-3
+    is the sanity bound beside it (f16-operand rounding, not more); and the policy must have switched kernels."""
     n, ci, co, d, h, w = shape
     x = R.seeded_tensor((n, ci, d, h, w), 41, scale=1.5)
     dy = R.seeded_tensor((n, co, d, h, w), 42)
@@ -96,12 +97,13 @@ def test_conv3d_bwd_weight_half_products_follow_the_autocast_contract(dev, ops, 
         half = ops.conv3d_bwd_weight(xd, dyd, 3, scale, precision=1)
     again = ops.conv3d_bwd_weight(xd, dyd, 3, scale, precision=1)
     assert torch.equal(full, again)                      # the flag is restored
-    x16, dy16 = x.half().double(), dy.half().double()   # (O(1) values: the kernels' power-of-two operand scales do not change the rounding)
+    x16, dy16 = R.round_f16_at_scale(x), R.round_f16_at_scale(dy)
     wt = torch.zeros(co, ci, 3, 3, 3, dtype=torch.float64, requires_grad=True)
     F.conv3d(x16, wt, None, padding=1).backward(dy16)
     top = wt.grad.abs().max().item()
     err = (half.cpu().double() - wt.grad).abs().max().item() / top
-    assert err < 3e-3, err
+    print(f"bwd-weight half products vs the f16-operand contract: {err:.2e} of max|dW| (gate 1e-4)")
+    assert err < 1e-4, err
     assert (full.cpu().double() - wt.grad).abs().max().item() / top < 3e-3    # (fp32-class result vs the f16-operand reference: same bar, looser side)
     assert not torch.equal(half, full)
 
@@ -720,6 +722,35 @@ def test_pack_table_rewrites_every_pack_bitwise(dev, M, ops):
         table.run()
 
 
+def test_pack_table_run_drops_precisions_it_does_not_cover(dev, M, ops):
+    """a PackedConv that acquires ANOTHER precision after the table was built — a ragged shape outside the f16x3
+    kernel's tiling falls back to precision 0 — must not keep serving that pack after a weight update: the table's run re-packs only its
+    own jobs, so it drops what it does not cover and packed() re-makes it lazily from the current weights."""
+    torch.manual_seed(9)
+    blk = M.ResBlock3D(96, 96).to(dev).eval()
+    x_fast = torch.randn(1, 96, 4, 16, 16, device=dev)       # f16x3 shapes: the table is built from these
+    x_odd = torch.randn(1, 96, 3, 5, 7, device=dev)          # not tileable: mphip_conv3d_supported -> precision 0
+    with torch.no_grad():
+        blk(x_fast)
+    table = ops.PackTable.from_module(blk)
+    pcs = [pc for _, _, pc in table._entries if pc.k == 3]
+    assert pcs and all(set(pc._packed) == {1} for pc in pcs)
+    with torch.no_grad():
+        blk(x_odd)                                            # lazily adds precision-0 packs of the OLD weights
+    assert all(0 in pc._packed for pc in pcs)
+    with torch.no_grad():
+        for p in blk.parameters():
+            p.mul_(1.7).add_(0.01)
+    table.run()
+    assert all(set(pc._packed) == {1} for pc in pcs), "uncovered precision survived a table run"
+    with torch.no_grad():
+        got = blk(x_odd)
+        ops.invalidate_packs()                                # fresh caches: the lazy path from the current weights
+        want = blk(x_odd)
+    assert torch.equal(got, want)
+    table.close()
+
+
 def test_eager_train_step_with_a_pack_table_is_bitwise_the_lazy_one(dev, M, ops):
     """training.train_step(pack_table=...): the eager (distributed) step with all re-packing batched at its top — same losses, same
     parameters as the step that packs lazily, over three optimizer updates."""
@@ -809,13 +840,20 @@ def test_graphed_train_step_matches_eager(dev, M):
         lg = step(x=x)                 # replay first, eager kernels of the other model right behind it
         le = training.train_step(eager, loss_fn, opt_e, {"x": x})
         assert abs(le.item() - lg.item()) <= 1e-5 * abs(le.item())
-    # the pipelined form: no wait inside __call__, the caller synchronizes before it reads the static buffer
-    step.sync_after_replay = False
-    lg = step(x=x)
-    le = training.train_step(eager, loss_fn, opt_e, {"x": x})
-    torch.cuda.synchronize()
-    assert lg.data_ptr() == step.static_loss.data_ptr() and abs(le.item() - lg.item()) <= 1e-5 * abs(le.item())
-    step.sync_after_replay = True
+    # the default since r06 is the pipelined form: no device-wide wait inside __call__, and the returned loss is a private,
+    # stream-ordered copy — two losses kept across replays do not alias the static buffer or each other
+    assert step.sync_after_replay is False
+    l1 = step(x=x)
+    e1 = training.train_step(eager, loss_fn, opt_e, {"x": x})
+    l2 = step(x=x)
+    e2 = training.train_step(eager, loss_fn, opt_e, {"x": x})
+    assert l1.data_ptr() != step.static_loss.data_ptr() and l1.data_ptr() != l2.data_ptr()
+    assert abs(e1.item() - l1.item()) <= 1e-5 * abs(e1.item()) and abs(e2.item() - l2.item()) <= 1e-5 * abs(e2.item())
+    assert l1.item() != l2.item()
+    step.sync_after_replay = True      # the belt-and-braces form still works
+    l3 = step(x=x)
+    e3 = training.train_step(eager, loss_fn, opt_e, {"x": x})
+    assert abs(e3.item() - l3.item()) <= 1e-5 * abs(e3.item())
     with torch.no_grad():
         assert rel_err(graphed(x), eager(x).cpu()) < 1e-5
 

@@ -339,12 +339,12 @@ HALF_CASES = [(1, 96, 96, 16, 64, 64), (8, 192, 192, 8, 32, 32), (2, 96, 192, 8,
 def test_conv3d_half_products_follow_the_autocast_contract(ops, _libmod, dev, case, monkeypatch):
     """The reference's generator step runs under torch.cuda.amp.autocast() (train.py:145,188): conv3d multiplies f16 operands and
     accumulates in fp32.  ops.half_products() switches the F(2,3) conv launches to that policy — ONE f16 product per multiply (the
-    transformed operands rounded to f16).  Oracle: oracle.hotpath_ref.conv3d_f16_operands (input and weight rounded to f16, exact
-    accumulation).  Bar, stated against THAT oracle (not the fp32 contract's 1e-3 max-abs): 3e-3 of max|y| — the kernel rounds t = Bx
-    and u = Gg instead of x and g (each f16-rounded once, like the oracle's operands), which moves an output by a few f16 ulps of the
-    operand scale, the distance two correct f16 implementations of one conv (direct vs Winograd, as cuDNN / MIOpen pick them) have; the
-    fp32-class result must be much closer to the float64 truth than either.  Outside the context nothing changes (bitwise), forward
-    and bwd-data."""
+    transformed operands rounded to f16).
+    THE GATE: oracle.hotpath_ref.conv3d_wino_f16_contract — the kernel's own arithmetic contract (t = Bt x in fp32 and
+    u = G g in double, each rounded to f16 once, exact accumulation): <= 2e-5 of max|y|, i.e. nothing but the kernel's fp32 accumulation
+    is left — a wrong tap, position or transform weighted 1/300 fails it.  Beside it, as a sanity bound only: 3e-3 of max|y| against
+    conv3d_f16_operands (x and g rounded instead of t and u — the distance two correct f16 implementations of one conv, direct vs
+    Winograd, have).  Outside the context nothing changes (bitwise), forward and bwd-data."""
     N, Ci, Co, D, H, W = case
     monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
     lib = _libmod.load()
@@ -361,10 +361,14 @@ def test_conv3d_half_products_follow_the_autocast_contract(ops, _libmod, dev, ca
         half = ops.conv3d(xd, pc, precision=1)
     again = ops.conv3d(xd, pc, precision=1)
     scale = truth.abs().max().item()
+    contract = R.conv3d_wino_f16_contract(x, wt, bias)
+    e_gate = maxabs(half, contract) / scale
     e_half, e_full, e_oracle = maxabs(half, want) / scale, maxabs(full, truth) / scale, maxabs(want, truth) / scale
-    print(f"relative to max|y|: half products vs f16-operand oracle {e_half:.2e}; f16-operand oracle vs fp64 {e_oracle:.2e}; f16x3 vs fp64 {e_full:.2e}")
+    print(f"relative to max|y|: half products vs the F(2,3) f16 contract {e_gate:.2e} (gate 2e-5); vs the f16-operand oracle {e_half:.2e}; "
+          f"f16-operand oracle vs fp64 {e_oracle:.2e}; f16x3 vs fp64 {e_full:.2e}")
     assert torch.equal(full, again)                      # the flag is scoped
-    assert e_half < 3e-3 and e_full < 1e-5 and not torch.equal(half, full)
+    assert e_gate < 2e-5, e_gate
+    assert e_half < 3e-3 and e_full < 1e-5 and not torch.equal(half, full)   # (sanity bound, not the gate)
     assert maxabs(half, truth) / scale < 2 * e_oracle + 3e-3
     # bwd-data is the same kernel on the transposed pack
     if lib.mphip_conv3d_kernel_variant(N, Co, Ci, D, H, W, 3, 1) == 5:
@@ -375,14 +379,17 @@ def test_conv3d_half_products_follow_the_autocast_contract(ops, _libmod, dev, ca
         with ops.half_products(True):
             dx = ops.conv3d_bwd_data(dy.to(dev), pct, sc)
         want_dx = R.conv3d_f16_operands(dy, wt_t, None, padding=1)
-        assert maxabs(dx, want_dx) / want_dx.abs().max().item() < 3e-3
+        top = want_dx.abs().max().item()
+        assert maxabs(dx, R.conv3d_wino_f16_contract(dy, wt_t)) / top < 2e-5     # the gate
+        assert maxabs(dx, want_dx) / top < 3e-3                                  # sanity bound
 
 
 def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
     """model.G3d inside torch.autocast(float16) runs its F(2,3) convs with f16 operands (the reference's policy), everything else — and
     everything outside the region — as before.  Oracle: the restatement's G3d with conv3d_f16_operands on exactly the layers the library
-    reports the F(2,3) kernel for.  Bar: 1e-2 of max|y| against that oracle through the 15 stacked convs (each GroupNorm renormalises; a
-    wrong layer shows at >= 1e-1), and the region must actually change the result."""
+    reports the F(2,3) kernel for.  THE GATE: with those layers on conv3d_wino_f16_contract (the kernel's own rounding
+    points) the whole stack agrees to 1e-4 of max|y|; the r05 oracle (conv3d_f16_operands: x and g rounded, not t and u) stays beside it
+    at 1e-2 as a sanity bound.  The region must actually change the result."""
     from megaportrait_hack_amd import model as M
 
     monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
@@ -401,6 +408,15 @@ def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
 
     monkeypatch.setattr(R, "CONV3D", conv)
     want = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
+
+    def conv_contract(xx, w, b=None, padding=0):
+        n, ci, d, h, ww = xx.shape
+        if w.shape[2] == 3 and lib.mphip_conv3d_kernel_variant(n, ci, w.shape[0], d, h, ww, 3, 1) == 5:
+            return R.conv3d_wino_f16_contract(xx, w, b, padding=padding).to(xx.dtype)
+        return F.conv3d(xx, w, b, padding=padding)
+
+    monkeypatch.setattr(R, "CONV3D", conv_contract)
+    gate = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
     monkeypatch.setattr(R, "CONV3D", F.conv3d)
     truth = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
     with torch.no_grad():
@@ -409,10 +425,12 @@ def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
             half = g(x.to(dev))
         plain2 = g(x.to(dev))
     scale = truth.abs().max().item()
-    print(f"relative to max|y|: autocast G3d vs policy oracle {maxabs(half, want) / scale:.2e}; policy oracle vs fp64 {maxabs(want, truth) / scale:.2e}; default vs fp64 {maxabs(plain, truth) / scale:.2e}")
+    print(f"relative to max|y|: autocast G3d vs the F(2,3) f16 contract {maxabs(half, gate) / scale:.2e} (gate 1e-4); vs the f16-operand oracle "
+          f"{maxabs(half, want) / scale:.2e}; that oracle vs fp64 {maxabs(want, truth) / scale:.2e}; default vs fp64 {maxabs(plain, truth) / scale:.2e}")
     assert half.dtype == torch.float32 and torch.equal(plain, plain2)
     assert maxabs(plain, truth) / scale < 1e-4
-    assert maxabs(half, want) / scale < 1e-2 and not torch.equal(half, plain)
+    assert maxabs(half, gate) / scale < 1e-4
+    assert maxabs(half, want) / scale < 1e-2 and not torch.equal(half, plain)   # (sanity bound, not the gate)
 
 
 def test_conv3d_f16x3_winograd_propagates_non_finite(ops, _libmod, dev):

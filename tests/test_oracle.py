@@ -3,6 +3,7 @@ plain-C hotpath_c.c) against each other, against the golden fixtures produced by
 (tests/golden/, oracle/make_golden.py) and — in the build container only — against the imported
 reference.  This is what "pins" the oracle."""
 import json
+import math
 import os
 
 import numpy as np
@@ -201,3 +202,32 @@ def test_backward_oracle_pinned_by_reference_gradients(sd):
         want = torch.as_tensor(g[name]).double()
         err = (t.detach().double() - want).abs().max().item() / max(want.abs().max().item(), 1e-30)
         assert err < 1e-5, (name, err)
+
+
+def test_winograd_f16_contract_oracle_is_the_conv_when_nothing_rounds():
+    """oracle.hotpath_ref.conv3d_wino_f16_contract (the gate of the autocast-mode parity tests) pinned against ATen's conv3d:
+    on operands whose transformed values are exactly representable in f16 (small integers; weights that are multiples of 2) nothing is
+    rounded anywhere, so the contract must EQUAL the float64 conv — which fixes its transforms, tap order, pairing along W, padding and
+    unscale; on real-valued operands it must sit at f16-rounding distance from the truth (not closer: it does round; not farther: one
+    rounding per operand), and differ from the direct-domain f16 contract (it rounds t = Bt x and u = G g, not x and g)."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randint(-8, 9, (2, 5, 3, 4, 6), generator=g).float()
+    w = 2.0 * torch.randint(-4, 5, (7, 5, 3, 3, 3), generator=g).float()
+    b = torch.randint(-3, 4, (7,), generator=g).float()
+    assert torch.equal(R.conv3d_wino_f16_contract(x, w, b), F.conv3d(x.double(), w.double(), b.double(), padding=1))
+    x = R.seeded_tensor((1, 16, 4, 8, 8), 901, scale=1.7)
+    w = R.seeded_tensor((24, 16, 3, 3, 3), 902, scale=(16 * 27) ** -0.5)
+    truth = F.conv3d(x.double(), w.double(), None, padding=1)
+    top = truth.abs().max().item()
+    e_contract = (R.conv3d_wino_f16_contract(x, w) - truth).abs().max().item() / top
+    e_direct = (R.conv3d_f16_operands(x, w, None, padding=1) - truth).abs().max().item() / top
+    assert 2e-5 < e_contract < 3e-3 and 2e-5 < e_direct < 3e-3, (e_contract, e_direct)
+    assert (R.conv3d_wino_f16_contract(x, w) - R.conv3d_f16_operands(x, w, None, padding=1)).abs().max().item() / top > 2e-5
+    # operand scales: the kernels' rules (max|x| * s in [2^13, 2^14) for activations, [2^14, 2^15) for weights), powers of two
+    for m in (1e-8, 0.3, 1.0, 7.5, 3e4):
+        for top_bit in (14, 15):
+            s = R.pow2_operand_scale(m, top_bit)
+            assert 2.0 ** (top_bit - 1) <= m * s < 2.0 ** top_bit and math.log2(s) == round(math.log2(s))
+    tiny = R.seeded_tensor((64,), 903) * 1e-7                      # unscaled .half() would flush these into subnormals
+    r = R.round_f16_at_scale(tiny)
+    assert ((r - tiny.double()).abs() <= 2.0 ** -11 * tiny.double().abs() + 1e-30).all()
