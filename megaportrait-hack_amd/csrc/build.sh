@@ -10,10 +10,10 @@ objs=()
 pids=()
 bdir="${MPHIP_BUILD_DIR:-$here/build}"
 mkdir -p "$bdir"
-for f in api warp norm conv3d conv3d_f16x3 conv3d_f16x3_wino conv3d_f16x3_wino_pp mfma_sol backward conv3d_bwd_f16x3 flowfield plan; do
+for f in api warp norm conv3d conv3d_f16x3 conv3d_f16x3_wino conv3d_f16x3_wino_pp conv3d_f16x3_wino_bt mfma_sol backward conv3d_bwd_f16x3 flowfield plan; do
   extra=""
   # (the role-split conv places its fp32 staging arithmetic by hand: no SLP packing into v_pk_*_f32, see the file's header)
-  if [ "$f" == "conv3d_f16x3_wino_pp" ]; then extra="-fno-slp-vectorize"; fi
+  if [ "$f" == "conv3d_f16x3_wino_pp" ] || [ "$f" == "conv3d_f16x3_wino_bt" ]; then extra="-fno-slp-vectorize"; fi
   "$HIPCC" $FLAGS $extra -c "$here/$f.hip" -o "$bdir/$f.o" &
   pids+=($!)
   objs+=("$bdir/$f.o")

@@ -643,6 +643,8 @@ int f16x3_wino_saturation(unsigned long long *count, int reset) {   // (mphip_f1
     unsigned long long pp = 0;   // (the role-split kernel keeps its own counter: separate translation unit)
     if (f16x3_wino_pp_saturation(&pp, reset) != 0) return -1;
     *count += pp;
+    if (f16x3_wino_bt_saturation(&pp, reset) != 0) return -1;
+    *count += pp;
     if (reset) {
         const unsigned long long z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_f16x3_wino_saturated), &z, sizeof(z)) != hipSuccess) return -1;
@@ -700,6 +702,14 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
     static const int xcd_on = !(getenv("MPHIP_F16X3_XCD") && getenv("MPHIP_F16X3_XCD")[0] == '0');
     const char *pp_env = getenv("MPHIP_WINO_PP");   // dev: same-box A/B against the lockstep schedule (read per call: tools flip it in-process)
     const bool pp_on = !(pp_env && pp_env[0] == '0');
+    // MPHIP_WINO_PP: 0 the lockstep kernel (r04), 1 the role-split kernel (r05), 2 the big-tile kernel (r06: one wave per SIMD; bit-identical
+    // to 1).  The one-product (autocast) arithmetic exists on the role-split schedule only.
+    const bool bt_on = pp_env && pp_env[0] == '2' && !conv_half_products();
+    if (bt_on) {
+        f16x3_wino_bt_launch(grid, s, t0, t1, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb, in_affine, in_relu, x_range,
+                             tiles, xcd_on, tile_list, gn_part);
+        return check_launch("conv3d_fwd(f16x3, F(2,3), big tile)");
+    }
     if (pp_on) {   // the role-split schedule (conv3d_f16x3_wino_pp.hip): same arithmetic, same packed weights, same tile
         f16x3_wino_pp_launch(grid, s, t0, t1, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb, in_affine, in_relu, x_range,
                              tiles, xcd_on, tile_list, gn_part, conv_half_products());

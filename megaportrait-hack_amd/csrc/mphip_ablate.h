@@ -13,11 +13,14 @@
 //  PP_ABL=bitmask                                 | conv3d_f16x3_wino_pp.hip   | role-split F(2,3) conv: 1 no halo convert + LDS writes, 2 no halo loads, 4 no
 //                                                 |                            | weight DMA, 8 no epilogue, 16 no MFMAs, 32 no fragment reads, 128 no LDS stores,
 //                                                 |                            | 512 no output stores, 1024 12 of 18 MFMAs per step (the 2-D F(2x2,3x3) bound)
+//  BT_ABL=bitmask                                 | conv3d_f16x3_wino_bt.hip   | big-tile F(2,3) conv: 1 no halo convert + LDS writes, 2 no halo loads, 4 no weight
+//                                                 |                            | DMA, 8 no epilogue, 16 no MFMAs, 32 no fragment reads, 64 no per-step wait + barrier
 //  MPHIP_K2_ABL_NOSTAGE / _NOLOOP / _NOSTORE      | warp.hip                   | K2 without image staging / gather loop / output stores
 //  -----------------------------------------------+----------------------------+---------------------------------------------------------
 //  instrumentation, results unchanged (not "ablated"; slower):
 //  MPHIP_PROFILE_PHASES                           | conv3d_f16x3(.hip,_wino)   | per-phase cycle counters (mphip_debug_f16x3_profile)
 //  MPHIP_PP_PROFILE, PP_PRIO=n                    | conv3d_f16x3_wino_pp.hip   | per-phase wall stamps (mphip_debug_wino_pp_profile); s_setprio policy
+//  MPHIP_BT_PROFILE                               | conv3d_f16x3_wino_bt.hip   | cycles per wave: whole kernel / epilogues / prologue (mphip_debug_wino_bt_profile)
 //  MPHIP_WN_TRACE / MPHIP_K2_TRACE                | conv3d_f16x3_wino / warp   | per-tile / per-workgroup wall-clock traces
 //  MPHIP_F16X3_OLD_FRAGS, MPHIP_BUILTIN_DMA,      | conv3d_f16x3.hip,          | r01's fragment schedule; compiler-issued LDS-DMA; halo write in its own phase
 //    MPHIP_WN_NO_OVERLAP8                         | conv3d_f16x3_wino.hip      |   (same results, other schedules)
@@ -26,11 +29,14 @@
 #ifndef PP_ABL
 #define PP_ABL 0
 #endif
+#ifndef BT_ABL
+#define BT_ABL 0
+#endif
 
 #if defined(MPHIP_ABL_NOX) || defined(MPHIP_ABL_NOW) || defined(MPHIP_ABL_NOMFMA) || defined(MPHIP_ABL_TAPS18) || defined(MPHIP_ABL_X2) || \
     defined(MPHIP_ABL_LOMASK) || defined(MPHIP_WN_ABL_NOMFMA) || defined(MPHIP_WN_ABL_NODMA) || defined(MPHIP_WN_ABL_NOWRITE) ||            \
     defined(MPHIP_WN_ABL_NOEPI) || defined(MPHIP_WN_ABL_NOXLOAD) || defined(MPHIP_K2_ABL_NOSTAGE) || defined(MPHIP_K2_ABL_NOLOOP) ||         \
-    defined(MPHIP_K2_ABL_NOSTORE) || (PP_ABL != 0)
+    defined(MPHIP_K2_ABL_NOSTORE) || (PP_ABL != 0) || (BT_ABL != 0)
 #define MPHIP_ABLATED 1
 // (weak: every ablated translation unit may define it; api.hip tests for its presence)
 extern "C" __attribute__((weak, visibility("default"))) int mphip_ablated_build_marker = 1;

@@ -72,6 +72,13 @@ void f16x3_wino_pp_launch(dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1
                           const float *in_affine, int in_relu, const float *x_range, int tiles, int xcd_on, const int *tile_list,
                           float *gn_part, bool half_products);
 int f16x3_wino_pp_saturation(unsigned long long *count, int reset);
+// conv3d_f16x3_wino_bt.hip: the same contract (three-product arithmetic only) with one wave per SIMD and a 96 x 128 register tile;
+// results bit-identical to the role-split kernel's
+void f16x3_wino_bt_launch(dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1, const float *x, const _Float16 *slabs, const float *hdr,
+                          const float *bias, float *dst, int N, int Ci, int Co, int D, int H, int W, int cps, unsigned xb,
+                          const float *in_affine, int in_relu, const float *x_range, int tiles, int xcd_on, const int *tile_list,
+                          float *gn_part);
+int f16x3_wino_bt_saturation(unsigned long long *count, int reset);
 
 // api.hip: the calling thread's conv arithmetic policy (mphip_conv3d_set_half_products): true inside torch.autocast(float16) regions
 bool conv_half_products();

@@ -86,8 +86,9 @@ class Gbase(M._HotSliceRunner, nn.Module):
 
         fp16 (config 5's "fp16"): the reference's own reduced-precision policy is `torch.cuda.amp.autocast()` around the
         generator (train.py:188).  Here that region covers the PyTorch-ROCm 2D modules (Emtn and G2d's body are the whole
-        per-driver cost: G3d runs once per SOURCE); the HIP kernels keep computing in fp32 / f16x3 — their inputs are
-        cast back to fp32 at the boundary (model._f32), which is never less precise than what autocast would run."""
+        per-driver cost: G3d runs once per SOURCE).  The HIP kernels take fp32 at the boundary (model._f32) and keep fp32 between
+        kernels; inside the region G3d's F(2,3) convs follow the reference's autocast arithmetic — one f16 product per multiply, fp32
+        accumulation (model._autocast_policy) — everything else on the HIP side computes as without it."""
         from . import dp, ops
 
         if xs.shape[0] != 1:

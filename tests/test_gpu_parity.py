@@ -1241,7 +1241,9 @@ def test_bench_line_contract_on_one_gpu():
     assert abs(roof["achieved"] - roof["flops_per_launch"] / (roof["launch_ms"] * 1e-3) / 1e12) / roof["achieved"] < 1e-2
     one = line["one_in_flight"]
     # (the events of the timed region come from ONE of the two plans: its 2 of the 4 steps, two full-size launches each)
-    assert one["dominant_conv"]["launch_ms"] == roof["launch_ms"] and roof["in_two_batch_loop"]["launches_timed"] == 4
+    # the line's primary figures are those of the loop `value` was measured in; the one-stream (isolated) launch stands beside them
+    assert roof["in_two_batch_loop"]["launches_timed"] == 4 and roof["in_two_batch_loop"]["launch_ms"] == roof["launch_ms"]
+    assert one["dominant_conv"]["launch_ms"] == roof["isolated_one_stream"]["launch_ms"] <= roof["launch_ms"] * 1.05
     assert one["value"] > 0 and one["step_ms"]["min"] <= one["step_ms"]["median"] <= one["step_ms"]["max"]
     assert roof["demand_driven_launch"]["launches_timed"] == 2
     # the graded shape runs in the F(2,3) domain: 2 f16 FLOPs issued per algorithmic FLOP (3 split products x 2/3)
