@@ -56,17 +56,11 @@ __device__ __forceinline__ unsigned long long bt_memtime() {
 }
 #endif
 
-// Six LDS-DMA pieces of 16 bytes per lane (pp_dma3's contract: wave-uniform base, per-lane offsets, M0 written in the statement that
-// reads it, `s_nop 4` for a base that may just have been reloaded from a spill lane).
-__device__ __forceinline__ void bt_dma6(const void *base, const unsigned (&off)[6], unsigned lds) {
-    asm volatile("s_nop 4\n\t"
-                 "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %6\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %6\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %6\n\t"
-                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6"
-                 ::"v"(off[0]), "v"(off[1]), "v"(off[2]), "v"(off[3]), "v"(off[4]), "v"(off[5]), "s"(base), "s"(lds) : "memory", "scc");
+// One LDS-DMA piece of 16 bytes per lane: global `base` (wave-uniform) + `off` (per lane) -> LDS byte address `lds` + 16 * lane (pp_dma3's
+// contract: M0 written in the statement that reads it; `s_nop 4` for a base that may just have been reloaded from a spill lane).  One piece
+// per statement: the step hangs each behind its own MFMA (a VMEM instruction holds the wave's issue for tens of cycles).
+__device__ __forceinline__ void bt_dma1(const void *base, unsigned off, unsigned lds) {
+    asm volatile("s_nop 4\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(lds) : "memory");
 }
 
 template <int N, class F, int... I>
@@ -78,6 +72,9 @@ __device__ __forceinline__ void bt_for(F &&f) {
     bt_for_impl<N>(static_cast<F &&>(f), std::make_integer_sequence<int, N>{});
 }
 
+// FUSE: the input GroupNorm (+ ReLU) is applied while staging (in_affine != nullptr) — a compile-time constant: a run-time flag costs the
+// single wave a branch (two issue slots) in every conversion piece.
+template <bool FUSE>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                                const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
@@ -111,7 +108,6 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     const int nper = c_end - c_begin;
     const int nmine = (ntiles - j_first + (int)gridDim.x - 1) / (int)gridDim.x;   // tiles this workgroup walks
     const int per_total = nmine * nper;                                           // 16-channel periods it walks
-    const int s_total = per_total * 9;                                            // slabs it consumes
 
     auto period_at = [&](int tj, int chunk) -> PpPeriod {
         PpPeriod r;
@@ -139,7 +135,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     // two register sets, their loads ordered by hand (the counted wait before a step's barrier retires the loads of two steps ago).
     const int cp = tid & 3, srow = min(tid >> 2, PP_ROWS - 1);
     const int sdl = srow / PP_HH, shl = srow % PP_HH;
-    const bool fuse_in = in_affine != nullptr;   // workgroup-uniform
+    constexpr bool fuse_in = FUSE;
     const float relu_floor = in_relu ? 0.0f : -3.0e38f;
     int aff_n = -1;
     f32x4 xa0[2], xb0[2], xa1[2], xb1[2];   // [role]: channels 2cp / 2cp+1 of the half: voxels w0..w0+3, w0+4..w0+7
@@ -147,87 +143,109 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     float xmaxf_ = 0.0f;                    // max |scaled halo value| this thread staged (finite or Inf) ...
     bool xnan_ = false;                     // ... and whether it saw a NaN (v_max drops them)
     unsigned o_row[2] = {OOB, OOB};         // byte offset of (n, channel 2cp of the half, row, w0) of the unit being loaded, or OOB (padding rows)
-    auto halo_load = [&](const PpPeriod &s, auto ROLEc, auto PARTc) __attribute__((always_inline)) {
-        constexpr int role = decltype(ROLEc)::value, part = decltype(PARTc)::value;
+    // ---- staging micro-operations: each is one piece of <= ~7 instructions that the step hangs behind one MFMA -----------------------------
+    // (fused GroupNorm) per-role table values: (scale, shift) x operand scale S of channels 2cp / 2cp+1 for interior voxels [0..3] and for the
+    // left / right edge voxels [4..11] (zero outside the volume: padding must stay 0 — max(0*x + 0, floor) = 0 for both floors, no select)
+    float fcm[2][12];
+    float wt0 = 0.0f, wt1 = 0.0f;   // the output-pair write in flight: the two channels' transformed value, then its lo remainders
+    unsigned whv = 0;               // ... and the packed hi halves
+    auto halo_addr = [&](const PpPeriod &s, auto ROLEc) __attribute__((always_inline)) {
+        constexpr int role = decltype(ROLEc)::value;
+        const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
+        const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
+        o_row[role] = in ? (unsigned)((((long)s.n * Ci + s.chunk * 16 + role * 8 + 2 * cp) * DHW + (long)gd * HW + gh * W + s.w0) * 4) : OOB;
+    };
+    // LD 0 / 1: voxels w0..w0+3 / w0+4..w0+7 of channel 2cp (one 16-byte load each), 2 / 3: of channel 2cp+1, 4 / 5: the edge voxels w0-1, w0+8
+    // of channel 2cp / 2cp+1 (two 4-byte loads).  One statement each: a VMEM instruction holds the wave's issue while the CU's address unit
+    // works off the other waves' — the step spaces them two MFMAs apart.
+    auto halo_load = [&](const PpPeriod &s, auto ROLEc, auto LDc) __attribute__((always_inline)) {
+        constexpr int role = decltype(ROLEc)::value, ld = decltype(LDc)::value;
         if (BT_ABL & 2) { asm volatile("" : "+v"(xa0[role]), "+v"(xb0[role]), "+v"(xa1[role]), "+v"(xb1[role]), "+v"(xl0[role]), "+v"(xr0[role]), "+v"(xl1[role]), "+v"(xr1[role])); return; }
-        if constexpr (part == 0) {
-            const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
-            const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
-            o_row[role] = in ? (unsigned)((((long)s.n * Ci + s.chunk * 16 + role * 8 + 2 * cp) * DHW + (long)gd * HW + gh * W + s.w0) * 4) : OOB;
-        }
         const bool in = o_row[role] != OOB;
         const unsigned o = o_row[role], o1 = in ? o + chan_stride : OOB;
-        if constexpr (part == 0) {
-            pp_buf_load_2x4(rsrc, o, in ? o + 16u : OOB, xa0[role], xb0[role]);
-        } else if constexpr (part == 1) {
-            pp_buf_load_2x4(rsrc, o1, in ? o1 + 16u : OOB, xa1[role], xb1[role]);
-        } else {
+        if constexpr (ld == 0) pp_buf_load_1x4(rsrc, o, xa0[role]);
+        else if constexpr (ld == 1) pp_buf_load_1x4(rsrc, in ? o + 16u : OOB, xb0[role]);
+        else if constexpr (ld == 2) pp_buf_load_1x4(rsrc, o1, xa1[role]);
+        else if constexpr (ld == 3) pp_buf_load_1x4(rsrc, in ? o1 + 16u : OOB, xb1[role]);
+        else {
             const bool lft = in && s.w0 > 0, rgt = in && s.w0 + PP_TW < W;
-            pp_buf_load_4x1(rsrc, lft ? o - 4u : OOB, rgt ? o + 32u : OOB, lft ? o1 - 4u : OOB, rgt ? o1 + 32u : OOB, xl0[role], xr0[role], xl1[role],
-                            xr1[role]);
+            const unsigned ob = ld == 4 ? o : o1;
+            pp_buf_load_2x1(rsrc, lft ? ob - 4u : OOB, rgt ? ob + 32u : OOB, ld == 4 ? xl0[role] : xl1[role], ld == 4 ? xr0[role] : xr1[role]);
         }
     };
-    // (fused GroupNorm + ReLU) -> operand scale, in place; part 0: channel 2cp, 1: channel 2cp+1, 2: the four edge voxels; HALF 0 / 1: the
-    // first / second four voxels of a channel part (one piece behind one MFMA).  The scale S is a power of two: (x m + a) S == x (m S) + a S
-    // and max(., 0) S == max(. S, 0) bit for bit, so the fused path folds S into the table entries.
-    auto note = [&](float a, float b) {
+    auto note = [&](float a, float b) {   // range diagnostic: one v_max3 (|a|, |b|, m) and one unordered compare per two values
         xmaxf_ = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(a), __builtin_fabsf(b)), xmaxf_);
         xnan_ |= __builtin_isunordered(a, b);
     };
-    auto halo_convert = [&](const PpPeriod &s, auto ROLEc, auto PARTc, auto HALFc) __attribute__((always_inline)) {
-        constexpr int role = decltype(ROLEc)::value, part = decltype(PARTc)::value, half = decltype(HALFc)::value;
-        if (BT_ABL & 1) return;
-        if (fuse_in) {   // padding (rows / edge voxels outside the volume) must stay 0: its (scale, shift) pair is zeroed, and
-                         // max(0*x + 0, floor) = 0 for both floors — no select, no branch
+    // PREP 0: read the row's (scale, shift) pairs; 1 / 2: fold the operand scale S (a power of two: (x m + a) S == x (m S) + a S and
+    // max(., 0) S == max(. S, 0) bit for bit) and the padding masks into them
+    f32x4 fsc[2];
+    auto halo_prep = [&](const PpPeriod &s, auto ROLEc, auto Kc) __attribute__((always_inline)) {
+        constexpr int role = decltype(ROLEc)::value, k = decltype(Kc)::value;
+        if (!fuse_in || (BT_ABL & 1)) return;
+        if constexpr (k == 0) {
+            fsc[role] = *reinterpret_cast<const f32x4 *>(aff + (s.chunk * 16 + role * 8 + 2 * cp) * 2);   // (scale, shift) of channel 2cp, then of 2cp+1
+        } else {
             const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
             const float mid = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? x_scale : 0.0f;
-            const float rf = relu_floor * x_scale;
-            const float *const tb = aff + (s.chunk * 16 + role * 8 + 2 * cp) * 2;   // (scale, shift) of channel 2cp, then of 2cp+1
-            if constexpr (part < 2) {
-                const float2 sc = *reinterpret_cast<const float2 *>(tb + 2 * part);
-                const float m = sc.x * mid, a = sc.y * mid;
-                f32x4 &xv = part == 0 ? (half == 0 ? xa0[role] : xb0[role]) : (half == 0 ? xa1[role] : xb1[role]);
+            if constexpr (k == 1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) xv[i] = fmaxf(xv[i] * m + a, rf);
-            } else if constexpr (half == 0) {
+                for (int i = 0; i < 4; ++i) fcm[role][i] = fsc[role][i] * mid;
+            } else {
                 const float lft = s.w0 > 0 ? mid : 0.0f, rgt = s.w0 + PP_TW < W ? mid : 0.0f;
-                const float4 sc = *reinterpret_cast<const float4 *>(tb);
-                xl0[role] = fmaxf(xl0[role] * (sc.x * lft) + sc.y * lft, rf);
-                xr0[role] = fmaxf(xr0[role] * (sc.x * rgt) + sc.y * rgt, rf);
-                xl1[role] = fmaxf(xl1[role] * (sc.z * lft) + sc.w * lft, rf);
-                xr1[role] = fmaxf(xr1[role] * (sc.z * rgt) + sc.w * rgt, rf);
-            }
-        } else if constexpr (part < 2) {
-            f32x4 &xv = part == 0 ? (half == 0 ? xa0[role] : xb0[role]) : (half == 0 ? xa1[role] : xb1[role]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) xv[i] *= x_scale;
-        } else if constexpr (half == 0) {
-            xl0[role] *= x_scale; xr0[role] *= x_scale; xl1[role] *= x_scale; xr1[role] *= x_scale;
-        }
-        if constexpr (part < 2) {
-            const f32x4 &xv = part == 0 ? (half == 0 ? xa0[role] : xb0[role]) : (half == 0 ? xa1[role] : xb1[role]);
-            note(xv[0], xv[1]); note(xv[2], xv[3]);
-        } else if constexpr (half == 0) {
-            note(xl0[role], xr0[role]); note(xl1[role], xr1[role]);
+                for (int i = 0; i < 4; ++i) { fcm[role][4 + i] = fsc[role][i] * lft; fcm[role][8 + i] = fsc[role][i] * rgt; }
+            }
         }
     };
-    // output pair q, Winograd position pp of the row: F(2,3) input transform (fp32, after the scale), hi/lo split (hi = rne_f16(t),
-    // lo = rne_f16(t - hi) with t - hi as ONE v_fma_mix_f32), two half2 stores into the role's buffer — one piece behind one MFMA
-    auto halo_write = [&](auto ROLEc, auto Qc, auto PPc) __attribute__((always_inline)) {
-        constexpr int role = decltype(ROLEc)::value, q = decltype(Qc)::value, pp = decltype(PPc)::value;
+    // CONVERT chunk c (in place): 0-3: two voxels each of channel 2cp (xa[0,1], xa[2,3], xb[0,1], xb[2,3]); 4 / 5: the edge voxels of channel
+    // 2cp / 2cp+1; 6-9: channel 2cp+1
+    auto halo_convert = [&](auto ROLEc, auto Cc) __attribute__((always_inline)) {
+        constexpr int role = decltype(ROLEc)::value, c = decltype(Cc)::value;
+        if (BT_ABL & 1) return;
+        const float rf = relu_floor * x_scale;
+        if constexpr (c == 4 || c == 5) {
+            float &l = c == 4 ? xl0[role] : xl1[role], &r = c == 4 ? xr0[role] : xr1[role];
+            constexpr int ch = c - 4;
+            if (fuse_in) {
+                l = fmaxf(l * fcm[role][4 + 2 * ch] + fcm[role][5 + 2 * ch], rf);
+                r = fmaxf(r * fcm[role][8 + 2 * ch] + fcm[role][9 + 2 * ch], rf);
+            } else { l *= x_scale; r *= x_scale; }
+            note(l, r);
+        } else {
+            constexpr int ch = c >= 6 ? 1 : 0, qd = c >= 6 ? c - 6 : c;
+            f32x4 &xv = ch == 0 ? (qd < 2 ? xa0[role] : xb0[role]) : (qd < 2 ? xa1[role] : xb1[role]);
+            constexpr int e = 2 * (qd & 1);
+            if (fuse_in) {
+                xv[e] = fmaxf(xv[e] * fcm[role][2 * ch] + fcm[role][2 * ch + 1], rf);
+                xv[e + 1] = fmaxf(xv[e + 1] * fcm[role][2 * ch] + fcm[role][2 * ch + 1], rf);
+            } else { xv[e] *= x_scale; xv[e + 1] *= x_scale; }
+            note(xv[e], xv[e + 1]);
+        }
+    };
+    // WRITE stage k = 3 pp + st of output pair q: Winograd position pp of the row — st 0: the F(2,3) input transform (fp32, after the scale) of
+    // the two channels; st 1: hi = rne_f16(t), t - hi as ONE v_fma_mix_f32 each; st 2: lo = rne_f16(t - hi), two half2 stores into the
+    // role's buffer
+    auto halo_write = [&](auto ROLEc, auto Qc, auto Kc) __attribute__((always_inline)) {
+        constexpr int role = decltype(ROLEc)::value, q = decltype(Qc)::value, pp = decltype(Kc)::value / 3, st = decltype(Kc)::value % 3;
         if (BT_ABL & 1) { asm volatile("" :: "v"(xa0[role]), "v"(xb0[role]), "v"(xa1[role]), "v"(xb1[role]), "v"(xl0[role]), "v"(xr0[role]), "v"(xl1[role]), "v"(xr1[role])); return; }
-        unsigned char *const xw = smem + PP_LDS_X + role * PP_XBUF_B + srow * 64 + cp * 4;
-        auto v0 = [&](int i) -> float { return i == 0 ? xl0[role] : i <= 4 ? xa0[role][i - 1] : i <= 8 ? xb0[role][i - 5] : xr0[role]; };   // (i folds: q is a constant)
-        auto v1 = [&](int i) -> float { return i == 0 ? xl1[role] : i <= 4 ? xa1[role][i - 1] : i <= 8 ? xb1[role][i - 5] : xr1[role]; };
-        float t0, t1;
-        if constexpr (pp == 0) { t0 = v0(2 * q) - v0(2 * q + 2); t1 = v1(2 * q) - v1(2 * q + 2); }
-        else if constexpr (pp == 1) { t0 = v0(2 * q + 1) + v0(2 * q + 2); t1 = v1(2 * q + 1) + v1(2 * q + 2); }
-        else if constexpr (pp == 2) { t0 = v0(2 * q + 2) - v0(2 * q + 1); t1 = v1(2 * q + 2) - v1(2 * q + 1); }
-        else { t0 = v0(2 * q + 1) - v0(2 * q + 3); t1 = v1(2 * q + 1) - v1(2 * q + 3); }
-        const unsigned hv = pp_cvt_pk(t0, t1);
-        const unsigned lv = pp_cvt_pk(pp_sub_lo(hv, t0), pp_sub_hi(hv, t1));
-        *reinterpret_cast<unsigned *>(xw + pp * PP_XPOS_B + q * 16) = hv;
-        *reinterpret_cast<unsigned *>(xw + PP_XPART_B + pp * PP_XPOS_B + q * 16) = lv;
+        if constexpr (st == 0) {
+            auto v0 = [&](int i) -> float { return i == 0 ? xl0[role] : i <= 4 ? xa0[role][i - 1] : i <= 8 ? xb0[role][i - 5] : xr0[role]; };   // (i folds: q is a constant)
+            auto v1 = [&](int i) -> float { return i == 0 ? xl1[role] : i <= 4 ? xa1[role][i - 1] : i <= 8 ? xb1[role][i - 5] : xr1[role]; };
+            if constexpr (pp == 0) { wt0 = v0(2 * q) - v0(2 * q + 2); wt1 = v1(2 * q) - v1(2 * q + 2); }
+            else if constexpr (pp == 1) { wt0 = v0(2 * q + 1) + v0(2 * q + 2); wt1 = v1(2 * q + 1) + v1(2 * q + 2); }
+            else if constexpr (pp == 2) { wt0 = v0(2 * q + 2) - v0(2 * q + 1); wt1 = v1(2 * q + 2) - v1(2 * q + 1); }
+            else { wt0 = v0(2 * q + 1) - v0(2 * q + 3); wt1 = v1(2 * q + 1) - v1(2 * q + 3); }
+        } else if constexpr (st == 1) {
+            whv = pp_cvt_pk(wt0, wt1);
+            wt0 = pp_sub_lo(whv, wt0);
+            wt1 = pp_sub_hi(whv, wt1);
+        } else {
+            unsigned char *const xw = smem + PP_LDS_X + role * PP_XBUF_B + srow * PP_XROW_B + cp * 4;
+            const unsigned lv = pp_cvt_pk(wt0, wt1);
+            *reinterpret_cast<unsigned *>(xw + pp * PP_XPOS_B + q * PP_XPAIR_B) = whv;
+            *reinterpret_cast<unsigned *>(xw + PP_XPART_B + pp * PP_XPOS_B + q * PP_XPAIR_B) = lv;
+        }
     };
     auto load_aff = [&](int n, int first, int stride) {
         for (int i = first; i < Ci * 2; i += stride) aff[i] = in_affine[(size_t)n * Ci * 2 + i];
@@ -259,23 +277,24 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     }
     const unsigned char *const wbytes = reinterpret_cast<const unsigned char *>(wslabs) + (size_t)cot * nchunks * 9 * PP_SLAB_B;
     auto wchunk = [&](int chunk) -> const unsigned char * { return wbytes + (size_t)chunk * 9 * PP_SLAB_B; };
-    auto dma_slab = [&](auto SQc, const unsigned char *base) __attribute__((always_inline)) {   // slab SQ (0..8) of the period at `base`
-        constexpr int sq = decltype(SQc)::value;
+    auto dma_piece = [&](auto SQc, auto Kc, const unsigned char *base) __attribute__((always_inline)) {   // piece K (0..5) of slab SQ (0..8) of the period at `base`
+        constexpr int sq = decltype(SQc)::value, k = decltype(Kc)::value;
         constexpr unsigned V0 = sq == 4 ? 0u : ((2 * sq) % 9) * PP_SLAB_B + ((2 * sq) / 9) * PP_KGBLK_B;   // (tap, k-group) of item 2 sq
         constexpr unsigned slot = sq % PP_R;
         if (BT_ABL & 4) return;
-        const unsigned dst = lds0 + slot * PP_SLAB_B + (unsigned)p * 1024u;
-        if constexpr (sq == 4) bt_dma6(base + V0, dsrc4, dst);
-        else bt_dma6(base + V0, dsrc, dst);
+        bt_dma1(base + V0, sq == 4 ? dsrc4[k] : dsrc[k], lds0 + slot * PP_SLAB_B + (unsigned)(p + 4 * k) * 1024u);
+    };
+    auto dma_slab = [&](auto SQc, const unsigned char *base) __attribute__((always_inline)) {
+        bt_for<BT_PIECES>([&](auto K) { dma_piece(SQc, K, base); });
     };
 
-    // fragment bases (bytes).  X: the two k-groups of a step read items 2s and 2s+1 — one halo row apart (+64 B), one plane apart (tap
-    // (kd,2) -> (kd+1,0): +512 B), or (step 4) the last tap of buffer 0 and the first of buffer 1: three per-lane bases, the step's own
-    // offset and the plane (t * 640 B) are immediates
+    // fragment bases (bytes).  X: the two k-groups of a step read items 2s and 2s+1 — one halo row apart (+16 B), eight rows apart (tap
+    // (kd,2) -> (kd+1,0): +128 B), or (step 4) the last tap of buffer 0 and the first of buffer 1: three per-lane bases, the step's own
+    // offset and the plane (t * 160 B) are immediates
     const unsigned a_off = (unsigned)(((p * 2 + kgl) * PP_COT + j) * 16);
-    const unsigned b_lane = (unsigned)(PP_LDS_X + p * PP_XPOS_B + ((j >> 2) * 4 + (j & 3)) * 16);
-    const unsigned b_row = b_lane + (unsigned)kgl * 64u, b_plane = b_lane + (unsigned)kgl * 512u,
-                   b_buf = b_lane + (unsigned)kgl * (unsigned)(PP_XBUF_B - pp_rowoff(8) * 64);
+    const unsigned b_lane = (unsigned)(PP_LDS_X + p * PP_XPOS_B + (j & 3) * PP_XPAIR_B + (j >> 2) * PP_XROW_B);
+    const unsigned b_row = b_lane + (unsigned)kgl * PP_XROW_B, b_plane = b_lane + (unsigned)kgl * (8u * PP_XROW_B),
+                   b_buf = b_lane + (unsigned)kgl * (unsigned)(PP_XBUF_B - pp_rowoff(8) * PP_XROW_B);
     half8 ah[3], al[3], bh[4], bl[4];
     auto ld_a = [&](auto SPc, auto Mc, bool lo) __attribute__((always_inline)) -> half8 {   // weight fragment m of step sp
         constexpr int sp = decltype(SPc)::value, m = decltype(Mc)::value;
@@ -287,10 +306,10 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         constexpr int sp = decltype(SPc)::value, t = decltype(Tc)::value;
         if (BT_ABL & 32) { half8 z = {}; asm volatile("" : "+v"(z)); return z; }
         constexpr int I0 = 2 * sp, I1 = 2 * sp + 1;
-        constexpr unsigned off0 = (I0 / 9) * PP_XBUF_B + pp_rowoff(I0 % 9) * 64;
-        constexpr unsigned off1 = (I1 / 9) * PP_XBUF_B + pp_rowoff(I1 % 9) * 64;
-        static_assert(off1 - off0 == 64 || off1 - off0 == 512 || off1 - off0 == PP_XBUF_B - pp_rowoff(8) * 64, "k-group distance");
-        const unsigned char *const xb = smem + (off1 - off0 == 64 ? b_row : off1 - off0 == 512 ? b_plane : b_buf) + off0 + t * (PP_HH * 64);
+        constexpr unsigned off0 = (I0 / 9) * PP_XBUF_B + pp_rowoff(I0 % 9) * PP_XROW_B;
+        constexpr unsigned off1 = (I1 / 9) * PP_XBUF_B + pp_rowoff(I1 % 9) * PP_XROW_B;
+        static_assert(off1 - off0 == PP_XROW_B || off1 - off0 == 8 * PP_XROW_B || off1 - off0 == PP_XBUF_B - pp_rowoff(8) * PP_XROW_B, "k-group distance");
+        const unsigned char *const xb = smem + (off1 - off0 == PP_XROW_B ? b_row : off1 - off0 == 8 * PP_XROW_B ? b_plane : b_buf) + off0 + t * (PP_HH * PP_XROW_B);
         return *reinterpret_cast<const half8 *>(xb + (lo ? PP_XPART_B : 0));
     };
 
@@ -308,18 +327,15 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     dma_slab(std::integral_constant<int, 1>{}, wchunk(cur.chunk));
     dma_slab(std::integral_constant<int, 2>{}, wchunk(cur.chunk));
     bt_for<2>([&](auto R) {
-        halo_load(cur, R, std::integral_constant<int, 0>{});
-        halo_load(cur, R, std::integral_constant<int, 1>{});
-        halo_load(cur, R, std::integral_constant<int, 2>{});
+        halo_addr(cur, R);
+        bt_for<6>([&](auto L) { halo_load(cur, R, L); });
     });
     lds_dma_wait<0>();
     __builtin_amdgcn_sched_barrier(0);
     bt_for<2>([&](auto R) {
-        bt_for<3>([&](auto P) {
-            halo_convert(cur, R, P, std::integral_constant<int, 0>{});
-            halo_convert(cur, R, P, std::integral_constant<int, 1>{});
-        });
-        bt_for<4>([&](auto Q) { bt_for<4>([&](auto PP) { halo_write(R, Q, PP); }); });
+        bt_for<3>([&](auto K) { halo_prep(cur, R, K); });
+        bt_for<10>([&](auto C) { halo_convert(R, C); });
+        bt_for<4>([&](auto Q) { bt_for<12>([&](auto K) { halo_write(R, Q, K); }); });
     });
     lds_barrier();
     bt_for<3>([&](auto M) { al[decltype(M)::value] = ld_a(std::integral_constant<int, 0>{}, M, true); });
@@ -358,69 +374,90 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
                 using SN = std::integral_constant<int, sn>;
                 using R0 = std::integral_constant<int, 0>;
                 using R1 = std::integral_constant<int, 1>;
-                // role 1's output pairs are written in steps 0-3 of the period the data belongs to (`cur`); everything else stages `nxt`
-                const bool st1_on = gp > 0;           // (period 0's odd half was staged by the prologue)
-                // ---------------- P1(sp) = Wlo x Xhi; behind its MFMAs: Whi(sp), Xlo(sp), role 1's output pair sp ----------------
+                // ---- the step's staging work as a list of micro-operations mop(0..16), hung one each behind the MFMAs of P2 (slots 3-11)
+                // and P3 (slots 4-11).  Role 0 stages the even half of `nxt` into buffer 0: loads in step 0, table prep in 2, conversion in 3
+                // (its loads were retired by the wait of step 3), output pairs 0-3 written in steps 4-7.  Role 1 stages the odd half into
+                // buffer 1: loads in step 3, prep in 5, conversion in 6-7, pair 0 written in step 8 and pairs 1-3 in steps 0-2 of the period
+                // the data belongs to (there it is `cur`).  Nothing of this is conditional — a branch per piece costs the single wave two issue
+                // slots: in the last period `nxt` is a stale copy of a valid period (redundant loads, writes into buffers nobody reads again),
+                // and period 0's pairs 1-3 are re-written from the registers the prologue converted (identical bytes).
+                auto mop = [&](auto Kc) __attribute__((always_inline)) {
+                    constexpr int k = decltype(Kc)::value;
+                    if constexpr (sp == 3) {            // role 0's conversion (10 chunks)
+                        if constexpr (k < 10) halo_convert(R0{}, std::integral_constant<int, (k < 10 ? k : 0)>{});
+                    } else if constexpr (k < 12) {      // the step's output pair
+                        if constexpr (sp >= 4 && sp < 8) halo_write(R0{}, std::integral_constant<int, (sp >= 4 && sp < 8 ? sp - 4 : 0)>{}, Kc);
+                        else if constexpr (sp == 8) halo_write(R1{}, std::integral_constant<int, 0>{}, Kc);
+                        else if constexpr (sp < 3) halo_write(R1{}, std::integral_constant<int, (sp < 3 ? sp + 1 : 0)>{}, Kc);
+                    } else {
+                        constexpr int e = k - 12;       // 0..4
+                        if constexpr (sp == 2) { if constexpr (e < 3) halo_prep(nxt, R0{}, std::integral_constant<int, (e < 3 ? e : 0)>{}); }
+                        else if constexpr (sp == 5) { if constexpr (e < 3) halo_prep(nxt, R1{}, std::integral_constant<int, (e < 3 ? e : 0)>{}); }
+                        else if constexpr (sp == 6) halo_convert(R1{}, std::integral_constant<int, e>{});
+                        else if constexpr (sp == 7) halo_convert(R1{}, std::integral_constant<int, 5 + e>{});
+                    }
+                };
+                // ---- the step's vector-memory operations, ONE per slot and at least two MFMAs apart (the four waves reach the same slot
+                // together, and the CU's address unit needs ~16 cycles per 16-byte-per-lane instruction: a wave whose VMEM instruction waits
+                // for it cannot issue its MFMAs either).  seg 2 = P2, 3 = P3.  Slab sp+3's six pieces: P2 slots 3, 7, 11, P3 slots 5, 8, 11
+                // (past the stream's end they re-read a valid slab into a slot nobody reads again: no branch).  The halo loads of role 0
+                // (step 0) / role 1 (step 3): P2 slots 5, 9, P3 slots 4, 6, 9, 10.
+                const unsigned char *const wsrc = (sp + 3 < 9) ? wcur : wnxt;
+                auto vm = [&](auto SEGc, auto Ic) __attribute__((always_inline)) {
+                    constexpr int seg = decltype(SEGc)::value, i = decltype(Ic)::value;
+                    constexpr int piece = seg == 2 ? (i == 3 ? 0 : i == 7 ? 1 : i == 11 ? 2 : -1) : (i == 5 ? 3 : i == 8 ? 4 : i == 11 ? 5 : -1);
+                    constexpr int ld = seg == 2 ? (i == 5 ? 0 : i == 9 ? 1 : -1) : (i == 4 ? 2 : i == 6 ? 3 : i == 9 ? 4 : i == 10 ? 5 : -1);
+                    if constexpr (piece >= 0) dma_piece(std::integral_constant<int, (sp + 3) % 9>{}, std::integral_constant<int, (piece >= 0 ? piece : 0)>{}, wsrc);
+                    if constexpr (ld >= 0 && sp == 0) halo_load(nxt, R0{}, std::integral_constant<int, (ld >= 0 ? ld : 0)>{});
+                    if constexpr (ld >= 0 && sp == 3) halo_load(nxt, R1{}, std::integral_constant<int, (ld >= 0 ? ld : 0)>{});
+                };
+                // ---------------- P1(sp) = Wlo x Xhi; behind its first MFMAs: Whi(sp), Xlo(sp) — nothing behind the last five, so that no LDS
+                // operation is young when the wave reaches the barrier
                 bt_for<12>([&](auto I) {
                     constexpr int i = decltype(I)::value, m = i / 4, t = i % 4;
                     if (BT_ABL & 16) asm volatile("" ::"v"(al[m]), "v"(bh[t])); else acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[m], bh[t], acc[m][t], 0, 0, 0);
                     if constexpr (i < 3) ah[i] = ld_a(SP{}, I, false);
                     else if constexpr (i < 7) bl[i - 3] = ld_b(SP{}, std::integral_constant<int, (i >= 3 && i < 7 ? i - 3 : 0)>{}, true);
-                    else if constexpr (i < 11 && sp < 4) {
-                        if (st1_on) halo_write(R1{}, std::integral_constant<int, (sp < 4 ? sp : 0)>{}, std::integral_constant<int, (i >= 7 && i < 11 ? i - 7 : 0)>{});
-                    }
+                    else if constexpr (i == 8 && sp == 0) halo_addr(nxt, R0{});
+                    else if constexpr (i == 8 && sp == 3) halo_addr(nxt, R1{});
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                // ---------------- the step's wait + barrier: slab sp+1 (this wave's pieces, issued two steps ago) has landed; slab sp is dead
-                // Younger than those pieces and left in flight: the halo loads of the previous step, the six pieces of slab sp+2, and — in
-                // a tile's first two steps — the epilogue's stores.
-                constexpr int hl_[9] = {2, 2, 4, 0, 2, 2, 4, 0, 0};                   // halo loads after BARRIER(step): roles 0 (0-2) and 1 (4-6)
+                // ---------------- the step's wait + barrier: slab sp+1 (this wave's pieces, issued two steps ago) has landed; slab sp is dead.
+                // Younger than those pieces and left in flight: everything the previous step issued (its six pieces, its halo loads) and — in a
+                // tile's first two steps — the epilogue's stores.  (vmcnt's immediate is a constant; an under-estimate would only wait longer)
+                constexpr int hl_[9] = {8, 0, 0, 8, 0, 0, 0, 0, 0};                   // halo load instructions of a step: roles 0 (step 0) and 1 (step 3)
                 constexpr int HP = hl_[(sp + 8) % 9];
-                const bool issued_prev = gp * 9 + sp + 2 < s_total;                  // slab sp+2 was issued after the previous barrier
-                // (vmcnt's immediate is a constant: the handful of counts that occur are spelled out; an UNDER-estimate only waits longer,
-                //  so the last period — no halo loads in flight — and the stream's last steps take the smaller count)
                 if (BT_ABL & 64) {}
-                else if (!issued_prev) lds_dma_wait<0>();
-                else if (sp < 2 && epi_stores == 48) { if (nxt_ok) lds_dma_wait<BT_PIECES + 48 + HP>(); else lds_dma_wait<BT_PIECES + 48>(); }
-                else if (sp < 2 && epi_stores == 24) { if (nxt_ok) lds_dma_wait<BT_PIECES + 24 + HP>(); else lds_dma_wait<BT_PIECES + 24>(); }
-                else if (HP != 0 && nxt_ok) lds_dma_wait<BT_PIECES + HP>();
-                else lds_dma_wait<BT_PIECES>();
+                else if (sp < 2 && epi_stores == 48) lds_dma_wait<BT_PIECES + 48 + HP>();
+                else if (sp < 2 && epi_stores == 24) lds_dma_wait<BT_PIECES + 24 + HP>();
+                else lds_dma_wait<BT_PIECES + HP>();
                 if (sp == 1) epi_stores = 0;
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(BT_ABL & 64)) lds_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                // ---------------- issue: halo loads of this step (older than its pieces: retired by the wait of step sp+2), the fused-GroupNorm
-                // table of the next period's frame (step 0: its last reader was step 8's conversion, the next one is step 2's), slab sp+3
-                if constexpr (sp < 3) { if (nxt_ok) halo_load(nxt, R0{}, std::integral_constant<int, (sp < 3 ? sp : 0)>{}); }
-                else if constexpr (sp >= 4 && sp < 7) { if (nxt_ok) halo_load(nxt, R1{}, std::integral_constant<int, (sp >= 4 && sp < 7 ? sp - 4 : 0)>{}); }
-                if constexpr (sp == 0) {
-                    if (reload_aff && p == 0) dma_aff(nxt.n);
-                }
-                if (gp * 9 + sp + 3 < s_total) {
-                    if constexpr (sp + 3 < 9) dma_slab(std::integral_constant<int, (sp + 3) % 9>{}, wcur);
-                    else dma_slab(std::integral_constant<int, (sp + 3) % 9>{}, wnxt);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---------------- P2(sp) = Whi x Xhi; behind its MFMAs: Wlo(sp+1) and role 0's slice
-                //   step 2 / 3 / 4: normalise + scale part 0 / 1 / 2;  steps 4-7: output pair sp-4
+                // ---------------- P2(sp) = Whi x Xhi; behind its MFMAs: Wlo(sp+1), the fused-GroupNorm table of the next period's frame (step 0,
+                // one wave: its last reader was step 5's prep, the next one is step 2's; issued ahead of the step's pieces, so the wait of step
+                // 2 retires it), the six pieces of slab sp+3 — into the slot of slab sp — and mop 0-8
                 bt_for<12>([&](auto I) {
                     constexpr int i = decltype(I)::value, m = i / 4, t = i % 4;
                     if (BT_ABL & 16) asm volatile("" ::"v"(ah[m]), "v"(bh[t])); else acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bh[t], acc[m][t], 0, 0, 0);
-                    if constexpr (i < 3) al[i] = ld_a(SN{}, I, true);
-                    else if constexpr (sp >= 2 && sp <= 4 && (i == 3 || i == 4)) {
-                        if (nxt_ok) halo_convert(nxt, R0{}, std::integral_constant<int, (sp >= 2 && sp <= 4 ? sp - 2 : 0)>{}, std::integral_constant<int, (i == 4 ? 1 : 0)>{});
-                    } else if constexpr (sp >= 4 && sp < 8 && i >= 6 && i < 10) {
-                        if (nxt_ok) halo_write(R0{}, std::integral_constant<int, (sp >= 4 && sp < 8 ? sp - 4 : 0)>{}, std::integral_constant<int, (i >= 6 && i < 10 ? i - 6 : 0)>{});
+                    if constexpr (i < 3) {
+                        al[i] = ld_a(SN{}, I, true);
+                        if constexpr (sp == 0 && i == 2) { if (reload_aff && p == 0) dma_aff(nxt.n); }
+                    } else {
+                        vm(std::integral_constant<int, 2>{}, I);
+                        mop(std::integral_constant<int, (i >= 3 ? i - 3 : 0)>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
-                // ---------------- P3(sp) = Whi x Xlo; behind its MFMAs: Xhi(sp+1) and role 1's conversions (steps 6 / 7 / 8: part 0 / 1 / 2)
+                // ---------------- P3(sp) = Whi x Xlo; behind its MFMAs: Xhi(sp+1) and mop 9-16
                 bt_for<12>([&](auto I) {
                     constexpr int i = decltype(I)::value, m = i / 4, t = i % 4;
                     if (BT_ABL & 16) asm volatile("" ::"v"(ah[m]), "v"(bl[t])); else acc[m][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[m], bl[t], acc[m][t], 0, 0, 0);
                     if constexpr (i < 4) bh[i] = ld_b(SN{}, I, false);
-                    else if constexpr (sp >= 6 && (i == 5 || i == 6)) {
-                        if (nxt_ok) halo_convert(nxt, R1{}, std::integral_constant<int, (sp >= 6 ? sp - 6 : 0)>{}, std::integral_constant<int, (i == 6 ? 1 : 0)>{});
+                    else {
+                        vm(std::integral_constant<int, 3>{}, I);
+                        mop(std::integral_constant<int, (i >= 4 ? 9 + i - 4 : 0)>{});
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 });
@@ -440,9 +477,10 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
             if (nxt_ok) nxt = period_next(cur);
         }
 
-        // ---- output transform + epilogue: three rounds (one 32-channel row tile each); the four positions of a pair live in the four waves:
-        // each wave parks the units the others finish — plane pair 0 in the exchange region, plane pair 1 in X buffer 1 (dead here) — and
-        // finishes its own unit of both pairs.  Same per-element arithmetic, GroupNorm partials and store pattern as the role-split kernel.
+        // ---- output transform + epilogue: six rounds (32-channel row tile x plane pair) through the exchange region; the four positions of a
+        // pair live in the four waves: each wave parks the units the others finish and finishes its own.  (X buffer 1 is NOT a second exchange
+        // region here: role 1 has already written the next period's first output pair into it.)  Same per-element arithmetic, GroupNorm
+        // partials and store pattern as the role-split kernel.
 #ifdef MPHIP_BT_PROFILE
         const unsigned long long prof_e0 = bt_memtime();
 #endif
@@ -461,16 +499,17 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         const unsigned yoff = (unsigned)(((8 * p + 4 * kgl + (odd ? 2 : 0)) * DHW + (j >> 2) * W + 2 * (j & 2)) * 4);
         auto rounds = [&](auto Pc) __attribute__((always_inline)) {
             constexpr int P = decltype(Pc)::value;
+            float *const Ex = reinterpret_cast<float *>(smem + PP_LDS_EX);   // [position][slot 0..5][lane][4]
 #pragma unroll
             for (int m = 0; m < 3; ++m) {
                 // (the accumulators live in AGPRs; without this pin hipcc hoists the v_accvgpr_read of ALL 192 above the switch over the
                 //  wave's position and spills ~100 registers around every tile's epilogue — a round needs its own 64 only)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) asm volatile("" : "+a"(acc[m][t]));
-                // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of a column tile; wave P keeps unit P
+                const f32x4 bv = *reinterpret_cast<const f32x4 *>(smem + PP_LDS_BIAS + (m * 32 + 8 * P + 4 * kgl) * 4);
 #pragma unroll
                 for (int pair = 0; pair < 2; ++pair) {
-                    float *const Ex = reinterpret_cast<float *>(smem + (pair == 0 ? PP_LDS_EX : PP_LDS_X + PP_XBUF_B));   // [position][slot 0..5][lane][4]
+                    // park the units other waves finish: unit u = accumulator registers 4u..4u+3 of a column tile; wave P keeps unit P
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
@@ -481,12 +520,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
                                 const f32x4 v = {a[4 * u], a[4 * u + 1], a[4 * u + 2], a[4 * u + 3]};
                                 *reinterpret_cast<f32x4 *>(Ex + ((P * 6 + slot) * 64 + lane) * 4) = v;
                             }
-                }
-                lds_barrier();
-                const f32x4 bv = *reinterpret_cast<const f32x4 *>(smem + PP_LDS_BIAS + (m * 32 + 8 * P + 4 * kgl) * 4);
-#pragma unroll
-                for (int pair = 0; pair < 2; ++pair) {
-                    const float *const Ex = reinterpret_cast<const float *>(smem + (pair == 0 ? PP_LDS_EX : PP_LDS_X + PP_XBUF_B));
+                    lds_barrier();
                     float ssum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, qsum[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
                     for (int tt = 0; tt < 2; ++tt) {
@@ -550,8 +584,8 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
                             }
                         }
                     }
+                    lds_barrier();   // the region is rewritten by the next round
                 }
-                lds_barrier();   // the regions are rewritten by the next round / (buffer 1) by the next period's halo
             }
         };
         switch (p) {   // (wave-uniform)
@@ -600,12 +634,17 @@ void f16x3_wino_bt_launch(dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1
                           const float *bias, float *dst, int N, int Ci, int Co, int D, int H, int W, int cps, unsigned xb,
                           const float *in_affine, int in_relu, const float *x_range, int tiles, int xcd_on, const int *tile_list,
                           float *gn_part) {
-    if (t0 && t1)
-        hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_bt_kernel, grid, dim3(256), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps,
-                              xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
-    else
-        hipLaunchKernelGGL(conv3d_k3_f16x3_wino_bt_kernel, grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb,
-                           in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);
+#define BT_LAUNCH(F_)                                                                                                                          \
+    {                                                                                                                                          \
+        if (t0 && t1)                                                                                                                          \
+            hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_bt_kernel<F_>, grid, dim3(256), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, \
+                                  cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                                    \
+        else                                                                                                                                   \
+            hipLaunchKernelGGL(conv3d_k3_f16x3_wino_bt_kernel<F_>, grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb,      \
+                               in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                                                \
+    }
+    if (in_affine) BT_LAUNCH(true) else BT_LAUNCH(false)
+#undef BT_LAUNCH
 }
 
 }  // namespace mphip

@@ -243,7 +243,7 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
     // Split of t: hi = rne_f16(t), lo = rne_f16(t - hi) with t - hi as ONE v_fma_mix_f32 (f16 source, exact); the four positions are
     // written as four independent chains (stage by stage, not position by position): a LOAD phase has ~250 cycles for this slice, and the
     // dependent form (packed adds, f16 -> f32 conversions) took 430.
-    unsigned char *const xw = smem + PP_LDS_X + team * PP_XBUF_B + srow * 64 + cp * 4;
+    unsigned char *const xw = smem + PP_LDS_X + team * PP_XBUF_B + srow * PP_XROW_B + cp * 4;
     auto halo_write = [&](auto Qc) __attribute__((always_inline)) {
         constexpr int q = decltype(Qc)::value;
         if (PP_ABL & 1) return;
@@ -270,8 +270,8 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
             asm volatile("" ::"v"(hv[pp]));
             if constexpr (!SINGLE) asm volatile("" ::"v"(lv[pp]));
 #else
-            *reinterpret_cast<unsigned *>(xw + pp * PP_XPOS_B + q * 16) = hv[pp];
-            if constexpr (!SINGLE) *reinterpret_cast<unsigned *>(xw + PP_XPART_B + pp * PP_XPOS_B + q * 16) = lv[pp];
+            *reinterpret_cast<unsigned *>(xw + pp * PP_XPOS_B + q * PP_XPAIR_B) = hv[pp];
+            if constexpr (!SINGLE) *reinterpret_cast<unsigned *>(xw + PP_XPART_B + pp * PP_XPOS_B + q * PP_XPAIR_B) = lv[pp];
 #endif
         }
     };
@@ -322,11 +322,11 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
 
     // fragment bases (bytes)
     const unsigned a_off = (unsigned)(((p * 2 + kgl) * PP_COT + j) * 16);
-    // X: the two k-groups of a step read items 2s and 2s+1 — one halo row apart (+64 B), one plane apart (tap (kd,2) -> (kd+1,0): +512 B), or
+    // X: the two k-groups of a step read items 2s and 2s+1 — one halo row apart (+16 B), eight rows apart (tap (kd,2) -> (kd+1,0): +128 B), or
     // (step 4) the last tap of buffer 0 and the first of buffer 1: three per-lane bases, the step's own offset is an immediate
-    const unsigned b_lane = (unsigned)(PP_LDS_X + p * PP_XPOS_B + (((2 * team) * PP_HH + (j >> 2)) * 4 + (j & 3)) * 16);
-    const unsigned b_row = b_lane + (unsigned)kgl * 64u, b_plane = b_lane + (unsigned)kgl * 512u,
-                   b_buf = b_lane + (unsigned)kgl * (unsigned)(PP_XBUF_B - pp_rowoff(8) * 64);
+    const unsigned b_lane = (unsigned)(PP_LDS_X + p * PP_XPOS_B + (j & 3) * PP_XPAIR_B + ((2 * team) * PP_HH + (j >> 2)) * PP_XROW_B);
+    const unsigned b_row = b_lane + (unsigned)kgl * PP_XROW_B, b_plane = b_lane + (unsigned)kgl * (8u * PP_XROW_B),
+                   b_buf = b_lane + (unsigned)kgl * (unsigned)(PP_XBUF_B - pp_rowoff(8) * PP_XROW_B);
 
     PPROF_DECL;
     // ---- prologue: slabs 0 and 1 in flight, both halves of period 0 staged ------------------------------------------------------------
@@ -410,21 +410,21 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
                 __builtin_amdgcn_sched_barrier(0);
                 if (!(PP_ABL & 32) || gp == 0) {
                     constexpr int I0 = 2 * sp, I1 = 2 * sp + 1;
-                    constexpr unsigned off0 = (I0 / 9) * PP_XBUF_B + pp_rowoff(I0 % 9) * 64;
-                    constexpr unsigned off1 = (I1 / 9) * PP_XBUF_B + pp_rowoff(I1 % 9) * 64;
+                    constexpr unsigned off0 = (I0 / 9) * PP_XBUF_B + pp_rowoff(I0 % 9) * PP_XROW_B;
+                    constexpr unsigned off1 = (I1 / 9) * PP_XBUF_B + pp_rowoff(I1 % 9) * PP_XROW_B;
                     const unsigned char *const wsl = smem + (sp % PP_R) * PP_SLAB_B + a_off;
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         ah[m] = *reinterpret_cast<const half8 *>(wsl + m * 512);
                         if constexpr (!SINGLE) al[m] = *reinterpret_cast<const half8 *>(wsl + PP_WPART_B + m * 512);
                     }
-                    static_assert(off1 - off0 == 64 || off1 - off0 == 512 || off1 - off0 == PP_XBUF_B - pp_rowoff(8) * 64, "k-group distance");
-                    const unsigned char *const xb = smem + (off1 - off0 == 64 ? b_row : off1 - off0 == 512 ? b_plane : b_buf) + off0;
+                    static_assert(off1 - off0 == PP_XROW_B || off1 - off0 == 8 * PP_XROW_B || off1 - off0 == PP_XBUF_B - pp_rowoff(8) * PP_XROW_B, "k-group distance");
+                    const unsigned char *const xb = smem + (off1 - off0 == PP_XROW_B ? b_row : off1 - off0 == 8 * PP_XROW_B ? b_plane : b_buf) + off0;
                     bh[0] = *reinterpret_cast<const half8 *>(xb);
-                    bh[1] = *reinterpret_cast<const half8 *>(xb + PP_HH * 64);
+                    bh[1] = *reinterpret_cast<const half8 *>(xb + PP_HH * PP_XROW_B);
                     if constexpr (!SINGLE) {
                         bl[0] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B);
-                        bl[1] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B + PP_HH * 64);
+                        bl[1] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B + PP_HH * PP_XROW_B);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);

@@ -16,7 +16,15 @@ constexpr int PP_KGBLK_B = PP_COT * 16;                   // one (part, position
 constexpr int PP_TD = 4, PP_TH = 8, PP_TW = 8;
 constexpr int PP_HH = PP_TH + 2;
 constexpr int PP_ROWS = (PP_TD + 2) * PP_HH;              // 60 halo rows
-constexpr int PP_XPOS_B = PP_ROWS * 4 * 16;               // (part, position) block: 240 (row, pair) slots x 8 channels = 3840 B
+constexpr int PP_XPOS_B = PP_ROWS * 4 * 16;               // (part, position) block: 240 (pair, row) slots x 8 channels = 3840 B
+// Inside a (part, position) block the slots are PAIR-major: [output pair 0..3][halo row 0..59][8 channels] (r06).  A staging thread owns
+// (channel pair, row) and writes 4 bytes per (position, pair): with rows 16 bytes apart the 64 lanes of a wave (4 channel pairs x 16 rows)
+// cover 64 consecutive banks.  r05's row-major form ([row][pair]: rows 64 bytes apart) made every one of those stores a 4-way bank
+// conflict — ALL of the kernel's 17.3 M conflict cycles per launch, 28 % of its LDS-active cycles (profiles/NOTES_r06.md).  The
+// fragment reads (16 bytes per lane, lane = (row j >> 2, pair j & 3)) stay conflict-free: the 16 lanes the LDS serves together hold 4 rows
+// x 4 pairs, whose first banks (48 pair + 4 row) mod 64 are 16 different multiples of 4.
+constexpr int PP_XROW_B = 16;                             // halo row to halo row
+constexpr int PP_XPAIR_B = PP_ROWS * PP_XROW_B;           // output pair to output pair: 960 B
 constexpr int PP_XPART_B = 4 * PP_XPOS_B;
 constexpr int PP_XBUF_B = 2 * PP_XPART_B;                 // one 8-channel buffer: 30720 B
 constexpr int PP_EX_B = 4 * 6 * 64 * 16;                  // one team's exchange round: 24576 B
@@ -68,6 +76,14 @@ __device__ __forceinline__ void pp_buf_load_4x1(pp_u32x4 rsrc, unsigned o0, unsi
     asm volatile("s_nop 4\n\tbuffer_load_dword %0, %4, %8, 0 offen\n\tbuffer_load_dword %1, %5, %8, 0 offen\n\t"
                  "buffer_load_dword %2, %6, %8, 0 offen\n\tbuffer_load_dword %3, %7, %8, 0 offen"
                  : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(o0), "v"(o1), "v"(o2), "v"(o3), "s"(rsrc) : "memory");
+}
+
+__device__ __forceinline__ void pp_buf_load_1x4(pp_u32x4 rsrc, unsigned o0, f32x4 &r0) {
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, 0 offen" : "=&v"(r0) : "v"(o0), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ void pp_buf_load_2x1(pp_u32x4 rsrc, unsigned o0, unsigned o1, float &r0, float &r1) {
+    asm volatile("s_nop 4\n\tbuffer_load_dword %0, %2, %4, 0 offen\n\tbuffer_load_dword %1, %3, %4, 0 offen"
+                 : "=&v"(r0), "=&v"(r1) : "v"(o0), "v"(o1), "s"(rsrc) : "memory");
 }
 
 struct PpPeriod {   // what a 16-channel period of the K stream addresses (wave-uniform)

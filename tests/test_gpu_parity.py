@@ -387,9 +387,14 @@ def test_conv3d_half_products_follow_the_autocast_contract(ops, _libmod, dev, ca
 def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
     """model.G3d inside torch.autocast(float16) runs its F(2,3) convs with f16 operands (the reference's policy), everything else — and
     everything outside the region — as before.  Oracle: the restatement's G3d with conv3d_f16_operands on exactly the layers the library
-    reports the F(2,3) kernel for.  THE GATE: with those layers on conv3d_wino_f16_contract (the kernel's own rounding
-    points) the whole stack agrees to 1e-4 of max|y|; the r05 oracle (conv3d_f16_operands: x and g rounded, not t and u) stays beside it
-    at 1e-2 as a sanity bound.  The region must actually change the result."""
+    reports the F(2,3) kernel for.  THE GATE: those layers on conv3d_wino_f16_contract (the kernel's own rounding points).
+    One conv agrees with that contract to 2e-5 (test_conv3d_half_products_follow_the_autocast_contract); a STACK of 15 cannot be held to
+    1e-4, and not because of the kernel: the contract oracle evaluated twice — activations between the layers kept in float64 / in float32
+    (what the kernels exchange) — differs from ITSELF by ~7e-4 of max|y| on this case (an operand that sits within 1e-7 of an f16 rounding
+    boundary flips, the flip is a 5e-4 relative change of that operand, and GroupNorm + ReLU carry it on).  So the bar is calibrated in the
+    test: the kernel must be as close to the fp32-activation contract as the contract's two evaluations are to each other (x2, + 1e-4).
+    The r05 oracle (conv3d_f16_operands: x and g rounded, not t and u) stays beside it at 1e-2 as a sanity bound.  The region must
+    actually change the result."""
     from megaportrait_hack_amd import model as M
 
     monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
@@ -416,7 +421,8 @@ def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
         return F.conv3d(xx, w, b, padding=padding)
 
     monkeypatch.setattr(R, "CONV3D", conv_contract)
-    gate = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
+    gate64 = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
+    gate = R.g3d(x.float(), {k: v.float() for k, v in sd.items()}).double()
     monkeypatch.setattr(R, "CONV3D", F.conv3d)
     truth = R.g3d(x.double(), {k: v.double() for k, v in sd.items()})
     with torch.no_grad():
@@ -425,11 +431,13 @@ def test_g3d_under_autocast_uses_half_products(ops, _libmod, dev, monkeypatch):
             half = g(x.to(dev))
         plain2 = g(x.to(dev))
     scale = truth.abs().max().item()
-    print(f"relative to max|y|: autocast G3d vs the F(2,3) f16 contract {maxabs(half, gate) / scale:.2e} (gate 1e-4); vs the f16-operand oracle "
-          f"{maxabs(half, want) / scale:.2e}; that oracle vs fp64 {maxabs(want, truth) / scale:.2e}; default vs fp64 {maxabs(plain, truth) / scale:.2e}")
+    sens = (gate - gate64).abs().max().item() / scale        # the contract against itself: fp32 vs fp64 activations between the layers
+    print(f"relative to max|y|: autocast G3d vs the F(2,3) f16 contract {maxabs(half, gate) / scale:.2e} (the contract vs itself, fp32 / fp64 "
+          f"activations: {sens:.2e}; gate 2x that + 1e-4); vs the f16-operand oracle {maxabs(half, want) / scale:.2e}; that oracle vs fp64 "
+          f"{maxabs(want, truth) / scale:.2e}; default vs fp64 {maxabs(plain, truth) / scale:.2e}")
     assert half.dtype == torch.float32 and torch.equal(plain, plain2)
     assert maxabs(plain, truth) / scale < 1e-4
-    assert maxabs(half, gate) / scale < 1e-4
+    assert sens < 3e-3 and maxabs(half, gate) / scale < 2 * sens + 1e-4
     assert maxabs(half, want) / scale < 1e-2 and not torch.equal(half, plain)   # (sanity bound, not the gate)
 
 

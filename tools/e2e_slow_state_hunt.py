@@ -76,6 +76,19 @@ for r in range(rounds):
         print("  smi (right after):", smi(), flush=True)
         print("  stages:", stages(g, xs, xd), flush=True)
         print("  6 more steps:", steps(g, xs, xd, 6), flush=True)
+        # is it the hot-slice plan's side stream (fork / join across HIP streams)?  one-stream plan, then the per-op schedule, then back
+        g.overlap_generators = False
+        print("  one-stream plan (overlap_generators=False):", steps(g, xs, xd, 5), flush=True)
+        g.overlap_generators = True
+        print("  two-stream plan again (the cached one):", steps(g, xs, xd, 4), flush=True)
+        g.use_c_plan = False
+        print("  per-op Python schedule (use_c_plan=False):", steps(g, xs, xd, 5), flush=True)
+        g.use_c_plan = True
+        g.__dict__.pop("_plans", None)
+        print("  a NEW two-stream plan for the same instance:", steps(g, xs, xd, 5), flush=True)
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            print("  the same instance driven from another caller stream:", steps(g, xs, xd, 5), flush=True)
         time.sleep(3)
         print("  after a 3 s pause:", steps(g, xs, xd, 4), flush=True)
         g.__dict__.pop("_plans", None)   # the hot-slice plan (its streams, packs, workspace) is rebuilt by the next forward
