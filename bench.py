@@ -27,11 +27,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-# Two batches in flight = four HIP streams (two callers + their plans' side streams) next to the null stream.  The ROCm runtime
-# multiplexes streams onto 4 hardware queues by default, and a queue is in-order: one lane's side chain then waits behind the other
-# lane's convs (profiles/r03_timeline_two_in_flight.txt).  Eight queues give every stream its own (same box: 3.65 -> 3.55 ms/step).
-# Must be in the environment before the HIP runtime initialises; an explicit setting wins.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# GPU_MAX_HW_QUEUES is left at the ROCm runtime's default (4).  r03-r05 raised it to 8 here (every stream of two batches in flight on its
+# own hardware queue: +1.3 % on the headline, re-measured in r06: 3026 vs 3068 frames/s).  It is also what made `end_to_end_autocast_fp16`
+# read 71 instead of 118 frames/s in r05: with more queues than the device keeps resident for the process, a side stream that lands on
+# a queue which goes idle between steps pays a scheduling delay on every dispatch — 28 ms per Gbase.forward (profiles/NOTES_r06.md §1).
+# `--hw-queues N` / an explicit environment setting still selects it (before the HIP runtime starts).
+if "--hw-queues" in sys.argv[:-1]:
+    os.environ["GPU_MAX_HW_QUEUES"] = str(int(sys.argv[sys.argv.index("--hw-queues") + 1]))
 
 import torch
 
@@ -45,6 +47,9 @@ FINAL_CONV_FLOPS = 2.0 * 16 * 64 * 64 * 96 * 96 * 27   # G3d.final_conv per fram
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--hw-queues", type=int, default=0,
+                    help="GPU_MAX_HW_QUEUES for this process (0: the ROCm runtime's default of 4; 8 gives each stream of two batches in flight "
+                         "its own queue, +1.3 %% on the headline, at the price described at the top of this file)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (BASELINE config 2: 8)")

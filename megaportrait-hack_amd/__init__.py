@@ -7,11 +7,14 @@ import os as _os
 
 
 def request_hw_queues(n: int = 8) -> bool:
-    """Several batches in flight = one C-side plan per caller stream, two HIP streams each.  The ROCm runtime multiplexes streams onto 4
-    in-order hardware queues by default; with 8 every stream of two batches gets its own (same box: 3.65 -> 3.55 ms per step).  The
-    variable GPU_MAX_HW_QUEUES is read when the HIP runtime starts and is process-wide, so the package does NOT touch it on import
-    (ADVICE r4): an APPLICATION that wants several batches in flight calls this before its first HIP call (bench.py and the reenact
-    CLI do).  An explicit setting of the variable wins.  Returns True when the request can still take effect."""
+    """Opt-in, for a process whose ONLY GPU work is the hot slice with several batches in flight (one C-side plan per caller stream, two
+    HIP streams each).  The ROCm runtime multiplexes streams onto 4 in-order hardware queues by default; with 8 every stream of two
+    batches gets its own (same box, r06: 3026 -> 3068 frames/s, +1.3 %).  NOT for a process that also runs other work between hot-slice
+    calls (gbase.Gbase.forward, the reenact CLI, a training loop): with more queues than the device keeps resident a queue that goes idle
+    is re-scheduled with a delay on EVERY dispatch, and a plan whose side stream sits on such a queue turns its 36 dependent generator
+    launches into ~28 ms per call (r05's `end_to_end_autocast_fp16` 118 -> 71 frames/s; profiles/NOTES_r06.md §1).  Nothing in this
+    repository calls it any more (bench.py: `--hw-queues 8`).  GPU_MAX_HW_QUEUES is read when the HIP runtime starts and is process-wide;
+    an explicit setting of the variable wins.  Returns True when the request can still take effect."""
     import logging
     import sys
 

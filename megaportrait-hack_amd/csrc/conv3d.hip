@@ -634,6 +634,7 @@ static size_t gn_epilogue_bytes(int N, int Ci, int Co, int D, int H, int W, int 
     if (off || precision != 1 || k != 3 || !mphip_conv3d_supported(N, Ci, Co, D, H, W, k, precision)) return 0;
     const F16x3Plan fp = f16x3_plan(N, Ci, Co, D, H, W, false);
     if (fp.splits != 1) return 0;
+    if (fp.variant == 4 && D == 2) return 0;   // (the F(2,3) kernel's two-frame mode leaves no partials: separate statistics pass)
     if (plan_out) *plan_out = fp;
     return (size_t)fp.grid.x * f16x3_tile_waves(fp) * Co * 2 * sizeof(float) + 256;   // (+ the accumulator unscale behind the partials)
 }

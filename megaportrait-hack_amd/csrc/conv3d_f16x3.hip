@@ -1001,8 +1001,9 @@ F16x3Plan f16x3_plan(int N, int Ci, int Co, int D, int H, int W, bool roi) {
     (void)roi;
     // variant 4: the 1-D Winograd F(2,3) kernel (conv3d_f16x3_wino.hip; (4,8,8) tile, 2/3 of the MFMAs) on launches that fill the chip
     // (demand-driven launches follow the full launch's choice, so that the tiles they compute carry the same bits)
-    if (!force && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
-    const long tiles = (long)N * (D / p.td) * (H / 8) * (W / 8);
+    // (depth-2 volumes: the F(2,3) kernel's two-frame mode — not for demand-driven launches)
+    if (!force && !(roi && D == 2) && f16x3_wino_usable(N, Ci, Co, D, H, W)) p.variant = 4;
+    const long tiles = p.variant == 4 ? f16x3_wino_tiles(N, D, H, W) : (long)N * (D / p.td) * (H / 8) * (W / 8);
     const int nchunks = Ci / F16X3_KC;
     // split-K only when the launch cannot give every CU a workgroup (each split adds a slab write + a reduce pass): the largest
     // whole-chunk split that still fits the chip in ONE round of resident workgroups (one per CU; two for the 4-wave (2,8,8) kernel).
@@ -1168,7 +1169,7 @@ int f16x3_launch(const F16x3Plan &p, const float *x, const void *wpacked, const 
         roi = tile_list;
     }
     if (p.variant == 4) {   // the 1-D Winograd F(2,3) kernel (full launches and demand-driven ones alike: a listed tile carries the full launch's bits)
-        if (in_affine && Ci > 384) {
+        if (in_affine && Ci > 384 && D != 2) {
             set_error("conv3d_fwd(f16x3, F(2,3)): fused input GroupNorm supports Ci <= 384 (got %d)", Ci);
             return MPHIP_EINVAL;
         }

@@ -662,14 +662,21 @@ static bool wino_enabled() {   // dev: same-box A/B against the direct kernel (r
 size_t f16x3_wino_packed_bytes(int Co, int Ci) {
     static const bool nopack = getenv("MPHIP_WINOGRAD_PACK") && getenv("MPHIP_WINOGRAD_PACK")[0] == '0';   // dev: bisecting (process-wide: set before the first pack)
     if (nopack) return 0;
-    if (Ci % WN_KC || Co % WN_COT || Ci > WN_AFF_CI) return 0;
+    // (Ci <= 768: G3d's 2x8x8 level — 384 / 768 channels — takes the two-frame mode of the big-tile kernel, r06; the LDS table of the fused
+    //  input GroupNorm limits the 4-plane kernels to Ci <= 384 only when the norm is fused, checked at launch)
+    if (Ci % WN_KC || Co % WN_COT || Ci > 2 * WN_AFF_CI) return 0;
     return (size_t)(Co / WN_COT) * (Ci / WN_KC) * WN_NG * WN_SLAB_HALFS * sizeof(_Float16);
 }
 
 // split-K factor of a launch (whole chunks only): the largest divisor of the chunk count that keeps the launch inside ONE round of
 // resident workgroups (one per CU) — the direct kernel's r03 rule
+// tiles of a launch: 4 x 8 x 8 voxels of one frame, or — depth-2 volumes, conv3d_f16x3_wino_bt.hip's D2 mode — 2 x 8 x 8 voxels of TWO frames
+long f16x3_wino_tiles(int N, int D, int H, int W) {
+    return D == 2 ? (long)((N + 1) / 2) * (H / WN_TH) * (W / WN_TW) : (long)N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW);
+}
+
 int f16x3_wino_splits(int N, int Ci, int Co, int D, int H, int W) {
-    const long base = (long)N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW) * (Co / WN_COT);
+    const long base = f16x3_wino_tiles(N, D, H, W) * (Co / WN_COT);
     const int nchunks = Ci / WN_KC;
     int sp = 1;
     if (base < 256)
@@ -679,10 +686,16 @@ int f16x3_wino_splits(int N, int Ci, int Co, int D, int H, int W) {
 }
 
 bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W) {
-    if (!wino_enabled() || f16x3_wino_packed_bytes(Co, Ci) == 0 || D % WN_TD || H % WN_TH || W % WN_TW) return false;
+    const char *d2_env = getenv("MPHIP_WINOGRAD_D2");   // dev: same-box A/B of the two-frame mode against the direct kernel (read per call: tests flip it in-process)
+    const bool d2_off = d2_env && d2_env[0] == '0';
+    if (!wino_enabled() || f16x3_wino_packed_bytes(Co, Ci) == 0 || (D % WN_TD && (D != 2 || d2_off)) || H % WN_TH || W % WN_TW) return false;
+    // (two frames per tile: a single frame leaves half of every tile empty — B = 1, 768 -> 768: 31.6 us against the direct kernel's 28.8;
+    //  from B = 4, the training shard, the mode wins: tools/d2_check.py)
+    if (D == 2 && N < 4 && !getenv("MPHIP_WINOGRAD_MIN_TILES")) return false;
+    if (D != 2 && Ci > WN_AFF_CI) return false;   // (the 4-plane kernels keep r05's range: their launches may fuse the input GroupNorm through the LDS table)
     // one workgroup per CU, ~1 us per (kd,kh) slab: worth it when the launch (with its split-K factor) fills the chip and the direct
     // kernel's advantage — a 512-voxel tile's weight economy, thirds of a tile per CU — does not apply (measured: tools/wino_check.py)
-    const long tiles = (long)N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW);
+    const long tiles = f16x3_wino_tiles(N, D, H, W);
     const char *min_s = getenv("MPHIP_WINOGRAD_MIN_TILES");   // dev: threshold sweep
     const long min_wgs = min_s ? atol(min_s) : 192;
     return tiles * (Co / WN_COT) * f16x3_wino_splits(N, Ci, Co, D, H, W) >= min_wgs;
@@ -691,7 +704,7 @@ bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W) {
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
                       int H, int W, int splits, const float *in_affine, int in_relu, const float *x_range, hipStream_t s, const int *tile_list,
                       float *gn_part, hipEvent_t t0, hipEvent_t t1) {
-    const int tiles = N * (D / WN_TD) * (H / WN_TH) * (W / WN_TW), cots = Co / WN_COT;
+    const int tiles = (int)f16x3_wino_tiles(N, D, H, W), cots = Co / WN_COT;
     static const char *cus_s = getenv("MPHIP_CONV_CUS");   // dev: persistent grid size (leave CUs to another batch's small kernels)
     const long cus = cus_s ? atol(cus_s) : 256;
     long gx = (cus + cots * splits - 1) / (cots * splits);   // persistent: one workgroup per CU
@@ -704,6 +717,16 @@ int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const
     const bool pp_on = !(pp_env && pp_env[0] == '0');
     // MPHIP_WINO_PP: 0 the lockstep kernel (r04), 1 the role-split kernel (r05), 2 the big-tile kernel (r06: one wave per SIMD; bit-identical
     // to 1).  The one-product (autocast) arithmetic exists on the role-split schedule only.
+    if (D == 2) {   // the two-frame mode exists in the big-tile kernel only (three-product arithmetic; under the autocast policy as well:
+                    // this level is 4 % of the slice's multiplies)
+        if (tile_list || gn_part) {
+            set_error("conv3d_fwd(f16x3, F(2,3), D = 2): no demand-driven tile list / GroupNorm partials in the two-frame mode");
+            return MPHIP_EINVAL;
+        }
+        f16x3_wino_bt_launch(grid, s, t0, t1, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb, in_affine, in_relu, x_range,
+                             tiles, xcd_on, tile_list, gn_part);
+        return check_launch("conv3d_fwd(f16x3, F(2,3), big tile, two frames)");
+    }
     const bool bt_on = pp_env && pp_env[0] == '2' && !conv_half_products();
     if (bt_on) {
         f16x3_wino_bt_launch(grid, s, t0, t1, x, (const _Float16 *)slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb, in_affine, in_relu, x_range,

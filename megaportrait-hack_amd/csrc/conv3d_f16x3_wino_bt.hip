@@ -74,7 +74,12 @@ __device__ __forceinline__ void bt_for(F &&f) {
 
 // FUSE: the input GroupNorm (+ ReLU) is applied while staging (in_affine != nullptr) — a compile-time constant: a run-time flag costs the
 // single wave a branch (two issue slots) in every conversion piece.
-template <bool FUSE>
+// D2: volumes of depth 2 (G3d's 2x8x8 level, model.py:576-589) — a tile is TWO frames x 2 planes x 8 x 8: the wave's four planes are
+// (frame n: d 0, 1; frame n+1: d 0, 1), the six halo-plane slots hold [zero, n:d0, n:d1, zero, n+1:d0, n+1:d1] — plane t reads slots
+// tb[t] + kd with tb = {0, 1, 3, 4}; the one combination that would leave the buffer (t = 3, kd = 2: the zero plane above frame n+1) reads
+// slot 3, the other zero plane.  The fused-GroupNorm table of two frames does not fit the LDS: a thread loads its row's four values from
+// global memory with its halo (one more load per role and period).  No demand-driven tile list, no GroupNorm partials in this mode.
+template <bool FUSE, bool D2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
 conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__restrict__ wslabs, const float *__restrict__ whdr,
                                const float *__restrict__ bias, float *__restrict__ y, int N, int Ci, int Co, int D, int H, int W,
@@ -114,9 +119,9 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         int bid = tile_at(tj);
         const int tw = bid % tiles_w; bid /= tiles_w;
         const int th = bid % tiles_h; bid /= tiles_h;
-        const int td = bid % tiles_d;
-        r.n = bid / tiles_d;
-        r.d0 = td * PP_TD; r.h0 = th * PP_TH; r.w0 = tw * PP_TW;
+        if constexpr (D2) { r.n = 2 * bid; r.d0 = 0; }      // a tile = the frame pair (2 bid, 2 bid + 1)
+        else { r.n = bid / tiles_d; r.d0 = (bid % tiles_d) * PP_TD; }
+        r.h0 = th * PP_TH; r.w0 = tw * PP_TW;
         r.chunk = chunk; r.tj = tj;
         return r;
     };
@@ -129,6 +134,8 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     const unsigned long long xaddr = (unsigned long long)(uintptr_t)x;
     const pp_u32x4 rsrc = {(unsigned)xaddr, (unsigned)(xaddr >> 32) & 0xffffu, x_bytes, 0x00020000u};
     const unsigned chan_stride = (unsigned)DHW * 4u;
+    const unsigned long long aaddr = (unsigned long long)(uintptr_t)in_affine;
+    const pp_u32x4 rsrc_aff = {(unsigned)aaddr, (unsigned)(aaddr >> 32) & 0xffffu, (unsigned)((size_t)N * Ci * 2 * 4), 0x00020000u};
 
     // ---- X staging: thread = (channel pair cp of an 8-channel half, halo row); 240 of the 256 threads (the other 16 re-do row 59:
     // same loads, same values, same LDS addresses — branch-free).  Role 0 = the even half (buffer 0), role 1 = the odd half (buffer 1):
@@ -142,18 +149,23 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     float xl0[2], xr0[2], xl1[2], xr1[2];   // ... w0-1, w0+8
     float xmaxf_ = 0.0f;                    // max |scaled halo value| this thread staged (finite or Inf) ...
     bool xnan_ = false;                     // ... and whether it saw a NaN (v_max drops them)
+    unsigned t_row[2] = {OOB, OOB};         // (D2, fused) byte offset of the row's four table values ((scale, shift) of channels 2cp, 2cp+1)
     unsigned o_row[2] = {OOB, OOB};         // byte offset of (n, channel 2cp of the half, row, w0) of the unit being loaded, or OOB (padding rows)
     // ---- staging micro-operations: each is one piece of <= ~7 instructions that the step hangs behind one MFMA -----------------------------
     // (fused GroupNorm) per-role table values: (scale, shift) x operand scale S of channels 2cp / 2cp+1 for interior voxels [0..3] and for the
     // left / right edge voxels [4..11] (zero outside the volume: padding must stay 0 — max(0*x + 0, floor) = 0 for both floors, no select)
     float fcm[2][12];
+    f32x4 fsc[2];                   // the row's (scale, shift) pairs: read from the LDS table (prep 0) or, D2, loaded with the halo
     float wt0 = 0.0f, wt1 = 0.0f;   // the output-pair write in flight: the two channels' transformed value, then its lo remainders
     unsigned whv = 0;               // ... and the packed hi halves
     auto halo_addr = [&](const PpPeriod &s, auto ROLEc) __attribute__((always_inline)) {
         constexpr int role = decltype(ROLEc)::value;
-        const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
-        const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H;
-        o_row[role] = in ? (unsigned)((((long)s.n * Ci + s.chunk * 16 + role * 8 + 2 * cp) * DHW + (long)gd * HW + gh * W + s.w0) * 4) : OOB;
+        const int gh = s.h0 - 1 + shl;
+        int gd = s.d0 - 1 + sdl, fn = s.n;
+        if constexpr (D2) { fn = s.n + (sdl >= 3 ? 1 : 0); gd = (sdl % 3) - 1; }   // slots [zero, n:d0, n:d1, zero, n+1:d0, n+1:d1]
+        const bool in = (unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && fn < N;
+        o_row[role] = in ? (unsigned)((((long)fn * Ci + s.chunk * 16 + role * 8 + 2 * cp) * DHW + (long)gd * HW + gh * W + s.w0) * 4) : OOB;
+        if constexpr (D2 && FUSE) t_row[role] = in ? (unsigned)((((long)fn * Ci + s.chunk * 16 + role * 8 + 2 * cp) * 2) * 4) : OOB;
     };
     // LD 0 / 1: voxels w0..w0+3 / w0+4..w0+7 of channel 2cp (one 16-byte load each), 2 / 3: of channel 2cp+1, 4 / 5: the edge voxels w0-1, w0+8
     // of channel 2cp / 2cp+1 (two 4-byte loads).  One statement each: a VMEM instruction holds the wave's issue while the CU's address unit
@@ -163,7 +175,8 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         if (BT_ABL & 2) { asm volatile("" : "+v"(xa0[role]), "+v"(xb0[role]), "+v"(xa1[role]), "+v"(xb1[role]), "+v"(xl0[role]), "+v"(xr0[role]), "+v"(xl1[role]), "+v"(xr1[role])); return; }
         const bool in = o_row[role] != OOB;
         const unsigned o = o_row[role], o1 = in ? o + chan_stride : OOB;
-        if constexpr (ld == 0) pp_buf_load_1x4(rsrc, o, xa0[role]);
+        if constexpr (ld == 6) { if constexpr (D2 && FUSE) pp_buf_load_1x4(rsrc_aff, t_row[role], fsc[role]); }   // (out of the volume: zeros = padding stays 0)
+        else if constexpr (ld == 0) pp_buf_load_1x4(rsrc, o, xa0[role]);
         else if constexpr (ld == 1) pp_buf_load_1x4(rsrc, in ? o + 16u : OOB, xb0[role]);
         else if constexpr (ld == 2) pp_buf_load_1x4(rsrc, o1, xa1[role]);
         else if constexpr (ld == 3) pp_buf_load_1x4(rsrc, in ? o1 + 16u : OOB, xb1[role]);
@@ -179,15 +192,16 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     };
     // PREP 0: read the row's (scale, shift) pairs; 1 / 2: fold the operand scale S (a power of two: (x m + a) S == x (m S) + a S and
     // max(., 0) S == max(. S, 0) bit for bit) and the padding masks into them
-    f32x4 fsc[2];
     auto halo_prep = [&](const PpPeriod &s, auto ROLEc, auto Kc) __attribute__((always_inline)) {
         constexpr int role = decltype(ROLEc)::value, k = decltype(Kc)::value;
         if (!fuse_in || (BT_ABL & 1)) return;
         if constexpr (k == 0) {
-            fsc[role] = *reinterpret_cast<const f32x4 *>(aff + (s.chunk * 16 + role * 8 + 2 * cp) * 2);   // (scale, shift) of channel 2cp, then of 2cp+1
+            if constexpr (!D2) fsc[role] = *reinterpret_cast<const f32x4 *>(aff + (s.chunk * 16 + role * 8 + 2 * cp) * 2);   // (scale, shift) of channel 2cp, then of 2cp+1
         } else {
-            const int gd = s.d0 - 1 + sdl, gh = s.h0 - 1 + shl;
-            const float mid = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H) ? x_scale : 0.0f;
+            const int gh = s.h0 - 1 + shl;
+            int gd = s.d0 - 1 + sdl, fn = s.n;
+            if constexpr (D2) { fn = s.n + (sdl >= 3 ? 1 : 0); gd = (sdl % 3) - 1; }
+            const float mid = ((unsigned)gd < (unsigned)D && (unsigned)gh < (unsigned)H && fn < N) ? x_scale : 0.0f;
             if constexpr (k == 1) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) fcm[role][i] = fsc[role][i] * mid;
@@ -295,6 +309,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     const unsigned b_lane = (unsigned)(PP_LDS_X + p * PP_XPOS_B + (j & 3) * PP_XPAIR_B + (j >> 2) * PP_XROW_B);
     const unsigned b_row = b_lane + (unsigned)kgl * PP_XROW_B, b_plane = b_lane + (unsigned)kgl * (8u * PP_XROW_B),
                    b_buf = b_lane + (unsigned)kgl * (unsigned)(PP_XBUF_B - pp_rowoff(8) * PP_XROW_B);
+    const unsigned d2_k1 = 0u - (unsigned)(kgl * 3 * PP_HH * PP_XROW_B), d2_k0 = 0u - (unsigned)((1 - kgl) * 3 * PP_HH * PP_XROW_B);
     half8 ah[3], al[3], bh[4], bl[4];
     auto ld_a = [&](auto SPc, auto Mc, bool lo) __attribute__((always_inline)) -> half8 {   // weight fragment m of step sp
         constexpr int sp = decltype(SPc)::value, m = decltype(Mc)::value;
@@ -309,7 +324,12 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         constexpr unsigned off0 = (I0 / 9) * PP_XBUF_B + pp_rowoff(I0 % 9) * PP_XROW_B;
         constexpr unsigned off1 = (I1 / 9) * PP_XBUF_B + pp_rowoff(I1 % 9) * PP_XROW_B;
         static_assert(off1 - off0 == PP_XROW_B || off1 - off0 == 8 * PP_XROW_B || off1 - off0 == PP_XBUF_B - pp_rowoff(8) * PP_XROW_B, "k-group distance");
-        const unsigned char *const xb = smem + (off1 - off0 == PP_XROW_B ? b_row : off1 - off0 == 8 * PP_XROW_B ? b_plane : b_buf) + off0 + t * (PP_HH * PP_XROW_B);
+        constexpr int PLANE = PP_HH * PP_XROW_B;
+        constexpr int tb = D2 ? (t < 2 ? t : t + 1) : t;                        // first halo-plane slot of plane t
+        constexpr bool z0 = D2 && t == 3 && (I0 % 9) / 3 == 2, z1 = D2 && t == 3 && (I1 % 9) / 3 == 2;   // k-group 0 / 1 would read slot 6: slot 3 instead
+        const unsigned base = (off1 - off0 == PP_XROW_B ? b_row : off1 - off0 == 8 * PP_XROW_B ? b_plane : b_buf);
+        const unsigned corr = z0 == z1 ? 0u : z1 ? d2_k1 : d2_k0;             // (per lane only where the two k-groups differ)
+        const unsigned char *const xb = smem + (base + corr) + (int)(off0 + tb * PLANE) - (z0 && z1 ? 3 * PLANE : 0);
         return *reinterpret_cast<const half8 *>(xb + (lo ? PP_XPART_B : 0));
     };
 
@@ -318,7 +338,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     bool nxt_ok = per_total > 1;
     if (nxt_ok) nxt = period_next(cur);
     if (tid < PP_COT) reinterpret_cast<float *>(smem + PP_LDS_BIAS)[tid] = (gridDim.z == 1 && bias) ? bias[cot * PP_COT + tid] : 0.0f;
-    if (fuse_in) {
+    if (fuse_in && !D2) {
         load_aff(cur.n, tid, 256);
         aff_n = cur.n;
         lds_barrier();
@@ -328,7 +348,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
     dma_slab(std::integral_constant<int, 2>{}, wchunk(cur.chunk));
     bt_for<2>([&](auto R) {
         halo_addr(cur, R);
-        bt_for<6>([&](auto L) { halo_load(cur, R, L); });
+        bt_for<7>([&](auto L) { halo_load(cur, R, L); });
     });
     lds_dma_wait<0>();
     __builtin_amdgcn_sched_barrier(0);
@@ -366,7 +386,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
             // here: cur = the period being multiplied, nxt = its successor (if nxt_ok)
             const unsigned char *const wcur = wchunk(cur.chunk);
             const unsigned char *const wnxt = wchunk(nxt.chunk);
-            const bool reload_aff = fuse_in && nxt_ok && nxt.n != aff_n;   // (uniform)
+            const bool reload_aff = fuse_in && !D2 && nxt_ok && nxt.n != aff_n;   // (uniform)
             auto step = [&](auto SPc) __attribute__((always_inline)) {
                 constexpr int sp = decltype(SPc)::value;
                 constexpr int sn = (sp + 1) % 9;                       // the next step (of this or the next period): its fragments are prefetched
@@ -406,7 +426,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
                 auto vm = [&](auto SEGc, auto Ic) __attribute__((always_inline)) {
                     constexpr int seg = decltype(SEGc)::value, i = decltype(Ic)::value;
                     constexpr int piece = seg == 2 ? (i == 3 ? 0 : i == 7 ? 1 : i == 11 ? 2 : -1) : (i == 5 ? 3 : i == 8 ? 4 : i == 11 ? 5 : -1);
-                    constexpr int ld = seg == 2 ? (i == 5 ? 0 : i == 9 ? 1 : -1) : (i == 4 ? 2 : i == 6 ? 3 : i == 9 ? 4 : i == 10 ? 5 : -1);
+                    constexpr int ld = seg == 2 ? (i == 5 ? 0 : i == 9 ? 1 : -1) : (i == 4 ? 2 : i == 6 ? 3 : i == 9 ? 4 : i == 10 ? 5 : (i == 7 && D2 && FUSE) ? 6 : -1);
                     if constexpr (piece >= 0) dma_piece(std::integral_constant<int, (sp + 3) % 9>{}, std::integral_constant<int, (piece >= 0 ? piece : 0)>{}, wsrc);
                     if constexpr (ld >= 0 && sp == 0) halo_load(nxt, R0{}, std::integral_constant<int, (ld >= 0 ? ld : 0)>{});
                     if constexpr (ld >= 0 && sp == 3) halo_load(nxt, R1{}, std::integral_constant<int, (ld >= 0 ? ld : 0)>{});
@@ -425,11 +445,13 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
                 // ---------------- the step's wait + barrier: slab sp+1 (this wave's pieces, issued two steps ago) has landed; slab sp is dead.
                 // Younger than those pieces and left in flight: everything the previous step issued (its six pieces, its halo loads) and — in a
                 // tile's first two steps — the epilogue's stores.  (vmcnt's immediate is a constant; an under-estimate would only wait longer)
-                constexpr int hl_[9] = {8, 0, 0, 8, 0, 0, 0, 0, 0};                   // halo load instructions of a step: roles 0 (step 0) and 1 (step 3)
+                constexpr int HL1 = 8 + (D2 && FUSE ? 1 : 0);                          // (+ the row's table values in the two-frame mode)
+                constexpr int hl_[9] = {HL1, 0, 0, HL1, 0, 0, 0, 0, 0};               // halo load instructions of a step: roles 0 (step 0) and 1 (step 3)
                 constexpr int HP = hl_[(sp + 8) % 9];
                 if (BT_ABL & 64) {}
                 else if (sp < 2 && epi_stores == 48) lds_dma_wait<BT_PIECES + 48 + HP>();
                 else if (sp < 2 && epi_stores == 24) lds_dma_wait<BT_PIECES + 24 + HP>();
+                else if (sp < 2 && epi_stores == 12) lds_dma_wait<BT_PIECES + 12 + HP>();
                 else lds_dma_wait<BT_PIECES + HP>();
                 if (sp == 1) epi_stores = 0;
                 __builtin_amdgcn_sched_barrier(0);
@@ -495,7 +517,10 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         if (gn_part && etile == 0 && tid == 0) gn_part[(size_t)gn_rows * Co * 2] = unscale;   // (behind the partials)
         const bool odd = (lane & 1) != 0;
         // (this lane's QUAD of voxels: lanes 2k / 2k+1 store the 4 voxels 4k..4k+3 of a row, for different channels)
+        // (D2: plane pair = frame: pair 1 is frame en + 1, d = 0, 1 — absent when N is odd and this is the last tile)
         float *const ybase = (direct ? y : y + (size_t)blockIdx.z * N * Co * DHW) + ((size_t)en * Co + co0) * DHW + (size_t)ed0 * HW + (size_t)eh0 * W + ew0;
+        const size_t pair_stride = D2 ? (size_t)Co * DHW : (size_t)2 * HW;
+        const bool pair1_ok = !D2 || en + 1 < N;
         const unsigned yoff = (unsigned)(((8 * p + 4 * kgl + (odd ? 2 : 0)) * DHW + (j >> 2) * W + 2 * (j & 2)) * 4);
         auto rounds = [&](auto Pc) __attribute__((always_inline)) {
             constexpr int P = decltype(Pc)::value;
@@ -557,9 +582,11 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
 #undef BT_SWAP
                         const f32x4 va = {odd ? g0 : y0[0], odd ? g1 : y1[0], odd ? y0[2] : g0, odd ? y1[2] : g1};
                         const f32x4 vb = {odd ? g2 : y0[1], odd ? g3 : y1[1], odd ? y0[3] : g2, odd ? y1[3] : g3};
-                        unsigned char *const dq = reinterpret_cast<unsigned char *>(ybase + (size_t)(m * 32 + tz) * DHW + (size_t)(2 * pair + tt) * HW);   // (uniform)
-                        *reinterpret_cast<f32x4 *>(dq + yoff) = va;
-                        *reinterpret_cast<f32x4 *>(dq + (size_t)DHW * 4 + yoff) = vb;
+                        unsigned char *const dq = reinterpret_cast<unsigned char *>(ybase + (size_t)(m * 32 + tz) * DHW + pair * pair_stride + (size_t)tt * HW);   // (uniform)
+                        if (pair == 0 || pair1_ok) {
+                            *reinterpret_cast<f32x4 *>(dq + yoff) = va;
+                            *reinterpret_cast<f32x4 *>(dq + (size_t)DHW * 4 + yoff) = vb;
+                        }
                     }
                     if (gn_part) {
                         // per-channel (sum, sum of squares) of the RAW transformed accumulators over this wave's 2 x 64 voxels of the channel and
@@ -594,7 +621,7 @@ conv3d_k3_f16x3_wino_bt_kernel(const float *__restrict__ x, const _Float16 *__re
         case 2: rounds(std::integral_constant<int, 2>{}); break;
         default: rounds(std::integral_constant<int, 3>{}); break;
         }
-        epi_stores = gn_part ? 48 : 24;
+        epi_stores = gn_part ? 48 : pair1_ok ? 24 : 12;   // (an odd batch's last tile stores one frame only: counted, an over-estimate would end a wait early)
 #ifdef MPHIP_BT_PROFILE
         prof_epi += bt_memtime() - prof_e0;
 #endif
@@ -634,16 +661,17 @@ void f16x3_wino_bt_launch(dim3 grid, hipStream_t s, hipEvent_t t0, hipEvent_t t1
                           const float *bias, float *dst, int N, int Ci, int Co, int D, int H, int W, int cps, unsigned xb,
                           const float *in_affine, int in_relu, const float *x_range, int tiles, int xcd_on, const int *tile_list,
                           float *gn_part) {
-#define BT_LAUNCH(F_)                                                                                                                          \
+#define BT_LAUNCH(F_, D_)                                                                                                                      \
     {                                                                                                                                          \
         if (t0 && t1)                                                                                                                          \
-            hipExtLaunchKernelGGL(conv3d_k3_f16x3_wino_bt_kernel<F_>, grid, dim3(256), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, \
-                                  cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                                    \
+            hipExtLaunchKernelGGL((conv3d_k3_f16x3_wino_bt_kernel<F_, D_>), grid, dim3(256), 0, s, t0, t1, 0, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, \
+                                  W, cps, xb, in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                                 \
         else                                                                                                                                   \
-            hipLaunchKernelGGL(conv3d_k3_f16x3_wino_bt_kernel<F_>, grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb,      \
+            hipLaunchKernelGGL((conv3d_k3_f16x3_wino_bt_kernel<F_, D_>), grid, dim3(256), 0, s, x, slabs, hdr, bias, dst, N, Ci, Co, D, H, W, cps, xb,   \
                                in_affine, in_relu, x_range, tiles, xcd_on, tile_list, gn_part);                                                \
     }
-    if (in_affine) BT_LAUNCH(true) else BT_LAUNCH(false)
+    if (D == 2) { if (in_affine) BT_LAUNCH(true, true) else BT_LAUNCH(false, true) }
+    else if (in_affine) BT_LAUNCH(true, false) else BT_LAUNCH(false, false)
 #undef BT_LAUNCH
 }
 

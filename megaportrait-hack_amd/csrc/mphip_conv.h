@@ -61,6 +61,7 @@ int f16x3_tile_waves(const F16x3Plan &p);
 size_t f16x3_wino_packed_bytes(int Co, int Ci);
 bool f16x3_wino_usable(int N, int Ci, int Co, int D, int H, int W);
 int f16x3_wino_splits(int N, int Ci, int Co, int D, int H, int W);
+long f16x3_wino_tiles(int N, int D, int H, int W);   // tiles of a launch (a depth-2 volume: one tile = two frames)
 int f16x3_wino_saturation(unsigned long long *count, int reset);
 int f16x3_wino_launch(const float *x, const void *slabs, const float *hdr, const float *bias, float *dst, int N, int Ci, int Co, int D,
                       int H, int W, int splits /* f16x3_wino_splits: dst = [splits] slabs when > 1 */, const float *in_affine, int in_relu,

@@ -518,20 +518,12 @@ class _HotSliceRunner:
         if pl is None:
             pl = _plan.HotSlicePlan(self, dims=tuple(vs.shape[1:]), single_stream=not self.overlap_generators,
                                     full_final_conv=self.full_final_conv)
-            if len(table) >= 1 and int(os.environ.get("GPU_MAX_HW_QUEUES", "4") or 4) < 8 and not _HotSliceRunner._warned_queues:
-                _HotSliceRunner._warned_queues = True
-                logging.warning("mphip: several batches in flight (one plan per caller stream = 2 HIP streams each) but GPU_MAX_HW_QUEUES=%s: "
-                                "the ROCm runtime multiplexes streams onto that many in-order hardware queues, so one batch's generator chain "
-                                "waits behind another's convs (measured: 3.65 -> 3.55 ms per step with 8).  Export GPU_MAX_HW_QUEUES=8 before "
-                                "the HIP runtime starts (importing megaportrait_hack_amd before the first CUDA call does it).",
-                                os.environ.get("GPU_MAX_HW_QUEUES", "unset (4)"))
         table[key] = pl   # (most recently used last)
         while len(table) > self._MAX_PLANS:   # a caller that keeps making new streams must not keep every plan's packed weights
             torch.cuda.synchronize(vs.device)
             table.pop(next(iter(table))).close()
         return pl
 
-    _warned_queues = False
     _MAX_PLANS = 6
 
     @_autocast_policy

@@ -194,5 +194,4 @@ def main(argv=None) -> int:
 
 
 if __name__ == "__main__":
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # (this process is the application: one hardware queue per stream, see request_hw_queues)
     sys.exit(main())

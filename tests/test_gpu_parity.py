@@ -332,6 +332,76 @@ def test_conv3d_f16x3_winograd_role_split_and_lockstep_schedules_agree(ops, dev,
     assert maxabs(out["1"][2], out["0"][2].cpu().double()) < 4e-6 * max(truth_gn.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("case", ROLE_SPLIT_CASES + [(8, 384, 384, 4, 16, 16), (2, 96, 192, 8, 32, 32)], ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_f16x3_winograd_big_tile_kernel_is_bitwise_the_role_split_one(ops, dev, case, monkeypatch):
+    """r06's third schedule of the F(2,3) conv (conv3d_f16x3_wino_bt.hip, MPHIP_WINO_PP=2: one wave per SIMD, 96 x 128 accumulators, both
+    staging roles in every thread) keeps the role-split kernel's accumulation order per output element: outputs, GroupNorm statistics
+    and fused-GroupNorm-input results must be torch.equal — full launches, split-K, a single period, several frames per workgroup."""
+    N, Ci, Co, D, H, W = case
+    monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
+    x = R.seeded_tensor((N, Ci, D, H, W), 471, scale=1.7).to(dev)
+    pc = ops.PackedConv(R.seeded_tensor((Co, Ci, 3, 3, 3), 472, scale=(Ci * 27) ** -0.5).to(dev), R.seeded_tensor((Co,), 473, scale=0.1).to(dev))
+    g, be = (R.seeded_tensor((Ci,), 474, scale=0.3) + 1.0).to(dev), R.seeded_tensor((Ci,), 475, scale=0.2).to(dev)
+    groups = 32 if Ci % 32 == 0 else 16
+    st_in = ops.groupnorm_stats(x, groups)
+    out = {}
+    for pp in ("1", "2"):
+        monkeypatch.setenv("MPHIP_WINO_PP", pp)
+        y, st = ops.conv3d(x, pc, precision=1, gn_groups=32)
+        out[pp] = (y, st, ops.conv3d_gn_in(x, st_in, g, be, groups, pc))
+    monkeypatch.delenv("MPHIP_WINO_PP")
+    for a, b in zip(out["1"], out["2"]):
+        a, b = (a[0], b[0]) if isinstance(a, tuple) else (a, b)
+        assert torch.equal(a, b)
+
+
+D2_CASES = [(8, 384, 768, 8, 8), (8, 768, 768, 8, 8), (8, 768, 384, 8, 8), (8, 384, 384, 8, 8), (3, 96, 96, 8, 16), (1, 96, 192, 16, 8), (5, 192, 96, 8, 8)]
+
+
+@pytest.mark.parametrize("case", D2_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv3d_f16x3_winograd_two_frame_mode_at_depth_2(ops, _libmod, dev, case, monkeypatch):
+    """G3d's 2x8x8 level (model.py:576-589: ResBlock3D(384,768), ResBlock3D(768,384)) in the F(2,3) domain ("a D = 2 form of
+    the fast conv"): the big-tile kernel's two-frame mode — a tile = two frames x 2 x 8 x 8, halo-plane slots [zero, n:d0, n:d1, zero,
+    n+1:d0, n+1:d1].  Against float64 it must be fp32-class (<= 2e-5 of max|y|, <= 2x the exact-fp32 MFMA kernel's error) plain and with
+    the input GroupNorm + ReLU fused (its table comes from global memory per halo row in this mode), for even and odd batches (the
+    last tile of an odd batch has one frame), split-K launches, and agree with the direct f16x3 kernel (MPHIP_WINOGRAD_D2=0) to that
+    class; the GroupNorm statistics of the output come from the separate pass and must agree too."""
+    N, Ci, Co, H, W = case
+    monkeypatch.setenv("MPHIP_WINOGRAD_MIN_TILES", "1")
+    lib = _libmod.load()
+    x = R.seeded_tensor((N, Ci, 2, H, W), 481, scale=1.7)
+    wt = R.seeded_tensor((Co, Ci, 3, 3, 3), 482, scale=(Ci * 27) ** -0.5)
+    bias = R.seeded_tensor((Co,), 483, scale=0.1)
+    pc = ops.PackedConv(wt.to(dev), bias.to(dev))
+    truth = F.conv3d(x.double(), wt.double(), bias.double(), padding=1)
+    g, be = R.seeded_tensor((Ci,), 484, scale=0.3) + 1.0, R.seeded_tensor((Ci,), 485, scale=0.2)
+    truth_gn = F.conv3d(F.relu(F.group_norm(x.double(), 32, g.double(), be.double(), 1e-5)), wt.double(), bias.double(), padding=1)
+    xd = x.to(dev)
+    st_in = ops.groupnorm_stats(xd, 32)
+    out = {}
+    for d2 in ("1", "0"):
+        monkeypatch.setenv("MPHIP_WINOGRAD_D2", d2)
+        assert (lib.mphip_conv3d_kernel_variant(N, Ci, Co, 2, H, W, 3, 1) == 5) == (d2 == "1")
+        y, st = ops.conv3d(xd, pc, precision=1, gn_groups=32)
+        out[d2] = (y, st, ops.conv3d_gn_in(xd, st_in, g.to(dev), be.to(dev), 32, pc))
+    monkeypatch.delenv("MPHIP_WINOGRAD_D2")
+    e32 = maxabs(ops.conv3d(xd, pc, precision=0), truth)
+    top, top_gn = truth.abs().max().item(), truth_gn.abs().max().item()
+    for d2 in ("1", "0"):
+        assert maxabs(out[d2][0], truth) < 2 * e32 + 1e-6 and maxabs(out[d2][0], truth) < 2e-5 * top, d2
+        gn_out = out[d2][2][0] if isinstance(out[d2][2], tuple) else out[d2][2]
+        assert maxabs(gn_out, truth_gn) < 2e-5 * max(top_gn, 1.0), d2
+    assert maxabs(out["1"][0], out["0"][0].cpu().double()) < 4e-6 * max(top, 1.0)
+    assert maxabs(out["1"][1], out["0"][1].cpu().double()) < 1e-5
+    # bwd-data of this level is the same launch on the transposed pack
+    dy = R.seeded_tensor((N, Co, 2, H, W), 486, scale=3e-3)
+    xg = x.clone().requires_grad_(True)
+    F.conv3d(xg, wt, None, padding=1).backward(dy)
+    _, sc = ops.grad_prep(dy.to(dev), want_bias=False)
+    dx = ops.conv3d_bwd_data(dy.to(dev), ops.PackedConv(wt.to(dev), None, transposed=True), sc)
+    assert maxabs(dx, xg.grad.double()) < 2e-5 * xg.grad.abs().max().item()
+
+
 HALF_CASES = [(1, 96, 96, 16, 64, 64), (8, 192, 192, 8, 32, 32), (2, 96, 192, 8, 32, 32)]
 
 
@@ -1219,6 +1289,28 @@ def test_bench_two_ranks_over_rccl():
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == 2 and line["scaling"] == "weak"
     assert line["config"]["global_batch"] == 16 and line["value"] > 0
+
+
+def test_end_to_end_autocast_leg_has_a_floor():
+    """the `end_to_end_autocast_fp16` leg of the bench line (gbase.Gbase.forward under torch.autocast(float16), B = 8) read 114
+    frames/s in r04 and 71 in r05.  Root cause (profiles/NOTES_r06.md §1): GPU_MAX_HW_QUEUES=8, which bench.py / the reenact CLI used to
+    request — a plan whose side stream landed on a hardware queue that goes idle between steps paid a scheduling delay on each of its 36
+    dependent generator launches, +28 ms per step; which plan did depended on the legs run before.  Nothing in the repository raises the
+    variable any more.  This test runs the legs of the slow sequence (a graphed training step, then the fp32 leg) in a fresh process with
+    the default environment and holds the autocast leg to >= 100 frames/s (68 ms per step = 118 measured)."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import os, sys, json, torch; sys.path.insert(0, %r); import bench; dev = torch.device('cuda:0'); "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; bench.train_leg(dev, autocast=True); bench.end_to_end(dev, 8, steps=3, warmup=1); "
+            "assert 'GPU_MAX_HW_QUEUES' not in os.environ; print('LEG ' + json.dumps(bench.end_to_end(dev, 8, steps=5, warmup=2, fp16=True)))" % root)
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    leg = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("LEG ")][-1][4:])
+    print("end_to_end_autocast_fp16:", leg["value"], "frames/s,", leg["ms_per_step"], "ms per step")
+    assert leg["value"] >= 100.0, leg
 
 
 def test_bench_line_contract_on_one_gpu():
