@@ -247,7 +247,8 @@ def test_hot_kernels_have_no_scratch():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import register_table
 
-    table = register_table.collect(["conv3d_f16x3_wino.hip", "conv3d_f16x3_wino_pp.hip", "conv3d_f16x3.hip", "conv3d_bwd_f16x3.hip", "warp.hip"])
+    table = register_table.collect(["conv3d_f16x3_wino.hip", "conv3d_f16x3_wino_pp.hip", "conv3d_f16x3_wino_bt.hip", "conv3d_f16x3.hip", "conv3d_bwd_f16x3.hip",
+                                    "warp.hip"])
     kernels = {k["demangled"]: k for t in table.values() for k in t["kernels"]}
     hot = [n for n in kernels if any(s in n for s in ("conv3d_k3_f16x3_wino_kernel", "conv3d_k3_f16x3_kernel", "conv3d_k3_f16x3_third_kernel",
                                                        "conv3d_k1_f16x3_kernel", "conv_bwd_weight_f16x3_kernel", "conv_bwd_weight_k1_f16x3_kernel",
@@ -259,6 +260,13 @@ def test_hot_kernels_have_no_scratch():
     for name in ("conv3d_k3_f16x3_wino_kernel", "conv3d_k3_f16x3_wino_pp_kernel"):
         wino = next(k for n, k in kernels.items() if name in n)
         assert wino["group_segment_fixed_size"] <= 160 * 1024 and wino["vgpr_count"] <= 256
+    # the big-tile kernel (r06: the two-frame mode of G3d's 2x8x8 level; MPHIP_WINO_PP=2): one wave per SIMD = 512 registers, four
+    # instantiations (fused input norm x two-frame mode), none with scratch
+    bt = [k for n, k in kernels.items() if "conv3d_k3_f16x3_wino_bt_kernel" in n]
+    assert len(bt) == 4
+    for k in bt:
+        assert k["group_segment_fixed_size"] <= 160 * 1024 and k["vgpr_count"] <= 512 and k["max_flat_workgroup_size"] == 256, k
+        assert k.get("private_segment_fixed_size", 0) == 0 and k.get("vgpr_spill_count", 0) == 0, k
 
 
 def test_role_split_conv_hand_issued_memory_ops_are_padded_and_unspilled(monkeypatch):
@@ -309,3 +317,62 @@ def test_role_split_conv_hand_issued_memory_ops_are_padded_and_unspilled(monkeyp
         bad = [ln for ln in body.splitlines() if re.match(r"\s+v_(mov_b32|mov_b64|pk_mov_b32|accvgpr_write)", ln) and
                any(re.search(r", v%d$" % r, ln.strip()) for r in loop_dest)]
         assert not bad, bad[:5]
+
+
+def test_big_tile_conv_hand_issued_memory_ops_are_padded_and_counted(monkeypatch):
+    """conv3d_f16x3_wino_bt.hip (one wave per SIMD) issues its LDS-DMA pieces and halo loads as inline assembly, ONE per statement, each hung
+    behind its own MFMA, and orders them with counted s_waitcnt.  Checked on the disassembly of all four instantiations: (1) every
+    hand-issued vector-memory statement opens with `s_nop 4`; (2) no compiler-generated instruction touches M0; (3) no spill, no scratch;
+    (4) the step loop issues exactly what the counted waits assume — per nine-step period 54 LDS-DMA pieces and, per role, the halo loads
+    of one unit (8 instructions; 9 in the fused two-frame mode: the row's table values) — and no compiler-visible vector load at all (hipcc
+    would wait vmcnt(0) for it in the middle of the MFMA stream); (5) the MFMAs of a step are not separated by more than a handful of
+    instructions (the single wave's issue slots are what bounds this kernel: profiles/NOTES_r06.md)."""
+    import re
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    monkeypatch.setenv("MPHIP_KEEP_ASM", "1")
+    import register_table
+
+    t = register_table.one(os.path.join(register_table.CSRC, "conv3d_f16x3_wino_bt.hip"))
+    ks = [k for k in t["kernels"] if "wino_bt_kernel" in k["name"]]
+    assert len(ks) == 4
+    asm = t["asm"]
+    for k in ks:
+        assert k.get("vgpr_spill_count", 0) == 0 and k.get("private_segment_fixed_size", 0) == 0, k
+        m = re.search(r"wino_bt_kernelILb([01])ELb([01])E", k["name"])
+        fused, d2 = m.group(1) == "1", m.group(2) == "1"
+        start = asm.index(k["name"] + ":")
+        body = asm[start:asm.index(".Lfunc_end", start)]
+        blocks = re.findall(r";;#ASMSTART\n(.*?);;#ASMEND", body, flags=re.S)
+        vmem = [b for b in blocks if "buffer_load" in b or "global_load_lds" in b]
+        for b in vmem:
+            lines = [ln.strip() for ln in b.splitlines() if ln.strip()]
+            assert lines[0] == "s_nop 4", b
+            assert sum(1 for ln in lines if ln.startswith(("buffer_load", "global_load_lds"))) <= 2, b   # (one per statement; the 4-byte edge loads go in pairs)
+        outside = re.sub(r";;#ASMSTART\n.*?;;#ASMEND", "", body, flags=re.S)
+        assert not re.search(r"\bm0\b", outside), [ln for ln in outside.splitlines() if re.search(r"\bm0\b", ln)][:3]
+        # the step loop: the blocks hipcc marks as loop members that contain MFMAs
+        loop_lines, in_loop = [], False
+        for ln in body.splitlines():
+            if re.match(r"\.LBB\d+_\d+:", ln):
+                in_loop = "Loop" in ln
+            elif in_loop and ln.startswith("\t") and not ln.strip().startswith((";", ".")):
+                loop_lines.append(ln.strip())
+        n_mfma = sum(1 for ln in loop_lines if ln.startswith("v_mfma"))
+        assert n_mfma == 9 * 36, n_mfma
+        first, last = next(i for i, ln in enumerate(loop_lines) if ln.startswith("v_mfma")), max(i for i, ln in enumerate(loop_lines) if ln.startswith("v_mfma"))
+        steps = loop_lines[first:last + 1]
+        tail = loop_lines[first:]                     # (+ what hangs behind the last MFMA, and the tile's epilogue: stores only)
+        # 54 pieces of the nine slabs; the fused 4-plane mode also re-loads its LDS table by LDS-DMA (one wave, up to three pieces)
+        assert sum(1 for ln in tail if ln.startswith("global_load_lds")) == 54 + (3 if fused and not d2 else 0)
+        n_halo = sum(1 for ln in tail if ln.startswith("buffer_load_dword"))
+        assert n_halo == 2 * (9 if (fused and d2) else 8), (k["name"], n_halo)
+        assert not any(ln.startswith(("global_load_dword", "flat_load", "scratch_")) for ln in steps)
+        gaps, run = [], 0
+        for ln in steps:
+            if ln.startswith("v_mfma"):
+                gaps.append(run); run = 0
+            else:
+                run += 1
+        assert sorted(gaps)[len(gaps) // 2] <= 4 and sum(gaps) / len(gaps) < 6.0, (sorted(gaps)[len(gaps) // 2], sum(gaps) / len(gaps))

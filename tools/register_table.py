@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "megaportrait-hack_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-S", "--cuda-device-only", "-o", "-"]
-EXTRA = {"conv3d_f16x3_wino_pp.hip": ["-fno-slp-vectorize"]}   # (mirrors csrc/build.sh)
+EXTRA = {"conv3d_f16x3_wino_pp.hip": ["-fno-slp-vectorize"], "conv3d_f16x3_wino_bt.hip": ["-fno-slp-vectorize"]}   # (mirrors csrc/build.sh)
 KEYS = (".vgpr_count", ".agpr_count", ".sgpr_count", ".vgpr_spill_count", ".sgpr_spill_count", ".private_segment_fixed_size",
         ".group_segment_fixed_size", ".max_flat_workgroup_size")
 
