@@ -206,7 +206,7 @@ def pmc_record(name, sources):
 
 def pmc_traffic(wino):
     """HBM bytes per launch of the dominant kernel from the committed PMC passes, or (None, stale)."""
-    rec, stale = pmc_record("r05_pmc_conv.json", ["conv3d_f16x3_wino_pp.hip" if wino else "conv3d_f16x3.hip", "mphip_f16x3.h"])
+    rec, stale = pmc_record("r06_pmc_conv.json", ["conv3d_f16x3_wino_pp.hip", "mphip_wino_tile.h", "mphip_f16x3.h"] if wino else ["conv3d_f16x3.hip", "mphip_f16x3.h"])
     if rec is None:
         return None, stale
     try:
@@ -372,7 +372,7 @@ def roofline_hbm(hot, inp, B):
     ("faithful") fields of this batch and for a smooth field that travels through the whole volume ("smooth": the
     stress case — the reference's fields only ever sample the 4^3 low corner).
     achieved = ALGORITHMIC bytes (K2 53.5 MB, K3 29.9 MB per frame) / time; `traffic` = counter bytes per launch from the
-    committed rocprofv3 --pmc passes (profiles/r05_pmc_warps.json, B=8), `counter_GBps` = traffic / this run's time."""
+    committed rocprofv3 --pmc passes (profiles/r06_pmc_warps.json, B=8), `counter_GBps` = traffic / this run's time."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_warps as BW
 
@@ -380,7 +380,7 @@ def roofline_hbm(hot, inp, B):
         w_s2c = hot.warp_generator_s2c(inp["Rs"], inp["ts"], inp["zs"], inp["es"])
     table = {"faithful": w_s2c, "smooth": BW.fields(B)["smooth"]}
     res = BW.measure(B, iters=20, quiet=True, field_override=table)
-    rec_, stale = pmc_record("r05_pmc_warps.json", ["warp.hip"])   # (counters are quoted only when stamped with this build's warp.hip)
+    rec_, stale = pmc_record("r06_pmc_warps.json", ["warp.hip"])   # (counters are quoted only when stamped with this build's warp.hip)
     pmc = rec_.get("kernels", {}) if rec_ else {}
     out = {}
     for key, rec in res.items():

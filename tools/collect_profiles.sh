@@ -1,9 +1,9 @@
 #!/bin/bash
 # Collects the round's evidence on a GPU box into gpurun_out/profiles_rNN/ — every JSON it writes carries the commit it was run at and the
 # sha256 of the kernel sources it measured; bench.py quotes counters only when those stamps match the sources of the build.
-# usage (from the build container):  gpurun -- "COMMIT=$(git rev-parse HEAD) ROUND=r05 bash tools/collect_profiles.sh"
+# usage (from the build container):  gpurun -- "COMMIT=$(git rev-parse HEAD) ROUND=r06 bash tools/collect_profiles.sh"
 cd $GRAFT_REPO_ROOT
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
 export TMPDIR=/tmp
 stamp() {   # stamp <json file> <source files...>: adds _commit / _sources (sha256) to a JSON object in place
@@ -40,12 +40,16 @@ rm -rf $out/kt
 python bench.py --no-cpu-baseline --extras-budget 30 --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${R}_bench_line_same_box_as_trace.json
 # 3. SQ / HBM counters of the dominant conv (the F(2,3) kernel; separate passes, MI355X_MICROARCH.md)
 bash tools/pmc_conv.sh $out/pmc_conv conv3d_k3_f16x3_wino_pp_kernel > $out/pmc_conv.log 2>&1
-cp $out/pmc_conv/conv_pmc.json $out/${R}_pmc_conv.json && stamp $out/${R}_pmc_conv.json conv3d_f16x3_wino_pp.hip mphip_f16x3.h
+cp $out/pmc_conv/conv_pmc.json $out/${R}_pmc_conv.json && stamp $out/${R}_pmc_conv.json conv3d_f16x3_wino_pp.hip mphip_wino_tile.h mphip_f16x3.h
 rm -rf $out/pmc_conv
 # 4. HBM counters of K2 / K3 (B = 8)
 bash tools/pmc_warps.sh $out/pmc_warps 8 > $out/pmc_warps.log 2>&1
 python tools/pmc_warps_profile.py $out/pmc_warps/summary.json $out/${R}_pmc_warps.json > /dev/null && stamp $out/${R}_pmc_warps.json warp.hip
 rm -rf $out/pmc_warps
+# 4b. the three F(2,3) schedules side by side (SQ / LDS counters), the two-frame mode at G3d's 2x8x8 level, the big-tile kernel's check
+bash tools/pmc_bt.sh $out/pmc_bt > $out/${R}_pmc_schedules.txt 2>&1; rm -rf $out/pmc_bt
+python tools/d2_check.py 2>&1 | grep -v amdgpu > $out/${R}_two_frame_mode.txt
+python tools/bt_check.py 2>&1 | grep -v amdgpu > $out/${R}_big_tile_check.txt
 # 5. batch sweep through the plan, one generator alone
 python tools/bench_plan.py 2>&1 | grep -v amdgpu > $out/${R}_plan_vs_perop.txt
 python tools/bench_generator.py 2>&1 | grep -v amdgpu > $out/${R}_generator.txt
