@@ -394,7 +394,7 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
                 if (sp == 0 && pet_) { pe_[6] += pt1_ - pet_; pet_ = 0; }
 #endif
                 // An LDS-DMA piece needs ~1 us to land under load (MI355X_MICROARCH.md "ldsdma-fill"): this step's pieces (slab sp+2) are issued
-                // FIRST and waited for at the END of the wave's next LOAD phase — two full phases plus a LOAD body later; that phase's barrier
+                // early in the phase (right behind its fragment reads) and waited for at the END of the wave's next LOAD phase — two full phases later; that phase's barrier
                 // publishes them one phase before their first reader.
                 const bool issue = !(sp == 0 && pre2) && gp * 9 + sp + 2 < s_total;
                 auto dma = [&]() __attribute__((always_inline)) {
@@ -406,8 +406,6 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
 #if PP_PRIO == 3
                 __builtin_amdgcn_s_setprio(1);
 #endif
-                dma();
-                __builtin_amdgcn_sched_barrier(0);
                 if (!(PP_ABL & 32) || gp == 0) {
                     constexpr int I0 = 2 * sp, I1 = 2 * sp + 1;
                     constexpr unsigned off0 = (I0 / 9) * PP_XBUF_B + pp_rowoff(I0 % 9) * PP_XROW_B;
@@ -427,6 +425,11 @@ conv3d_k3_f16x3_wino_pp_kernel(const float *__restrict__ x, const _Float16 *__re
                         bl[1] = *reinterpret_cast<const half8 *>(xb + PP_XPART_B + PP_HH * PP_XROW_B);
                     }
                 }
+                __builtin_amdgcn_sched_barrier(0);
+                // (r06: the fragment reads — what the next MFMA phase waits for — go out first, the LDS-DMA pieces behind them: the four
+                //  waves of a team reach this point together, and twelve 16-byte-per-lane VMEM instructions hold the address unit ~190 cycles.
+                //  Same box, three interleaved rounds: 0.457 / 0.461 / 0.462 ms with the pieces first, 0.456 / 0.455 / 0.458 ms so.)
+                dma();
                 __builtin_amdgcn_sched_barrier(0);
                 // Halo staging, one slice per LOAD phase.  In the team's own count ts (A: ts = step; B starts at step 4: ts = step - 4 mod 9):
                 //   ts 0, 1, 2: load part 0 (channel 2cp), part 1 (channel 2cp+1), part 2 (the four edge voxels)

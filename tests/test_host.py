@@ -59,10 +59,11 @@ def test_argument_validation_needs_no_gpu(lib):
     assert lib.mphip_packed_weight_bytes(3, 32, 3, 0) == 27 * 32 * 32 * 4     # Co padded to 32
     assert lib.mphip_packed_weight_bytes(7, 5, 3, 0) == 27 * 6 * 32 * 4       # Ci padded to even
     assert lib.mphip_packed_weight_bytes(4, 4, 2, 0) == 0
-    # f16x3: header + f16 hi/lo planes of the 27 taps + (Ci <= 384: layers that can meet the F(2,3) kernel) the hi/lo planes of its
-    # 9 x 4 transformed taps
+    # f16x3: header + f16 hi/lo planes of the 27 taps + (Ci <= 768: layers that can meet an F(2,3) kernel — up to 384 channels the 4-plane
+    # kernels, up to 768 the two-frame mode of G3d's 2x8x8 level, r06) the hi/lo planes of its 9 x 4 transformed taps
     assert lib.mphip_packed_weight_bytes(96, 96, 3, 1) == 16 + 27 * 96 * 96 * 2 * 2 + 36 * 96 * 96 * 2 * 2
-    assert lib.mphip_packed_weight_bytes(96, 768, 3, 1) == 16 + 27 * 96 * 768 * 2 * 2
+    assert lib.mphip_packed_weight_bytes(96, 768, 3, 1) == 16 + 27 * 96 * 768 * 2 * 2 + 36 * 96 * 768 * 2 * 2
+    assert lib.mphip_packed_weight_bytes(96, 1536, 3, 1) == 16 + 27 * 96 * 1536 * 2 * 2
     assert lib.mphip_packed_weight_bytes(3, 32, 3, 1) == 0                     # f16x3 needs Co%96, Ci%16
     assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 3, 1) == 1
     assert lib.mphip_conv3d_supported(8, 96, 96, 16, 64, 64, 1, 1) == 1     # r02: the k=1 split-f16 GEMM kernel
