@@ -58,16 +58,7 @@ __device__ unsigned long long g_f16x3_prof[8];
 #define PROF_FLUSH
 #endif
 
-#ifdef MPHIP_ABL_LOMASK  /* dev (energy probe): low mantissa bits of the lo halves zeroed — do the cross-term MFMAs draw less power? */
-#define F16X3_LO_MASK(lv_) { unsigned u_ = __builtin_bit_cast(unsigned, lv_) & (MPHIP_ABL_LOMASK); lv_ = __builtin_bit_cast(half2v, u_); }
-#else
-#define F16X3_LO_MASK(lv_)
-#endif
-#ifdef MPHIP_NO_SAT_GUARD  /* dev: same-box A/B of the range guard's cost */
-#define F16X3_SAT_COUNT(a_, b_)
-#else
 #define F16X3_SAT_COUNT(a_, b_) sat_ += !(fabsf((a_) * x_scale) <= F16_CLAMP) + !(fabsf((b_) * x_scale) <= F16_CLAMP);  /* NaN counts */
-#endif
 
 // ---- weight packing ----------------------------------------------------------------------------
 // header (16 B): [0] inv_scale (float)  [1] scale (float)  [2] max|w| bits (uint)  [3] unused
@@ -152,9 +143,6 @@ f16x3_pack_body(const float *__restrict__ w, _Float16 *__restrict__ out, const u
             const float v = transposed ? tile[ci * pitch + co * 27 + (26 - tap)] : tile[co * pitch + ci * 27 + tap];
             _Float16 h, l;
             split_f16(v * scale, h, l);
-#ifdef MPHIP_ABL_LOMASK
-            l = __builtin_bit_cast(_Float16, (unsigned short)(__builtin_bit_cast(unsigned short, l) & (unsigned short)(MPHIP_ABL_LOMASK)));
-#endif
             hi[e] = h; lo[e] = l;
         }
         const size_t slab = ((size_t)cot * nchunks + chunk) * F16X3_NG + g;
@@ -363,7 +351,6 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
         split_f16(v0_ * x_scale, h0_, l0_);                                                       \
         split_f16(v1_ * x_scale, h1_, l1_);                                                       \
         half2v hv_ = {h0_, h1_}, lv_ = {l0_, l1_};                                                \
-        F16X3_LO_MASK(lv_)                                                                        \
         *reinterpret_cast<half2v *>(Xs + dst_) = hv_;                                             \
         *reinterpret_cast<half2v *>(Xs + X_PART + dst_) = lv_;                                    \
     }
@@ -480,7 +467,6 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
 
     for (int c = c_begin; c < c_end; ++c) {
         const bool more = c + 1 < c_end;
-#ifndef MPHIP_ABL_NOX
         if (more) {
             F16X3_LOAD_X(c + 1);
         } else if (has_next) {
@@ -490,12 +476,10 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
             if (fuse_in && n != aff_n) load_aff();
             F16X3_LOAD_X(c_begin);
         }
-#endif
         PROF_ADD(1)
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
             // stream the next group of slabs while this one is consumed
-#ifndef MPHIP_ABL_NOW
             if (g < NGRP - 1) {
                 F16X3_DMA_W(c, g + 1, wb ^ 1);
             } else if (more) {
@@ -503,15 +487,10 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
             } else if (has_next) {
                 F16X3_DMA_W(c_begin, 0, wb ^ 1);  // the next tile's first slab (weights do not depend on the tile)
             }
-#endif
             PROF_ADD(2)
             const _Float16 *wsb = Ws + wb * W_BUF + a_base;
             const int gt = ((g + 1) * GS <= F16X3_NG ? GS : F16X3_NG - g * GS) * F16X3_TG;  // taps in this group
-#ifdef MPHIP_ABL_NOMFMA
-#define F16X3_MFMA(a_, b_, c_) (c_)
-#else
 #define F16X3_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
-#endif
 #ifndef MPHIP_F16X3_OLD_FRAGS
             // Fragment schedule: per tap the three products run as  P1 = Wlo*Xhi,  P2 = Whi*Xhi,  P3 = Whi*Xlo  (6 MFMAs = 192
             // MFMA cycles each).  Only the Xhi fragments are double buffered; every other fragment is loaded into the registers
@@ -537,10 +516,6 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
                     F16X3_LD_BL(tg)
                     if (tg + 1 < gt) { F16X3_LD_BH(cur ^ 1, tg + 1) }
                     __builtin_amdgcn_sched_barrier(0);  // the loads above stay above this tap's MFMAs
-#ifdef MPHIP_ABL_TAPS18  /* dev (timing only, wrong results): every third tap's MFMAs and fragment reads dropped = the matrix work of a
-                            1-D F(2,3) Winograd transform with TODAY's staging and weight stream (an optimistic bound) */
-                    if ((g * GT + tg) % 3 == 2) continue;
-#endif
 #pragma unroll
                     for (int m = 0; m < MT; ++m)
 #pragma unroll
@@ -558,10 +533,6 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
                         for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(ah[m], bl[t], acc[m][t]);
                 }
             }
-#ifdef MPHIP_ABL_NOMFMA
-            asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(bh[0][0]), "v"(bl[0]), "v"(ah[MT - 1]), "v"(al[MT - 1]), "v"(bh[1][NT - 1]),
-                         "v"(bl[NT - 1]));
-#endif
 #undef F16X3_TOFF
 #undef F16X3_WOFF
 #undef F16X3_LD_AH
@@ -606,10 +577,6 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
                     for (int t = 0; t < NT; ++t) acc[m][t] = F16X3_MFMA(ah[cur][m], bh[cur][t], acc[m][t]);
                 }
             }
-#ifdef MPHIP_ABL_NOMFMA
-            asm volatile("" ::"v"(ah[0][0]), "v"(al[0][0]), "v"(bh[0][0]), "v"(bl[0][0]), "v"(ah[1][MT - 1]), "v"(al[1][MT - 1]),
-                         "v"(bh[1][NT - 1]), "v"(bl[1][NT - 1]));
-#endif
 #undef F16X3_LOAD_FRAGS
 #endif
 #undef F16X3_MFMA
@@ -619,23 +586,13 @@ conv3d_k3_f16x3_body(const float *__restrict__ x, const _Float16 *__restrict__ w
             PROF_ADD(4)
             wb ^= 1;
         }
-#ifndef MPHIP_ABL_NOX
         if (more) {
             F16X3_WRITE_X(c + 1);  // every wave is past its last read of the X tile (barrier above)
-#ifdef MPHIP_ABL_X2  /* dev (timing only): the staging VALU + LDS-write work done twice (what a transformed-domain input tile costs) */
-            asm volatile("" : "+v"(tz)::"memory");
-            F16X3_WRITE_X(c + 1);
-#endif
             __syncthreads();
         } else if (has_next) {
             F16X3_WRITE_X(c_begin);  // the next tile's first halo chunk; its barrier doubles as the next tile's "prologue done"
-#ifdef MPHIP_ABL_X2
-            asm volatile("" : "+v"(tz)::"memory");
-            F16X3_WRITE_X(c_begin);
-#endif
             __syncthreads();
         }
-#endif
         PROF_ADD(5)
     }
 #undef F16X3_WRITE_X

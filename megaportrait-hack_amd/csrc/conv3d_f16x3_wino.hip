@@ -146,28 +146,12 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             return (unsigned)((((long)n * Ci + 2 * cp) * DHW + (long)gd * HW + gh * W + w0) * 4);
         return OOB;
     };
-#ifdef MPHIP_WN_ABL_NOXLOAD   /* dev (timing only, wrong results): the halo loads are issued out of range — no cache / memory access behind them */
-#define WN_ABL_XOFF(o__) (tiles_total > 0 ? OOB : (o__))
-#else
-#define WN_ABL_XOFF(o__) (o__)
-#endif
-#ifdef MPHIP_WN_ABL_NOXLOAD   /* ... and the registers get pseudo-random values instead (all-zero operands would also make the MFMAs cheaper) */
-#define WN_ABL_FAKE_X(chunk)                                                                               \
-    {                                                                                                      \
-        unsigned h_ = (unsigned)tid * 2654435761u + (unsigned)(chunk) * 40503u + (unsigned)d0 * 977u;      \
-        auto nx_ = [&]() { h_ = h_ * 1664525u + 1013904223u; return ((float)(h_ >> 8) * (1.0f / 8388608.0f) - 1.0f) * 2.0f; }; \
-        _Pragma("unroll") for (int k = 0; k < 4; ++k) { xa0[k] += nx_(); xb0[k] += nx_(); xa1[k] += nx_(); xb1[k] += nx_(); } \
-        xl0 += nx_(); xr0 += nx_(); xl1 += nx_(); xr1 += nx_();                                            \
-    }
-#else
-#define WN_ABL_FAKE_X(chunk)
-#endif
     f32x4 xa0, xb0, xa1, xb1;   // channels 2cp / 2cp+1: voxels w0..w0+3, w0+4..w0+7
     float xl0, xr0, xl1, xr1;   // ... w0-1, w0+8
 #define WN_LOAD_X(chunk)                                                                                   \
     {                                                                                                      \
         const unsigned soff_ = (unsigned)((long)(chunk) * WN_KC * DHW * 4);                                \
-        const unsigned o_ = WN_ABL_XOFF(row_off());                                                        \
+        const unsigned o_ = row_off();                                                        \
         const unsigned o1_ = o_ == OOB ? OOB : o_ + chan_stride;                                           \
         const bool lft_ = o_ != OOB && w0 > 0, rgt_ = o_ != OOB && w0 + WN_TW < W;                         \
         xa0 = buf_load_f4(rsrc, o_, soff_);                                                                \
@@ -178,16 +162,11 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         xr0 = buf_load_f(rsrc, rgt_ ? o_ + 32u : OOB, soff_);                                              \
         xl1 = buf_load_f(rsrc, lft_ ? o1_ - 4u : OOB, soff_);                                              \
         xr1 = buf_load_f(rsrc, rgt_ ? o1_ + 32u : OOB, soff_);                                             \
-        WN_ABL_FAKE_X(chunk)                                                                               \
     }
     unsigned xmax_ = 0;   // max |scaled halo value| this thread staged, as bits (NaN sorts above Inf above finite): beyond 2^15 the
                           // transformed values can leave the f16 range
     // registers -> (fused GroupNorm + ReLU) -> scale -> F(2,3) input transform -> split -> LDS
-#ifdef MPHIP_WN_ABL_NOWRITE   /* dev (timing only, wrong results): no halo transform / split / LDS stores */
-#define WN_STAGER_ON (stager && tiles_total < 0)
-#else
 #define WN_STAGER_ON stager
-#endif
     // All arithmetic on (channel 2cp, channel 2cp+1) PAIRS (f32x2): the pair is exactly the half2 a staging store writes, so scale,
     // transform and split run on v_pk_mul_f32 / v_pk_add_f32 / v_cvt_pk_f16_f32 — ~130 VALU instructions per thread and chunk instead of
     // ~560 with scalar conversions (the halo write was 21 % of a launch: profiles/r04_wino_ablations.txt).  Split: hi = rne(t), lo =
@@ -234,10 +213,6 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
     int dma_s = 0, dma_cg = c_begin * WN_NG;   // slabs issued so far; its (chunk*9 + group) index into the packed tensor
     const int cg_total = c_end * WN_NG;
     auto dma_issue = [&]() -> int {   // 3 pieces of 1 KiB per wave; returns the number of vector-memory instructions issued
-#ifdef MPHIP_WN_ABL_NODMA   /* dev (timing only, wrong results): no weight stream */
-        ++dma_s;
-        return 0;
-#endif
         if (dma_s >= s_total) return 0;
         const _Float16 *src = wsrc + (size_t)dma_cg * WN_SLAB_HALFS + wave * 512;
         const unsigned dst = ws_lds + (unsigned)(dma_s & (WN_RING - 1)) * (WN_SLAB_HALFS * 2) + (unsigned)wave * 1024u;
@@ -317,13 +292,7 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
             //   bottom   : wait for THIS wave's pieces of slab s+2 (issued one interval ago; younger transfers stay in flight),
             //              barrier s: slab s+2 published, slot of slab s free
 #define WN_TOFF(G) ((((G) / 3) * WN_HH + (G) % 3) * 32)
-#ifdef MPHIP_WN_ABL_NOMFMA   /* dev (timing only, wrong results): everything but the MFMAs */
-#define WN_MFMA(a_, b_, c_) (c_)
-#define WN_ABL_KEEP_FRAGS asm volatile("" ::"v"(ah[0]), "v"(ah[1]), "v"(ah[2]), "v"(al[0]), "v"(al[1]), "v"(al[2]), "v"(bl[0]), "v"(bl[1]), "v"(bh[0][0]), "v"(bh[0][1]), "v"(bh[1][0]), "v"(bh[1][1]));
-#else
-#define WN_ABL_KEEP_FRAGS
 #define WN_MFMA(a_, b_, c_) __builtin_amdgcn_mfma_f32_32x32x16_f16(a_, b_, c_, 0, 0, 0)
-#endif
 #ifdef MPHIP_WN_DMA_FIRST   /* dev: same-box A/B — r04's first order: DMA issue and fragment reads in front of the interval's first MFMAs */
 #define WN_INTERVAL(G)                                                                                                     \
     {                                                                                                                      \
@@ -354,7 +323,6 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
                 acc[m][t] = WN_MFMA(ah[m], bl[t], acc[m][t]);                      \
-        WN_ABL_KEEP_FRAGS                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         WPROF_ADD(1)                                                                                                       \
         /* younger than this wave's pieces of slab s+2: interval 2's halo prefetch (8) and this interval's pieces (3) */   \
@@ -403,7 +371,6 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         _Pragma("unroll") for (int m = 0; m < 3; ++m)                                                                      \
             _Pragma("unroll") for (int t = 0; t < 2; ++t)                                                                  \
                 acc[m][t] = WN_MFMA(ah[m], bl[t], acc[m][t]);                      \
-        WN_ABL_KEEP_FRAGS                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                                 \
         WPROF_ADD(1)                                                                                                       \
         /* younger than this wave's pieces of slab s+2: interval 2's halo prefetch (8) and this interval's pieces (3) */   \
@@ -493,7 +460,6 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
                 if (more && ch == 0) {
                     if (fuse_in) { WN_WRITE_X(c + 1, true) } else { WN_WRITE_X(c + 1, false) }
                 }
-                WN_ABL_KEEP_FRAGS
                 __builtin_amdgcn_sched_barrier(0);
                 WPROF_ADD(1)
                 if (issued_) lds_dma_wait<3>(); else lds_dma_wait<0>();
@@ -511,21 +477,6 @@ conv3d_k3_f16x3_wino_kernel(const float *__restrict__ x, const _Float16 *__restr
         }
 
         // ---- output transform + epilogue: three rounds (one 32-channel row tile each) through the dead X region ---------------------
-#ifdef MPHIP_WN_ABL_NOEPI   /* dev (timing only, wrong results): no output transform / stores */
-        if (tiles_total > 0) {
-#pragma unroll
-            for (int m = 0; m < 3; ++m)
-#pragma unroll
-                for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(acc[m][t]));
-            if (has_next) {
-                if (fuse_in) { WN_WRITE_X(c_begin, true) } else { WN_WRITE_X(c_begin, false) }
-                lds_barrier();
-#pragma unroll
-                for (int t = 0; t < 2; ++t) bh[0][t] = *reinterpret_cast<const half8 *>(Xs + b_base[t]);
-            }
-            continue;
-        }
-#endif
         const int gn_rows = tiles_total * 2;   // channel-major [Co][tile * 2 + ch][2] (the finalize kernel reads rows of it)
         if (gn_part && etile == 0 && tid == 0) gn_part[(size_t)gn_rows * Co * 2] = unscale;   // (behind the partials)
         const bool odd = (lane & 1) != 0;

@@ -1,15 +1,13 @@
 // Every compile-time switch that changes what a kernel COMPUTES (timing-only ablations: wrong results by design) or adds
 // instrumentation to it, in one place.  The product build (build.sh) defines none of them; dev variants are built by
-// tools/build_variant.sh / tools/k2_ablate.sh into build_variants/ and never replace libmphip.so.  A translation unit that is compiled
+// tools/build_variant.sh / tools/k2_ablate.sh into build_variants/ and never replace libmphip.so.  (r06: the ablations of the r02-r04 kernels
+// — MPHIP_ABL_* of the direct conv, MPHIP_WN_ABL_* of the lockstep F(2,3) conv — were deleted from the sources; what they measured is in
+// profiles/NOTES_r01-r04.md.  The generated code of those two translation units is unchanged, instruction for instruction.)  A translation unit that is compiled
 // with any ablation ON leaves a marker in the library: mphip_build_flags() reports it and the Python loader (_lib.py) REFUSES such a
 // library unless MPHIP_ALLOW_ABLATED=1 is set (the dev tools set it) — a timing variant cannot become the product by a stray MPHIP_LIB.
 //
 //  switch                                         | file                       | effect (timing only unless noted)
 //  -----------------------------------------------+----------------------------+---------------------------------------------------------
-//  MPHIP_ABL_NOX / _NOW / _NOMFMA                 | conv3d_f16x3.hip           | direct conv without X staging / weight DMA / MFMAs
-//  MPHIP_ABL_TAPS18 / _X2 / _LOMASK=mask          | conv3d_f16x3.hip           | 18 of 27 taps / X tile staged twice / lo halves masked (energy probe)
-//  MPHIP_WN_ABL_NOMFMA / _NODMA / _NOWRITE /      | conv3d_f16x3_wino.hip      | lockstep F(2,3) conv without MFMAs / weight DMA / halo LDS writes /
-//    _NOEPI / _NOXLOAD                            |                            | output transform + stores / halo global loads
 //  PP_ABL=bitmask                                 | conv3d_f16x3_wino_pp.hip   | role-split F(2,3) conv: 1 no halo convert + LDS writes, 2 no halo loads, 4 no
 //                                                 |                            | weight DMA, 8 no epilogue, 16 no MFMAs, 32 no fragment reads, 128 no LDS stores,
 //                                                 |                            | 512 no output stores, 1024 12 of 18 MFMAs per step (the 2-D F(2x2,3x3) bound)
@@ -33,10 +31,7 @@
 #define BT_ABL 0
 #endif
 
-#if defined(MPHIP_ABL_NOX) || defined(MPHIP_ABL_NOW) || defined(MPHIP_ABL_NOMFMA) || defined(MPHIP_ABL_TAPS18) || defined(MPHIP_ABL_X2) || \
-    defined(MPHIP_ABL_LOMASK) || defined(MPHIP_WN_ABL_NOMFMA) || defined(MPHIP_WN_ABL_NODMA) || defined(MPHIP_WN_ABL_NOWRITE) ||            \
-    defined(MPHIP_WN_ABL_NOEPI) || defined(MPHIP_WN_ABL_NOXLOAD) || defined(MPHIP_K2_ABL_NOSTAGE) || defined(MPHIP_K2_ABL_NOLOOP) ||         \
-    defined(MPHIP_K2_ABL_NOSTORE) || (PP_ABL != 0) || (BT_ABL != 0)
+#if defined(MPHIP_K2_ABL_NOSTAGE) || defined(MPHIP_K2_ABL_NOLOOP) || defined(MPHIP_K2_ABL_NOSTORE) || (PP_ABL != 0) || (BT_ABL != 0)
 #define MPHIP_ABLATED 1
 // (weak: every ablated translation unit may define it; api.hip tests for its presence)
 extern "C" __attribute__((weak, visibility("default"))) int mphip_ablated_build_marker = 1;
