@@ -65,6 +65,14 @@ def tag_range(t: torch.Tensor, rng: Optional[torch.Tensor]) -> torch.Tensor:
     return t
 
 
+# Module-global state: `_capture_epoch`, `_repack_always` / `_repack_token`, `_weight_epoch`, `_conv_hook`, `_default_precision`
+# are PROCESS-wide on purpose — a capture's forward runs on the caller's thread and its backward on autograd's device thread, and both
+# must see the same "this is a capture" state (a thread-local would hide it from the backward's pack lookups).  The counters are bumped
+# under a lock; the flags are configuration of the process: one capture at a time (torch.cuda.graph is not re-entrant either), hooks and
+# the default precision set before the threads that launch are started.
+import threading as _threading
+
+_state_lock = _threading.Lock()
 _capture_epoch = 0
 
 
@@ -72,7 +80,8 @@ def begin_capture() -> None:
     """Called by GraphedHotSlice / training.GraphedTrainStep right before `torch.cuda.graph(...)`: descriptors noted during an
     earlier capture (or during warm-up) are not trusted inside the new one."""
     global _capture_epoch
-    _capture_epoch += 1
+    with _state_lock:
+        _capture_epoch += 1
 
 
 def tensor_range(t: torch.Tensor) -> Optional[torch.Tensor]:
@@ -409,8 +418,9 @@ class repack_always:
 
     def __enter__(self):
         global _repack_always, _repack_token
-        self._old, _repack_always = _repack_always, True
-        _repack_token += 1
+        with _state_lock:
+            self._old, _repack_always = _repack_always, True
+            _repack_token += 1
 
     def __exit__(self, *exc):
         global _repack_always
@@ -522,7 +532,8 @@ def invalidate_packs() -> None:
     torch.no_grad(): p.copy_(...)`) bump `_version` and need nothing.  training.GraphedTrainStep calls this after
     every replay."""
     global _weight_epoch
-    _weight_epoch += 1
+    with _state_lock:
+        _weight_epoch += 1
 
 
 def weight_epoch() -> int:
