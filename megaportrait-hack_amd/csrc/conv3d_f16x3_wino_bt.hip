@@ -2,32 +2,34 @@
 // conv3d_f16x3_wino.hip / conv3d_f16x3_wino_pp.hip: same arithmetic, same packed weights, same 4x8x8-voxel tile, same LDS map, and the
 // SAME accumulation order per output element — its results are bit-identical to the role-split kernel's (tests hold them torch.equal).
 //
-// Why (r06): the role-split kernel's LOAD side, not the matrix pipe, bounds it — a phase lasts ~845 cycles for 576 of
-// MFMAs, and the no-MFMA ablation still takes 0.342 of the launch's 0.456 ms.  What the LOAD side moves is LDS bytes: each of its eight
-// waves multiplies a 96 x 64 tile (M = 96 output channels, N = 2 planes x 32 output pairs) and re-reads (96 + 64) x 16 x 2 B x (hi, lo)
-// = 10 KB of fragments per K = 16 step — 80 KB per workgroup and step, plus the 24 KB slab the LDS-DMA writes: 104 KB at the LDS's
-// 128 B/clk = 810 of the 1152 cycles the step's MFMAs need, all of it squeezed into the half of the time in which a team is NOT
-// multiplying.  The two waves of a SIMD (same Winograd position, different plane pairs) read the SAME weight fragments: 48 of the
-// 80 KB are that duplication.
-//
-// Here a workgroup is 4 waves (one per SIMD, 512 registers each), wave = Winograd position, and a wave owns all four planes of the
-// tile: 96 x 128 accumulators (192 registers), fragments (96 + 128) x 16 x 4 B = 14 KB per step and wave, 56 KB per workgroup (-30 %),
-// and nothing is squeezed: with one wave per SIMD the overlap of loads and MFMAs is software pipelining inside the wave.
+// Why (r06): the role-split kernel's LOAD side, not the matrix pipe, bounds it.  Each of its eight waves multiplies a
+// 96 x 64 tile (M = 96 output channels, N = 2 planes x 32 output pairs) and re-reads (96 + 64) x 16 x 2 B x (hi, lo) = 10 KB of fragments per
+// K = 16 step — 80 KB per workgroup and step, 48 KB of it the SAME weight fragments read by the two waves of a SIMD (same Winograd
+// position, different plane pairs).  Here a workgroup is 4 waves (one per SIMD, 512 registers each), wave = Winograd position, and a wave
+// owns all four planes of the tile: 96 x 128 accumulators (192 AGPRs), 14 KB of fragments per step and wave, 56 KB per workgroup (-30 %),
+// one barrier per step instead of four; with one wave per SIMD the overlap of loads and MFMAs is software pipelining inside the wave.
+// MEASURED (profiles/NOTES_r06.md 3): bit-identical and SLOWER than the role-split kernel on the 4-plane launches (0.504 vs 0.444-0.452 ms):
+// a single wave cannot hide its own issue stalls.  It is the default only of the TWO-FRAME MODE (D2 below: G3d's 2x8x8 level);
+// MPHIP_WINO_PP=2 selects it elsewhere.
 //
 // Step s (K = 16: two (8-channel chunk, (kd,kh) tap) items, exactly the role-split kernel's K loop), per wave:
-//      P1(s) = Wlo x Xhi | wait, BARRIER(s), issue | P2(s) = Whi x Xhi | P3(s) = Whi x Xlo          (12 MFMAs each)
+//      P1(s) = Wlo x Xhi | counted wait, BARRIER(s) | P2(s) = Whi x Xhi | P3(s) = Whi x Xlo          (12 MFMAs each)
 // ONE fragment register set; every fragment is re-loaded in the segment after its last use, a full segment (>= 384 cycles) ahead of its
 // next one:   during P1(s): Whi(s), Xlo(s)      during P2(s): Wlo(s+1)      during P3(s): Xhi(s+1).
 // So slab s is read from P2(s-1) to P1(s) and is dead at BARRIER(s); slab s+1 must be visible there.  After the barrier a wave issues
-// its six LDS-DMA pieces of slab s+3 into the slot of slab s (ring of 3) and waits for them just before BARRIER(s+2): two full steps
-// (> 2300 cycles) to land.  One barrier per step instead of the role-split kernel's four.
+// its six LDS-DMA pieces of slab s+3 into the slot of slab s (ring of 3), ONE per slot and >= 2 MFMAs apart, and waits for them just
+// before BARRIER(s+2).
 //
-// X staging (the role-split kernel's 8-channel double buffer, both halves done by every thread as two "roles"):
-//   buffer 0 (even chunk of the NEXT period): read until P1(4), next read P3(8): loads after BARRIER 0/1/2, normalise + scale in steps
-//            2/3/4, the four output pairs written in steps 4-7 (P2 / P3 segments);
-//   buffer 1 (odd chunk): read from P3(3) to P1(8): loads after BARRIER 4/5/6, normalise in steps 6/7/8, pairs written in the P1 segments
-//            of steps 0-3 of the next period (after the tile's epilogue, which uses buffer 1 as an exchange region, like team B there).
-// Every slice is cut into pieces of <= 8 instructions hung behind one MFMA each (pinned with sched_barrier: hipcc clusters otherwise).
+// X staging (the role-split kernel's 8-channel double buffer and pair-major image; both halves done by every thread as two "roles" with
+// their own register sets):
+//   role 0 -> buffer 0 (even chunk of the NEXT period; read until P1(4), next read P3(8)): loads in step 0, table prep in step 2,
+//            conversion in step 3, the four output pairs written in steps 4-7;
+//   role 1 -> buffer 1 (odd chunk; read from P3(3) to P1(8)): loads in step 3, prep in step 5, conversion in steps 6-7, pair 0 written in
+//            step 8 and pairs 1-3 in steps 0-2 of the period the data belongs to.
+// Every slice is cut into micro-operations of <= 7 instructions hung behind one MFMA each of P2 / P3 (pinned with sched_barrier: hipcc
+// clusters otherwise), nothing is conditional (a branch costs the single wave two issue slots), P1 carries the fragment reads only, so
+// that no LDS operation is young at the barrier.  The tile's epilogue goes through ONE exchange region (buffer 1 already holds the next
+// period's first pair): six rounds (row tile x plane pair).
 #include <stdlib.h>
 
 #include <type_traits>
